@@ -1,0 +1,157 @@
+/*
+ * ohs_hip.h -- C ABI of the MI355X-native binaural convolution core.
+ *
+ * Drop-in boundary for Open-Headstage's `src/dsp` hot path.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * repository).  The reference host is Rust; the binding a maintainer adds is in
+ * INTEGRATION.md (extern "C" block + a shim keeping `ConvolutionEngine` /
+ * `StereoParametricEQ` source-compatible with src/lib.rs).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `int` status, 0 == OHS_OK; nothing throws
+ *     or unwinds across this boundary.
+ *   - one handle == one thread at a time (the reference takes `&mut self`,
+ *     convolution.rs:111,141; parametric_eq.rs:144,166).
+ *   - the library owns device memory; the caller owns every host buffer, which
+ *     need only stay valid for the duration of the call.
+ *   - engine / eq / chain calls are blocking: outputs are complete on return.
+ *   - there is NO CPU fallback: without a usable HIP device every create call
+ *     fails with OHS_ERR_NO_DEVICE.
+ *   - audio is planar f32, as nih-plug hands it to Plugin::process
+ *     (src/lib.rs:1175-1177).
+ */
+#ifndef OHS_HIP_H
+#define OHS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OHS_BLOCK_SIZE 512   /* src/dsp/convolution.rs:22 BLOCK_SIZE */
+#define OHS_FFT_SIZE   1024  /* src/dsp/convolution.rs:23 FFT_SIZE   */
+#define OHS_MAX_EQ_BANDS 64  /* num_bands is the caller's choice (parametric_eq.rs:132); the plugin uses 10 (lib.rs:40) */
+
+/* status codes */
+enum {
+    OHS_OK = 0,
+    OHS_ERR_INVALID_ARG = 1,
+    OHS_ERR_NO_DEVICE = 2,        /* no HIP device / runtime unusable: no CPU fallback exists */
+    OHS_ERR_HIP = 3,              /* a HIP runtime call failed; see ohs_last_error() */
+    OHS_ERR_OUTSIDE_NYQUIST = 4,  /* biquad::Errors::OutsideNyquist (the reference unwrap()s: parametric_eq.rs:111) */
+    OHS_ERR_NEGATIVE_Q = 5,       /* biquad::Errors::NegativeQ */
+    OHS_ERR_ALLOC = 6
+};
+
+/* ConvolutionPath discriminants -- src/dsp/convolution.rs:28-33.
+ * L/R speaker -> l/r ear; out_l = Lsl + Rsl, out_r = Lsr + Rsr (:228-231). */
+enum { OHS_PATH_LSL = 0, OHS_PATH_LSR = 1, OHS_PATH_RSL = 2, OHS_PATH_RSR = 3 };
+
+/* FilterType discriminants -- src/dsp/parametric_eq.rs:23-35 (also the CLAP enum values). */
+enum {
+    OHS_FILTER_PEAK = 0, OHS_FILTER_LOWSHELF = 1, OHS_FILTER_HIGHSHELF = 2, OHS_FILTER_LOWPASS = 3,
+    OHS_FILTER_HIGHPASS = 4, OHS_FILTER_BANDPASS = 5, OHS_FILTER_NOTCH = 6, OHS_FILTER_ALLPASS = 7
+};
+
+/* ---- library ---------------------------------------------------------------- */
+int         ohs_version(void);               /* (major<<16)|(minor<<8)|patch */
+const char *ohs_status_string(int status);
+const char *ohs_last_error(void);            /* thread-local detail of the last failure */
+int         ohs_device_count(int *count);    /* OHS_ERR_NO_DEVICE if the runtime is unusable */
+
+/* Diagnostic: `batch` natural-order complex DFT-1024s (interleaved re,im; host pointers) through the
+ * wavefront FFT primitive -- the device counterpart of rustfft's `Fft::process`
+ * (convolution.rs:129,255,276): unnormalised, forward = e^{-2 pi i jk/N}. */
+int         ohs_debug_fft1024(int device, const float *in, float *out, int inverse, size_t batch);
+
+/* ---- ConvolutionEngine  (src/dsp/convolution.rs:68-295) ---------------------- */
+typedef struct ohs_engine ohs_engine;
+
+/* ConvolutionEngine::new()  convolution.rs:87-108.  Four default paths, each one
+ * all-zero partition => silence (:46-63). */
+int  ohs_engine_create(int device, ohs_engine **out);
+/* #[derive(Clone)]  convolution.rs:68 -- deep copy of IR spectra, history, overlap, FIFOs. */
+int  ohs_engine_clone(const ohs_engine *src, ohs_engine **out);
+/* Drop */
+void ohs_engine_destroy(ohs_engine *e);
+/* ConvolutionEngine::set_ir(&mut self, path, &[f32])  convolution.rs:111-139.
+ * len == 0 => one zero partition (mute, :114-118); else ceil(len/512) partitions,
+ * each chunk zero-padded to 1024 and forward-transformed (:120-132); resets THAT
+ * path's history, history index and overlap (:135-138); FIFOs untouched. */
+int  ohs_engine_set_ir(ohs_engine *e, int path, const float *ir, size_t len);
+/* ConvolutionEngine::process_block(&mut self, in_l, in_r, out_l, out_r)
+ * convolution.rs:141-182.  All four slices have n elements.  Appends to the input
+ * FIFOs, runs every complete 512-block, pops n outputs, or fills zeros when fewer
+ * than n are available (:176-181). */
+int  ohs_engine_process_block(ohs_engine *e, const float *in_l, const float *in_r,
+                              float *out_l, float *out_r, size_t n);
+/* engine.paths[p].ir_fft_partitions.len()  (asserted by the reference test, convolution.rs:395-399) */
+int  ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out);
+
+/* ---- StereoParametricEQ  (src/dsp/parametric_eq.rs:125-210) ------------------ */
+typedef struct ohs_eq ohs_eq;
+
+/* biquad::Coefficients::<f32>::from_params as called at parametric_eq.rs:64-70,105-111;
+ * out = {b0,b1,b2,a1,a2} normalised by a0.  gain_db is used by Peak/LowShelf/HighShelf only. */
+int  ohs_biquad_coeffs(int filter_type, float fs, float fc, float q, float gain_db, float out[5]);
+/* StereoParametricEQ::new(num_bands, fs)  parametric_eq.rs:132-142: every band
+ * PeakingEQ 0 dB @ 20 Hz Q 0.707, disabled (:63-76). */
+int  ohs_eq_create(int device, size_t num_bands, float fs, ohs_eq **out);
+void ohs_eq_destroy(ohs_eq *eq);
+/* update_band_coeffs(band_idx, sample_rate, &BandConfig)  parametric_eq.rs:144-164.
+ * band >= num_bands is ignored (returns OHS_OK).  State (s1,s2) is kept (:112). */
+int  ohs_eq_update_band(ohs_eq *eq, size_t band, float fs, int filter_type, float fc, float q,
+                        float gain_db, int enabled);
+/* Same, but the host supplies biquad-crate coefficients so the bits are its own. */
+int  ohs_eq_set_band_coeffs(ohs_eq *eq, size_t band, const float coeffs[5], int enabled);
+int  ohs_eq_get_band_coeffs(const ohs_eq *eq, size_t band, float coeffs[5], int *enabled);
+/* process_block(&mut [f32], &mut [f32]) in place  parametric_eq.rs:166-179. */
+int  ohs_eq_process_block(ohs_eq *eq, float *left, float *right, size_t n);
+/* reset_all_bands_state  parametric_eq.rs:181-188 (also Plugin::reset, lib.rs:1152-1154). */
+int  ohs_eq_reset(ohs_eq *eq);
+/* calculate_frequency_response(fs, &[f32]) -> Vec<f32>  parametric_eq.rs:190-209
+ * (|H| of the enabled LEFT bands). */
+int  ohs_eq_frequency_response(const ohs_eq *eq, float fs, const float *freqs, size_t n, float *out);
+
+/* ---- Plugin::process DSP chain  (src/lib.rs:1169-1207) ----------------------- */
+/* In place on left/right: bypass => untouched; [eq_enable => EQ in place] ->
+ * convolution -> every sample *= gain.  One H2D + one D2H per call; the caller
+ * refreshes EQ coefficients beforehand (lib.rs:1180-1193). eq may be NULL when
+ * eq_enable == 0. */
+int  ohs_chain_process(ohs_engine *e, ohs_eq *eq, int bypass, int eq_enable, float gain,
+                       float *left, float *right, size_t n);
+
+/* ---- offline many-stream batch mode (north_star; no reference counterpart) ---- */
+/* n_streams independent stereo streams share one HRIR set and one EQ table; all
+ * per-stream state (EQ s1/s2, spectrum history, overlap) is device resident.
+ * Audio buffers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()),
+ * planar: sample (s, ch, i) at base[s*stream_stride + ch*channel_stride + i]. */
+typedef struct ohs_batch ohs_batch;
+
+int  ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch **out);
+void ohs_batch_destroy(ohs_batch *b);
+/* set_ir semantics of convolution.rs:111-139 applied to every stream. `ir` is a HOST pointer. */
+int  ohs_batch_set_ir(ohs_batch *b, int path, const float *ir, size_t len);
+int  ohs_batch_set_eq_band_coeffs(ohs_batch *b, size_t band, const float coeffs[5], int enabled);
+int  ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_type, float fc,
+                              float q, float gain_db, int enabled);
+/* eq_enable / output gain of lib.rs:1179,1202 */
+int  ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable);
+int  ohs_batch_set_gain(ohs_batch *b, float gain);
+/* zero every stream's EQ state, history and overlap (IRs and EQ table kept) */
+int  ohs_batch_reset(ohs_batch *b);
+/* Process n_blocks * 512 frames of every stream: [EQ] -> convolution -> gain.
+ * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
+ * d_in may equal d_out. Strides are in floats. */
+int  ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                       size_t stream_stride, size_t channel_stride, void *hip_stream);
+int  ohs_batch_sync(ohs_batch *b, void *hip_stream);
+/* algorithmic HBM bytes one ohs_batch_process call of n_blocks moves (DESIGN.md byte model) */
+int  ohs_batch_algorithmic_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OHS_HIP_H */

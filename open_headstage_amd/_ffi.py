@@ -1,0 +1,101 @@
+"""ctypes loader for libohs_hip.so (the C ABI in include/ohs_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises,
+and every create call fails with OHS_ERR_NO_DEVICE when no GPU is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libohs_hip.so")
+
+OHS_OK = 0
+OHS_ERR_INVALID_ARG = 1
+OHS_ERR_NO_DEVICE = 2
+OHS_ERR_HIP = 3
+OHS_ERR_OUTSIDE_NYQUIST = 4
+OHS_ERR_NEGATIVE_Q = 5
+OHS_ERR_ALLOC = 6
+
+fp = C.POINTER(C.c_float)
+vp = C.c_void_p
+vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes): the complete export list of include/ohs_hip.h
+PROTOTYPES = {
+    "ohs_version": (C.c_int, []),
+    "ohs_status_string": (C.c_char_p, [C.c_int]),
+    "ohs_last_error": (C.c_char_p, []),
+    "ohs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "ohs_debug_fft1024": (C.c_int, [C.c_int, fp, fp, C.c_int, C.c_size_t]),
+    "ohs_engine_create": (C.c_int, [C.c_int, vpp]),
+    "ohs_engine_clone": (C.c_int, [vp, vpp]),
+    "ohs_engine_destroy": (None, [vp]),
+    "ohs_engine_set_ir": (C.c_int, [vp, C.c_int, fp, C.c_size_t]),
+    "ohs_engine_process_block": (C.c_int, [vp, fp, fp, fp, fp, C.c_size_t]),
+    "ohs_engine_num_partitions": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
+    "ohs_biquad_coeffs": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp]),
+    "ohs_eq_create": (C.c_int, [C.c_int, C.c_size_t, C.c_float, vpp]),
+    "ohs_eq_destroy": (None, [vp]),
+    "ohs_eq_update_band": (C.c_int, [vp, C.c_size_t, C.c_float, C.c_int, C.c_float, C.c_float,
+                                     C.c_float, C.c_int]),
+    "ohs_eq_set_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.c_int]),
+    "ohs_eq_get_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.POINTER(C.c_int)]),
+    "ohs_eq_process_block": (C.c_int, [vp, fp, fp, C.c_size_t]),
+    "ohs_eq_reset": (C.c_int, [vp]),
+    "ohs_eq_frequency_response": (C.c_int, [vp, C.c_float, fp, C.c_size_t, fp]),
+    "ohs_chain_process": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, fp, fp, C.c_size_t]),
+    "ohs_batch_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, vpp]),
+    "ohs_batch_destroy": (None, [vp]),
+    "ohs_batch_set_ir": (C.c_int, [vp, C.c_int, fp, C.c_size_t]),
+    "ohs_batch_set_eq_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.c_int]),
+    "ohs_batch_update_eq_band": (C.c_int, [vp, C.c_size_t, C.c_float, C.c_int, C.c_float, C.c_float,
+                                           C.c_float, C.c_int]),
+    "ohs_batch_set_eq_enabled": (C.c_int, [vp, C.c_int]),
+    "ohs_batch_set_gain": (C.c_int, [vp, C.c_float]),
+    "ohs_batch_reset": (C.c_int, [vp]),
+    "ohs_batch_process": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),
+    "ohs_batch_sync": (C.c_int, [vp, vp]),
+    "ohs_batch_algorithmic_bytes": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_uint64)]),
+}
+
+
+class OhsError(RuntimeError):
+    def __init__(self, status: int, detail: str):
+        self.status = status
+        super().__init__(f"{lib().ohs_status_string(status).decode()} ({status}): {detail}")
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m open_headstage_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and the
+        # dynamic loader de-duplicates by SONAME only when torch's copy is loaded FIRST (torch's
+        # libs ask for "libamdhip64.so", ours for "libamdhip64.so.7").  Two runtimes in one
+        # process leave the second one without a device.  torch is plumbing here (device
+        # tensors, streams, torch.distributed); without it the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)     # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != OHS_OK:
+        raise OhsError(status, lib().ohs_last_error().decode(errors="replace"))

@@ -1,0 +1,95 @@
+"""Offline many-stream batch mode (BASELINE.json north_star) over the C ABI.
+
+`n_streams` independent stereo streams share one HRIR set and one EQ table; all
+per-stream state lives in HBM / registers of the GPU.  Audio is exchanged as
+device tensors shaped [stream, channel(2), frame] -- torch is used only as the
+owner of device memory and streams; every sample is computed by the HIP
+kernels behind libohs_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._ffi import check, fp, lib
+from .dsp import BLOCK_SIZE, BandConfig
+
+
+class BatchProcessor:
+    def __init__(self, n_streams: int, num_bands: int = 10, device: int = 0):
+        self.n_streams = int(n_streams)
+        self.num_bands = int(num_bands)
+        self.device = int(device)
+        h = C.c_void_p()
+        check(lib().ohs_batch_create(self.device, self.n_streams, self.num_bands, C.byref(h)))
+        self._h = h
+
+    # -- shared tables -----------------------------------------------------------
+    def set_ir(self, path, ir_data) -> None:
+        ir = np.ascontiguousarray(ir_data, dtype=np.float32).ravel()
+        check(lib().ohs_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp), ir.size))
+
+    def update_band_coeffs(self, band_idx: int, sample_rate: float, config: BandConfig) -> None:
+        check(lib().ohs_batch_update_eq_band(self._h, int(band_idx), sample_rate,
+                                             int(config.filter_type), config.center_freq, config.q,
+                                             config.gain_db, int(bool(config.enabled))))
+
+    def set_band_coeffs(self, band_idx: int, coeffs, enabled: bool) -> None:
+        c = np.ascontiguousarray(coeffs, dtype=np.float32).ravel()
+        if c.size != 5:
+            raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
+        check(lib().ohs_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp),
+                                                 int(bool(enabled))))
+
+    def set_eq_enabled(self, eq_enable: bool) -> None:
+        check(lib().ohs_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
+
+    def set_gain(self, gain: float) -> None:
+        check(lib().ohs_batch_set_gain(self._h, float(gain)))
+
+    def reset(self) -> None:
+        check(lib().ohs_batch_reset(self._h))
+
+    # -- processing --------------------------------------------------------------
+    def process_ptr(self, d_in: int, d_out: int, n_blocks: int, stream_stride: int,
+                    channel_stride: int, hip_stream: int = 0) -> None:
+        check(lib().ohs_batch_process(self._h, C.c_void_p(d_in), C.c_void_p(d_out), int(n_blocks),
+                                      int(stream_stride), int(channel_stride),
+                                      C.c_void_p(hip_stream) if hip_stream else None))
+
+    def process(self, x, out=None, hip_stream: int | None = None):
+        """x, out: torch.float32 CUDA tensors [n_streams, 2, frames], frames % 512 == 0."""
+        import torch
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()):
+            raise TypeError("x must be a contiguous float32 CUDA tensor [streams, 2, frames]")
+        S, ch, frames = x.shape
+        if S != self.n_streams or ch != 2 or frames % BLOCK_SIZE:
+            raise ValueError(f"expected [{self.n_streams}, 2, k*{BLOCK_SIZE}], got {tuple(x.shape)}")
+        if x.device.index != self.device:
+            raise ValueError("tensor is on a different device than the BatchProcessor")
+        if out is None:
+            out = torch.empty_like(x)
+        elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous() or out.device != x.device:
+            raise ValueError("out must match x")
+        if hip_stream is None:
+            hip_stream = torch.cuda.current_stream(x.device).cuda_stream
+        self.process_ptr(x.data_ptr(), out.data_ptr(), frames // BLOCK_SIZE, 2 * frames, frames,
+                         hip_stream)
+        return out
+
+    def sync(self, hip_stream: int = 0) -> None:
+        check(lib().ohs_batch_sync(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def algorithmic_bytes(self, n_blocks: int) -> int:
+        v = C.c_uint64()
+        check(lib().ohs_batch_algorithmic_bytes(self._h, int(n_blocks), C.byref(v)))
+        return int(v.value)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().ohs_batch_destroy(h)
+            except Exception:
+                pass

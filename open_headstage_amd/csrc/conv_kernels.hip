@@ -1,0 +1,246 @@
+// conv_kernels.hip -- partitioned FFT convolution kernels for gfx950 (MI355X).
+//
+// What they compute is fixed by the reference's src/dsp/convolution.rs
+// (set_ir :111-139, process_internal_block :184-233, convolve_path_partitioned
+// :236-289); how they compute it is MI355X-first:
+//   * one wavefront owns one stereo stream and keeps its overlap tails in VGPRs;
+//   * L and R are packed into ONE complex FFT-1024 (z = x_l + j x_r) and each
+//     speaker's two ear paths into ONE inverse FFT (w = y_*l + j y_*r), so a
+//     block costs 1 forward + 2 inverse transforms instead of the reference's 4 + 4;
+//   * one spectrum history per stream (packed Z), not one per path; per-path
+//     set_ir resets are reproduced by gating partitions on "blocks since reset";
+//   * all global traffic is lane-contiguous ([reg][lane] images, 512 B per wave load).
+#include "kernels.h"
+#include "wave_fft.hpp"
+
+namespace ohs {
+
+// ---------------------------------------------------------------------------------
+// IR partition spectra (set_ir, convolution.rs:120-132)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ir_spectrum(const float *__restrict__ ir, int len,
+                                                    float2 *__restrict__ dst,
+                                                    const float2 *__restrict__ tw)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *lds = smem + kTabComplex;
+    const int lane = threadIdx.x;
+    const int part = blockIdx.x;
+    fill_twiddle_tables(tab, tw, lane, 64);
+    __syncthreads();
+
+    float2 v[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const int idx = part * kBlock + 64 * a + lane;
+        v[a] = make_float2((a < 8 && idx < len) ? ir[idx] : 0.0f, 0.0f);
+    }
+    wave_fft_fwd(v, lds, tab, lane);
+    float2 *o = dst + (size_t)part * kFft;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r * 64 + lane] = v[r];
+}
+
+hipError_t launch_ir_spectrum(const float *d_ir, int len, int n_parts, float2 *dst,
+                              const float2 *tw, hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + kWaveLdsComplex) * sizeof(float2);
+    hipLaunchKernelGGL(k_ir_spectrum, dim3(n_parts), dim3(64), shmem, st, d_ir, len, dst, tw);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// General convolution kernel: one wave per stream, blocks in sequence.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *lds = smem + kTabComplex;
+    const int lane = threadIdx.x;
+    const size_t s = blockIdx.x;
+    fill_twiddle_tables(tab, A.tw, lane, 64);
+    __syncthreads();
+
+    const float *in_l = A.in + s * A.in_stream_stride;
+    const float *in_r = in_l + A.in_ch_stride;
+    float *out_l = A.out + s * A.out_stream_stride;
+    float *out_r = out_l + A.out_ch_stride;
+    float2 *hist = A.hist + s * (size_t)A.cap * kFft;
+    float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
+
+    float2 tail1[8], tail2[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        tail1[a] = tails[a * 64 + lane];
+        tail2[a] = tails[(8 + a) * 64 + lane];
+    }
+    int maxP = A.P[0];
+#pragma unroll
+    for (int p = 1; p < 4; ++p) maxP = A.P[p] > maxP ? A.P[p] : maxP;
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+    const float scale = 1.0f / (float)kFft;   // convolution.rs:280
+
+    for (int t = 0; t < A.n_blocks; ++t) {
+        float2 v[16];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+            v[a] = make_float2(in_l[idx], in_r[idx]);
+        }
+#pragma unroll
+        for (int a = 8; a < 16; ++a) v[a] = make_float2(0.0f, 0.0f);   // zero pad (:248-254)
+        wave_fft_fwd(v, lds, tab, lane);
+
+        // history[history_index] = spectrum (:258); one packed ring per stream
+        {
+            float2 *hs = hist + ((A.cnt + (unsigned long long)t) & mask) * kFft;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hs[r * 64 + lane] = v[r];
+        }
+
+        float2 acc1[16], acc2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[r] = make_float2(0.f, 0.f); acc2[r] = make_float2(0.f, 0.f); }
+
+        // partitions, newest block with partition 0 (:261-273)
+        for (int i = 0; i < maxP; ++i) {
+            // path p sees block (t - i) only if that block was processed after p's last set_ir
+            const bool g0 = i < A.P[0] && (long long)i <= A.since[0] + t;
+            const bool g1 = i < A.P[1] && (long long)i <= A.since[1] + t;
+            const bool g2 = i < A.P[2] && (long long)i <= A.since[2] + t;
+            const bool g3 = i < A.P[3] && (long long)i <= A.since[3] + t;
+            if (!(g0 || g1 || g2 || g3)) continue;
+
+            float2 zi[16], zm[16];
+            if (i == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zi[r] = v[r];
+            } else {
+                const float2 *hs =
+                    hist + ((A.cnt + (unsigned long long)t - (unsigned long long)i) & mask) * kFft;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zi[r] = hs[r * 64 + lane];
+            }
+            wave_mirror(zi, zm, lane);
+            const float2 *h0 = A.H[0] + (size_t)i * kFft;
+            const float2 *h1 = A.H[1] + (size_t)i * kFft;
+            const float2 *h2 = A.H[2] + (size_t)i * kFft;
+            const float2 *h3 = A.H[3] + (size_t)i * kFft;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // X_l = (Z + conj(Zm))/2 ; X_r = -j (Z - conj(Zm))/2
+                const float2 xl = make_float2(0.5f * (zi[r].x + zm[r].x), 0.5f * (zi[r].y - zm[r].y));
+                const float2 xr = make_float2(0.5f * (zi[r].y + zm[r].y), -0.5f * (zi[r].x - zm[r].x));
+                if (g0) { const float2 y = cmul(xl, h0[r * 64 + lane]); acc1[r].x += y.x; acc1[r].y += y.y; }
+                if (g1) { const float2 y = cmul(xl, h1[r * 64 + lane]); acc1[r].x -= y.y; acc1[r].y += y.x; }
+                if (g2) { const float2 y = cmul(xr, h2[r * 64 + lane]); acc2[r].x += y.x; acc2[r].y += y.y; }
+                if (g3) { const float2 y = cmul(xr, h3[r * 64 + lane]); acc2[r].x -= y.y; acc2[r].y += y.x; }
+            }
+        }
+
+        wave_fft_inv(acc1, lds, tab, lane);   // re = lsl, im = lsr   (:276)
+        wave_fft_inv(acc2, lds, tab, lane);   // re = rsl, im = rsr
+
+        // overlap-add per path, then ear sums (:279-284, :228-231), then gain (lib.rs:1202-1207)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const float lsl = acc1[a].x * scale + tail1[a].x;
+            const float lsr = acc1[a].y * scale + tail1[a].y;
+            const float rsl = acc2[a].x * scale + tail2[a].x;
+            const float rsr = acc2[a].y * scale + tail2[a].y;
+            tail1[a] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
+            tail2[a] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
+            const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+            out_l[idx] = (lsl + rsl) * A.gain;
+            out_r[idx] = (lsr + rsr) * A.gain;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        tails[a * 64 + lane] = tail1[a];
+        tails[(8 + a) * 64 + lane] = tail2[a];
+    }
+}
+
+hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + kWaveLdsComplex) * sizeof(float2);
+    hipLaunchKernelGGL(k_conv_general, dim3(n_streams), dim3(64), shmem, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Diagnostic: natural-order complex FFT-1024 through wave_fft_fwd / wave_fft_inv
+// (one wave per transform).  Used by the tests to measure the primitive's accuracy.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_debug_fft(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                  int inverse, const float2 *__restrict__ tw)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *lds = smem + kTabComplex;
+    const int lane = threadIdx.x;
+    fill_twiddle_tables(tab, tw, lane, 64);
+    __syncthreads();
+    const float2 *src = in + (size_t)blockIdx.x * kFft;
+    float2 *dst = out + (size_t)blockIdx.x * kFft;
+    float2 v[16];
+    if (!inverse) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = src[64 * a + lane];
+        wave_fft_fwd(v, lds, tab, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[4 * lane + j + 256 * r] = v[4 * r + j];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * r + j] = src[4 * lane + j + 256 * r];
+        wave_fft_inv(v, lds, tab, lane);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) dst[64 * a + lane] = v[a];
+    }
+}
+hipError_t launch_debug_fft(const float2 *in, float2 *out, int inverse, int batch, const float2 *tw,
+                            hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + kWaveLdsComplex) * sizeof(float2);
+    hipLaunchKernelGGL(k_debug_fft, dim3(batch), dim3(64), shmem, st, in, out, inverse, tw);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------------
+__global__ void k_zero_tail_component(float2 *tails, long long n_streams, int which, int comp)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over n_streams * 512
+    if (i >= n_streams * 512) return;
+    float2 *p = tails + ((i >> 9) * 2 + which) * 512 + (i & 511);
+    if (comp == 0) p->x = 0.0f; else p->y = 0.0f;
+}
+hipError_t launch_zero_tail_component(float2 *tails, long long n_streams, int which, int comp, hipStream_t st)
+{
+    const long long n = n_streams * 512;
+    hipLaunchKernelGGL(k_zero_tail_component, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tails,
+                       n_streams, which, comp);
+    return hipGetLastError();
+}
+
+__global__ void k_scale_copy(const float *__restrict__ src, float *__restrict__ dst, long long n, float gain)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] * gain;
+}
+hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, gain);
+    return hipGetLastError();
+}
+
+}  // namespace ohs

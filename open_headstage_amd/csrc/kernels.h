@@ -1,0 +1,60 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ohs {
+
+// ---- convolution -------------------------------------------------------------
+// "General" kernel: faithful per-path semantics of src/dsp/convolution.rs
+// (per-path partition count, per-path history reset, four separate overlap tails).
+struct ConvGeneralArgs {
+    const float *in;            // planar device audio
+    float *out;
+    long long in_stream_stride, in_ch_stride;     // floats
+    long long out_stream_stride, out_ch_stride;   // floats
+    int n_blocks;               // 512-frame blocks to process
+    const float2 *H[4];         // per path: [P][16][64] spectra in bin layout
+    int P[4];                   // partitions per path
+    long long since[4];         // blocks processed since that path's last set_ir (before this launch)
+    float2 *hist;               // [stream][cap][16][64] packed spectra ring Z = FFT(x_l + j x_r)
+    int cap;                    // ring capacity, power of two >= max P
+    unsigned long long cnt;     // absolute block counter at launch start
+    float2 *tails;              // [stream][2][8][64]: (lsl + j lsr) tail, (rsl + j rsr) tail
+    const float2 *tw;           // master twiddle table, 1024 entries
+    float gain;
+};
+hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st);
+
+// IR chunk -> spectrum: dst[part][16][64], one wave per partition.
+hipError_t launch_ir_spectrum(const float *d_ir, int len, int n_parts, float2 *dst,
+                              const float2 *tw, hipStream_t st);
+
+// set_ir's overlap reset (convolution.rs:138) for every stream: tails is [S][2][512] float2;
+// zero the re (comp 0) or im (comp 1) part of tail `which` (0 = L-speaker pair, 1 = R-speaker pair).
+hipError_t launch_zero_tail_component(float2 *tails, long long n_streams, int which, int comp, hipStream_t st);
+
+// diagnostic natural-order FFT-1024 (batch transforms)
+hipError_t launch_debug_fft(const float2 *in, float2 *out, int inverse, int batch, const float2 *tw,
+                            hipStream_t st);
+
+// dst[i] = src[i] * gain  (n floats)
+hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st);
+
+// ---- EQ ------------------------------------------------------------------------
+// One pass of up to 16 cascaded DF2T bands (parametric_eq.rs:116-122,166-179).
+struct EqPassTable {
+    float b0[16], b1[16], b2[16], a1[16], a2[16];
+    int en[16];
+};
+// chains = streams * 2 (L, R); chain c -> stream c>>1, channel c&1.
+// state: [chain][16][2] (s1, s2) for this pass.
+hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
+                          long long n, int n_chains, const EqPassTable &tab, float *state,
+                          hipStream_t st);
+
+// |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
+hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,
+                                   const float *d_freqs, int n, float *d_out, hipStream_t st);
+
+}  // namespace ohs

@@ -1,0 +1,911 @@
+// ohs_api.hip -- implementation of the C ABI declared in include/ohs_hip.h.
+//
+// Host-side orchestration only: device memory, FIFOs, per-path bookkeeping and
+// kernel launches.  Every sample of audio is computed by the HIP kernels in
+// conv_kernels.hip / eq_kernels.hip; there is no CPU compute path and every
+// create call fails with OHS_ERR_NO_DEVICE when no GPU is usable.
+#include "../../include/ohs_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ohs;
+
+namespace {
+
+constexpr int BS = OHS_BLOCK_SIZE;
+constexpr int NF = OHS_FFT_SIZE;
+
+thread_local std::string g_err;
+
+int fail(int status, const std::string &msg)
+{
+    g_err = msg;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(OHS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+// ---- per-device context: the master twiddle table ------------------------------
+struct DeviceCtx {
+    int device = -1;
+    float2 *d_tw = nullptr;
+};
+std::mutex g_ctx_mu;
+std::vector<DeviceCtx *> g_ctx;
+
+int get_ctx(int device, DeviceCtx **out)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(OHS_ERR_NO_DEVICE, std::string("no usable HIP device (") +
+                                           (e != hipSuccess ? hipGetErrorString(e) : "count == 0") +
+                                           "); this library has no CPU fallback");
+    if (device < 0 || device >= count) return fail(OHS_ERR_INVALID_ARG, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (DeviceCtx *c : g_ctx)
+        if (c->device == device) { *out = c; return OHS_OK; }
+    HIP_TRY(hipSetDevice(device));
+    DeviceCtx *c = new (std::nothrow) DeviceCtx();
+    if (!c) return fail(OHS_ERR_ALLOC, "out of host memory");
+    c->device = device;
+    // tw[e] = exp(-2 pi i e / 1024), computed in f64 and rounded to f32 (as rustfft does)
+    std::vector<float2> tw(NF);
+    for (int k = 0; k < NF; ++k) {
+        const double ang = -2.0 * 3.14159265358979323846264338327950288 * (double)k / (double)NF;
+        tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    if (hipMalloc(&c->d_tw, NF * sizeof(float2)) != hipSuccess) {
+        delete c;
+        return fail(OHS_ERR_HIP, "hipMalloc(twiddles) failed");
+    }
+    if (hipMemcpy(c->d_tw, tw.data(), NF * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(c->d_tw);
+        delete c;
+        return fail(OHS_ERR_HIP, "hipMemcpy(twiddles) failed");
+    }
+    g_ctx.push_back(c);
+    *out = c;
+    return OHS_OK;
+}
+
+int next_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ---- convolution state shared by the engine (1 stream) and batch (S streams) ----
+struct ConvState {
+    size_t S = 1;
+    float2 *d_H[4] = {nullptr, nullptr, nullptr, nullptr};
+    int P[4] = {1, 1, 1, 1};
+    long long since[4] = {0, 0, 0, 0};
+    float2 *d_hist = nullptr;       // [S][cap][1024]
+    int cap = 1;
+    unsigned long long cnt = 0;
+    float2 *d_tails = nullptr;      // [S][2][8][64]
+};
+
+void conv_free(ConvState &c)
+{
+    for (int p = 0; p < 4; ++p) { if (c.d_H[p]) hipFree(c.d_H[p]); c.d_H[p] = nullptr; }
+    if (c.d_hist) hipFree(c.d_hist);
+    if (c.d_tails) hipFree(c.d_tails);
+    c.d_hist = nullptr; c.d_tails = nullptr;
+}
+
+int conv_init(ConvState &c, size_t S, hipStream_t st)
+{
+    c.S = S;
+    for (int p = 0; p < 4; ++p) {
+        // default path: one all-zero partition (convolution.rs:46-63); FFT(0) == 0
+        HIP_TRY(hipMalloc(&c.d_H[p], NF * sizeof(float2)));
+        HIP_TRY(hipMemsetAsync(c.d_H[p], 0, NF * sizeof(float2), st));
+        c.P[p] = 1;
+        c.since[p] = 0;
+    }
+    c.cap = 1;
+    c.cnt = 0;
+    HIP_TRY(hipMalloc(&c.d_hist, S * (size_t)c.cap * NF * sizeof(float2)));
+    HIP_TRY(hipMemsetAsync(c.d_hist, 0, S * (size_t)c.cap * NF * sizeof(float2), st));
+    HIP_TRY(hipMalloc(&c.d_tails, S * 2 * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMemsetAsync(c.d_tails, 0, S * 2 * 8 * 64 * sizeof(float2), st));
+    return OHS_OK;
+}
+
+// grow the spectrum ring so that cap >= need, keeping the most recent old_cap blocks
+int conv_grow_ring(ConvState &c, int need, hipStream_t st)
+{
+    if (need <= c.cap) return OHS_OK;
+    const int ncap = next_pow2(need);
+    float2 *nh = nullptr;
+    HIP_TRY(hipMalloc(&nh, c.S * (size_t)ncap * NF * sizeof(float2)));
+    HIP_TRY(hipMemsetAsync(nh, 0, c.S * (size_t)ncap * NF * sizeof(float2), st));
+    for (int i = 0; i < c.cap; ++i) {
+        if (c.cnt < (unsigned long long)(i + 1)) break;
+        const unsigned long long u = c.cnt - 1 - (unsigned long long)i;
+        const size_t so = (size_t)(u & (unsigned long long)(c.cap - 1));
+        const size_t sn = (size_t)(u & (unsigned long long)(ncap - 1));
+        // one strided copy over all streams
+        HIP_TRY(hipMemcpy2DAsync(nh + sn * NF, (size_t)ncap * NF * sizeof(float2),
+                                 c.d_hist + so * NF, (size_t)c.cap * NF * sizeof(float2),
+                                 NF * sizeof(float2), c.S, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(c.d_hist);
+    c.d_hist = nh;
+    c.cap = ncap;
+    return OHS_OK;
+}
+
+// set_ir (convolution.rs:111-139) for one path; `ir` is a host pointer
+int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st)
+{
+    if (path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "path must be 0..3");
+    if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
+    if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
+    const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
+    float2 *nH = nullptr;
+    HIP_TRY(hipMalloc(&nH, (size_t)P * NF * sizeof(float2)));
+    if (len == 0) {
+        HIP_TRY(hipMemsetAsync(nH, 0, NF * sizeof(float2), st));   // :114-118 mute
+    } else {
+        float *d_ir = nullptr;
+        HIP_TRY(hipMalloc(&d_ir, len * sizeof(float)));
+        hipError_t e = hipMemcpyAsync(d_ir, ir, len * sizeof(float), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = launch_ir_spectrum(d_ir, (int)len, P, nH, ctx->d_tw, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        hipFree(d_ir);
+        if (e != hipSuccess) { hipFree(nH); return fail(OHS_ERR_HIP, hipGetErrorString(e)); }
+    }
+    int rc = conv_grow_ring(c, P, st);
+    if (rc) { hipFree(nH); return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(c.d_H[path]);
+    c.d_H[path] = nH;
+    c.P[path] = P;
+    c.since[path] = 0;      // :135-137 that path's history is "all zero" again
+    // :138 that path's overlap := 0.  Tails are (lsl + j lsr) and (rsl + j rsr).
+    const int which = path >> 1, comp = path & 1;
+    HIP_TRY(launch_zero_tail_component(c.d_tails, (long long)c.S, which, comp, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return OHS_OK;
+}
+
+int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
+                float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st)
+{
+    ConvGeneralArgs a;
+    a.in = in; a.out = out;
+    a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+    a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+    a.n_blocks = n_blocks;
+    for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
+    a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
+    a.tails = c.d_tails; a.tw = ctx->d_tw; a.gain = gain;
+    hipError_t e = launch_conv_general(a, (int)c.S, st);
+    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+    c.cnt += (unsigned long long)n_blocks;
+    for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;
+    return OHS_OK;
+}
+
+// ---- EQ table / state shared by ohs_eq (1 stream) and ohs_batch -------------------
+struct EqState {
+    size_t nb = 0;
+    size_t chains = 2;
+    std::vector<float> coeffs;   // nb * 5  {b0,b1,b2,a1,a2}
+    std::vector<int> en;         // nb
+    float *d_state = nullptr;    // [passes][chains][16][2]
+    int passes() const { return (int)((nb + 15) / 16); }
+};
+
+int rbj(int type, float fs, float fc, float q, float gain_db, float out[5]);
+
+int eq_init(EqState &e, size_t nb, size_t chains, float fs, hipStream_t st)
+{
+    if (nb > OHS_MAX_EQ_BANDS) return fail(OHS_ERR_INVALID_ARG, "num_bands > OHS_MAX_EQ_BANDS");
+    e.nb = nb; e.chains = chains;
+    e.coeffs.assign(nb * 5, 0.0f);
+    e.en.assign(nb, 0);
+    float c[5];
+    int rc = rbj(OHS_FILTER_PEAK, fs, 20.0f, 0.707f, 0.0f, c);   // parametric_eq.rs:63-76
+    if (rc) return rc;
+    for (size_t b = 0; b < nb; ++b) std::memcpy(&e.coeffs[5 * b], c, sizeof(c));
+    const size_t n = (size_t)std::max(1, e.passes()) * chains * 16 * 2;
+    HIP_TRY(hipMalloc(&e.d_state, n * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(e.d_state, 0, n * sizeof(float), st));
+    return OHS_OK;
+}
+
+int eq_reset(EqState &e, hipStream_t st)
+{
+    const size_t n = (size_t)std::max(1, e.passes()) * e.chains * 16 * 2;
+    HIP_TRY(hipMemsetAsync(e.d_state, 0, n * sizeof(float), st));
+    return OHS_OK;
+}
+
+// run the cascade over n frames of `chains` chains, in place allowed
+int eq_launch(EqState &e, const float *in, float *out, long long ss, long long cs, long long n,
+              hipStream_t st, bool *did_anything = nullptr)
+{
+    bool did = false;
+    const float *src = in;
+    for (int pass = 0; pass < e.passes(); ++pass) {
+        EqPassTable t;
+        std::memset(&t, 0, sizeof(t));
+        bool any = false;
+        for (int j = 0; j < 16; ++j) {
+            const size_t b = (size_t)pass * 16 + j;
+            if (b >= e.nb) break;
+            t.b0[j] = e.coeffs[5 * b + 0]; t.b1[j] = e.coeffs[5 * b + 1]; t.b2[j] = e.coeffs[5 * b + 2];
+            t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
+            t.en[j] = e.en[b];
+            any = any || e.en[b];
+        }
+        if (!any) continue;   // a pass of disabled bands is the identity, bit for bit (parametric_eq.rs:118-120)
+        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t,
+                                        e.d_state + (size_t)pass * e.chains * 16 * 2, st);
+        if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
+        src = out;
+        did = true;
+    }
+    if (did_anything) *did_anything = did;
+    return OHS_OK;
+}
+
+// biquad 0.4.2 Coefficients::<f32>::from_params, restated (see oracle/ohs_oracle.h for the caveat
+// that biquad/libm are not vendored under the reference); f32 arithmetic, left to right.
+int rbj(int type, float fs, float fc, float q, float gain_db, float out[5])
+{
+    if (2.0f * fc > fs) return fail(OHS_ERR_OUTSIDE_NYQUIST, "2*fc > fs (biquad::Errors::OutsideNyquist)");
+    if (q < 0.0f) return fail(OHS_ERR_NEGATIVE_Q, "q < 0 (biquad::Errors::NegativeQ)");
+    if (type < 0 || type > 7) return fail(OHS_ERR_INVALID_ARG, "filter_type must be 0..7");
+    const float pi = 3.14159265358979323846264338327950288f;
+    const float omega = 2.0f * pi * fc / fs;
+    const float sn = sinf(omega), cs = cosf(omega);
+    const float alpha = sn / (2.0f * q);
+    float b0, b1, b2, a0, a1, a2;
+    switch (type) {
+    case OHS_FILTER_LOWPASS:
+        b0 = (1.0f - cs) * 0.5f; b1 = 1.0f - cs; b2 = (1.0f - cs) * 0.5f;
+        a0 = 1.0f + alpha; a1 = -2.0f * cs; a2 = 1.0f - alpha; break;
+    case OHS_FILTER_HIGHPASS:
+        b0 = (1.0f + cs) * 0.5f; b1 = -(1.0f + cs); b2 = (1.0f + cs) * 0.5f;
+        a0 = 1.0f + alpha; a1 = -2.0f * cs; a2 = 1.0f - alpha; break;
+    case OHS_FILTER_BANDPASS:
+        b0 = sn / 2.0f; b1 = 0.0f; b2 = -(sn / 2.0f);
+        a0 = 1.0f + alpha; a1 = -2.0f * cs; a2 = 1.0f - alpha; break;
+    case OHS_FILTER_NOTCH:
+        b0 = 1.0f; b1 = -2.0f * cs; b2 = 1.0f;
+        a0 = 1.0f + alpha; a1 = -2.0f * cs; a2 = 1.0f - alpha; break;
+    case OHS_FILTER_ALLPASS:
+        b0 = 1.0f - alpha; b1 = -2.0f * cs; b2 = 1.0f + alpha;
+        a0 = 1.0f + alpha; a1 = -2.0f * cs; a2 = 1.0f - alpha; break;
+    case OHS_FILTER_LOWSHELF: {
+        const float a = powf(10.0f, gain_db / 40.0f), sa = sqrtf(a);
+        b0 = a * ((a + 1.0f) - (a - 1.0f) * cs + 2.0f * alpha * sa);
+        b1 = 2.0f * a * ((a - 1.0f) - (a + 1.0f) * cs);
+        b2 = a * ((a + 1.0f) - (a - 1.0f) * cs - 2.0f * alpha * sa);
+        a0 = (a + 1.0f) + (a - 1.0f) * cs + 2.0f * alpha * sa;
+        a1 = -2.0f * ((a - 1.0f) + (a + 1.0f) * cs);
+        a2 = (a + 1.0f) + (a - 1.0f) * cs - 2.0f * alpha * sa; break; }
+    case OHS_FILTER_HIGHSHELF: {
+        const float a = powf(10.0f, gain_db / 40.0f), sa = sqrtf(a);
+        b0 = a * ((a + 1.0f) + (a - 1.0f) * cs + 2.0f * alpha * sa);
+        b1 = -2.0f * a * ((a - 1.0f) + (a + 1.0f) * cs);
+        b2 = a * ((a + 1.0f) + (a - 1.0f) * cs - 2.0f * alpha * sa);
+        a0 = (a + 1.0f) - (a - 1.0f) * cs + 2.0f * alpha * sa;
+        a1 = 2.0f * ((a - 1.0f) - (a + 1.0f) * cs);
+        a2 = (a + 1.0f) - (a - 1.0f) * cs - 2.0f * alpha * sa; break; }
+    default: {   // Peak
+        const float a = powf(10.0f, gain_db / 40.0f);
+        b0 = 1.0f + alpha * a; b1 = -2.0f * cs; b2 = 1.0f - alpha * a;
+        a0 = 1.0f + alpha / a; a1 = -2.0f * cs; a2 = 1.0f - alpha / a; break; }
+    }
+    out[0] = b0 / a0; out[1] = b1 / a0; out[2] = b2 / a0; out[3] = a1 / a0; out[4] = a2 / a0;
+    return OHS_OK;
+}
+
+// ---- growable planar device FIFO [2][cap] ---------------------------------------------
+struct DevFifo {
+    float *d = nullptr;
+    size_t cap = 0, len = 0;
+};
+
+int fifo_reserve(DevFifo &f, size_t need, hipStream_t st)
+{
+    if (need <= f.cap) return OHS_OK;
+    size_t ncap = f.cap ? f.cap : 4 * BS;
+    while (ncap < need) ncap *= 2;
+    float *nd = nullptr;
+    HIP_TRY(hipMalloc(&nd, 2 * ncap * sizeof(float)));
+    if (f.len) {
+        HIP_TRY(hipMemcpyAsync(nd, f.d, f.len * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(nd + ncap, f.d + f.cap, f.len * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (f.d) hipFree(f.d);
+    f.d = nd;
+    f.cap = ncap;
+    return OHS_OK;
+}
+
+// drop the first n frames.  The survivors are copied through `scratch` (>= 2*cap floats are not
+// needed: survivors < cap) because source and destination ranges may overlap.
+int fifo_drop_front(DevFifo &f, size_t n, DevFifo &scratch, hipStream_t st)
+{
+    const size_t rem = f.len - n;
+    if (rem == 0) { f.len = 0; return OHS_OK; }
+    if (rem <= n) {   // ranges [n, n+rem) and [0, rem) do not overlap
+        HIP_TRY(hipMemcpyAsync(f.d, f.d + n, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(f.d + f.cap, f.d + f.cap + n, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
+        f.len = rem;
+        return OHS_OK;
+    }
+    int rc = fifo_reserve(scratch, f.cap, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(scratch.d, f.d + n, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(scratch.d + scratch.cap, f.d + f.cap + n, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    std::swap(f.d, scratch.d);
+    std::swap(f.cap, scratch.cap);
+    f.len = rem;
+    scratch.len = 0;
+    return OHS_OK;
+}
+
+}  // namespace
+
+// =======================================================================================
+// handles
+// =======================================================================================
+struct ohs_engine {
+    int device = 0;
+    DeviceCtx *ctx = nullptr;
+    hipStream_t st = nullptr;
+    ConvState conv;
+    DevFifo in, out, scratch;
+    float *d_stage = nullptr;   // [2][stage_cap] pop staging (gain applied here)
+    size_t stage_cap = 0;
+};
+
+struct ohs_eq {
+    int device = 0;
+    DeviceCtx *ctx = nullptr;
+    hipStream_t st = nullptr;
+    EqState eq;
+    float fs = 48000.0f;
+    float *d_buf = nullptr;     // [2][buf_cap]
+    size_t buf_cap = 0;
+};
+
+struct ohs_batch {
+    int device = 0;
+    DeviceCtx *ctx = nullptr;
+    hipStream_t st = nullptr;   // for set-up work only
+    ConvState conv;
+    EqState eq;
+    int eq_enable = 0;
+    float gain = 1.0f;
+};
+
+namespace {
+
+int engine_stage_reserve(ohs_engine *e, size_t n)
+{
+    if (n <= e->stage_cap) return OHS_OK;
+    size_t ncap = e->stage_cap ? e->stage_cap : 4 * BS;
+    while (ncap < n) ncap *= 2;
+    if (e->d_stage) hipFree(e->d_stage);
+    e->d_stage = nullptr; e->stage_cap = 0;
+    HIP_TRY(hipMalloc(&e->d_stage, 2 * ncap * sizeof(float)));
+    e->stage_cap = ncap;
+    return OHS_OK;
+}
+
+// process_block (convolution.rs:141-182) with the FIFOs on the device; optionally the
+// lib.rs:1179-1207 chain around it (EQ on the freshly appended frames, gain on the popped ones).
+int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *out_l, float *out_r,
+                   size_t n, ohs_eq *eq, float gain)
+{
+    if (n == 0) return OHS_OK;
+    if (!in_l || !in_r || !out_l || !out_r) return fail(OHS_ERR_INVALID_ARG, "NULL audio pointer");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = e->st;
+    int rc = fifo_reserve(e->in, e->in.len + n, st);
+    if (rc) return rc;
+    // :149-150 append
+    float *app_l = e->in.d + e->in.len, *app_r = e->in.d + e->in.cap + e->in.len;
+    HIP_TRY(hipMemcpyAsync(app_l, in_l, n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(app_r, in_r, n * sizeof(float), hipMemcpyHostToDevice, st));
+    if (eq) {   // lib.rs:1194: EQ in place on this host block, before the engine sees it
+        rc = eq_launch(eq->eq, app_l, app_l, 0, (long long)e->in.cap, (long long)n, st);
+        if (rc) return rc;
+    }
+    e->in.len += n;
+    // :152-161 every complete 512-block
+    const size_t k = e->in.len / BS;
+    if (k) {
+        rc = fifo_reserve(e->out, e->out.len + k * BS, st);
+        if (rc) return rc;
+        rc = conv_launch(e->conv, e->ctx, e->in.d, 0, (long long)e->in.cap, e->out.d + e->out.len, 0,
+                         (long long)e->out.cap, (int)k, 1.0f, st);
+        if (rc) return rc;
+        e->out.len += k * BS;
+        rc = fifo_drop_front(e->in, k * BS, e->scratch, st);
+        if (rc) return rc;
+    }
+    // :163-181 pop n or silence
+    if (e->out.len >= n) {
+        rc = engine_stage_reserve(e, n);
+        if (rc) return rc;
+        HIP_TRY(launch_scale_copy(e->out.d, e->d_stage, (long long)n, gain, st));
+        HIP_TRY(launch_scale_copy(e->out.d + e->out.cap, e->d_stage + e->stage_cap, (long long)n, gain, st));
+        HIP_TRY(hipMemcpyAsync(out_l, e->d_stage, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_r, e->d_stage + e->stage_cap, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        rc = fifo_drop_front(e->out, n, e->scratch, st);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memset(out_l, 0, n * sizeof(float));
+        std::memset(out_r, 0, n * sizeof(float));
+    }
+    return OHS_OK;
+}
+
+}  // namespace
+
+// =======================================================================================
+// C ABI
+// =======================================================================================
+extern "C" {
+
+int ohs_version(void) { return (0 << 16) | (1 << 8) | 0; }
+
+const char *ohs_status_string(int s)
+{
+    switch (s) {
+    case OHS_OK: return "OHS_OK";
+    case OHS_ERR_INVALID_ARG: return "OHS_ERR_INVALID_ARG";
+    case OHS_ERR_NO_DEVICE: return "OHS_ERR_NO_DEVICE";
+    case OHS_ERR_HIP: return "OHS_ERR_HIP";
+    case OHS_ERR_OUTSIDE_NYQUIST: return "OHS_ERR_OUTSIDE_NYQUIST";
+    case OHS_ERR_NEGATIVE_Q: return "OHS_ERR_NEGATIVE_Q";
+    case OHS_ERR_ALLOC: return "OHS_ERR_ALLOC";
+    default: return "OHS_ERR_UNKNOWN";
+    }
+}
+
+const char *ohs_last_error(void) { return g_err.c_str(); }
+
+int ohs_device_count(int *count)
+{
+    if (!count) return fail(OHS_ERR_INVALID_ARG, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *count = 0;
+        return fail(OHS_ERR_NO_DEVICE, std::string("no usable HIP device: ") +
+                                           (e != hipSuccess ? hipGetErrorString(e) : "count == 0"));
+    }
+    *count = c;
+    return OHS_OK;
+}
+
+// ---- diagnostics -----------------------------------------------------------------------
+int ohs_debug_fft1024(int device, const float *in, float *out, int inverse, size_t batch)
+{
+    if (!in || !out || batch == 0 || batch > 65535) return fail(OHS_ERR_INVALID_ARG, "bad argument");
+    DeviceCtx *ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    float2 *d = nullptr;
+    const size_t bytes = batch * NF * sizeof(float2);
+    HIP_TRY(hipMalloc(&d, 2 * bytes));
+    hipError_t e = hipMemcpy(d, in, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_debug_fft(d, d + batch * NF, inverse, (int)batch, ctx->d_tw, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d + batch * NF, bytes, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(OHS_ERR_HIP, hipGetErrorString(e));
+    return OHS_OK;
+}
+
+// ---- engine ----------------------------------------------------------------------------
+int ohs_engine_create(int device, ohs_engine **out)
+{
+    if (!out) return fail(OHS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    DeviceCtx *ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    ohs_engine *e = new (std::nothrow) ohs_engine();
+    if (!e) return fail(OHS_ERR_ALLOC, "out of host memory");
+    e->device = device; e->ctx = ctx;
+    if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) {
+        delete e;
+        return fail(OHS_ERR_HIP, "hipStreamCreate failed");
+    }
+    rc = conv_init(e->conv, 1, e->st);
+    if (rc == OHS_OK && hipStreamSynchronize(e->st) != hipSuccess) rc = fail(OHS_ERR_HIP, "sync failed");
+    if (rc) { ohs_engine_destroy(e); return rc; }
+    *out = e;
+    return OHS_OK;
+}
+
+void ohs_engine_destroy(ohs_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->st) hipStreamSynchronize(e->st);
+    conv_free(e->conv);
+    if (e->in.d) hipFree(e->in.d);
+    if (e->out.d) hipFree(e->out.d);
+    if (e->scratch.d) hipFree(e->scratch.d);
+    if (e->d_stage) hipFree(e->d_stage);
+    if (e->st) hipStreamDestroy(e->st);
+    delete e;
+}
+
+int ohs_engine_clone(const ohs_engine *src, ohs_engine **out)
+{
+    if (!src || !out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    ohs_engine *e = nullptr;
+    int rc = ohs_engine_create(src->device, &e);
+    if (rc) return rc;
+    hipStream_t st = e->st;
+    auto bail = [&](int code) { ohs_engine_destroy(e); return code; };
+    const ConvState &s = src->conv;
+    ConvState &d = e->conv;
+    hipStreamSynchronize(src->st);
+    for (int p = 0; p < 4; ++p) {
+        hipFree(d.d_H[p]); d.d_H[p] = nullptr;
+        if (hipMalloc(&d.d_H[p], (size_t)s.P[p] * NF * sizeof(float2)) != hipSuccess) return bail(fail(OHS_ERR_HIP, "hipMalloc"));
+        if (hipMemcpyAsync(d.d_H[p], s.d_H[p], (size_t)s.P[p] * NF * sizeof(float2), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return bail(fail(OHS_ERR_HIP, "hipMemcpy"));
+        d.P[p] = s.P[p]; d.since[p] = s.since[p];
+    }
+    hipFree(d.d_hist); d.d_hist = nullptr;
+    d.cap = s.cap; d.cnt = s.cnt;
+    if (hipMalloc(&d.d_hist, (size_t)s.cap * NF * sizeof(float2)) != hipSuccess) return bail(fail(OHS_ERR_HIP, "hipMalloc"));
+    if (hipMemcpyAsync(d.d_hist, s.d_hist, (size_t)s.cap * NF * sizeof(float2), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return bail(fail(OHS_ERR_HIP, "hipMemcpy"));
+    if (hipMemcpyAsync(d.d_tails, s.d_tails, 2 * 8 * 64 * sizeof(float2), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return bail(fail(OHS_ERR_HIP, "hipMemcpy"));
+    const DevFifo *sf[2] = {&src->in, &src->out};
+    DevFifo *df[2] = {&e->in, &e->out};
+    for (int i = 0; i < 2; ++i) {
+        if (!sf[i]->len) continue;
+        rc = fifo_reserve(*df[i], sf[i]->len, st);
+        if (rc) return bail(rc);
+        hipMemcpyAsync(df[i]->d, sf[i]->d, sf[i]->len * sizeof(float), hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(df[i]->d + df[i]->cap, sf[i]->d + sf[i]->cap, sf[i]->len * sizeof(float), hipMemcpyDeviceToDevice, st);
+        df[i]->len = sf[i]->len;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(OHS_ERR_HIP, "sync failed"));
+    *out = e;
+    return OHS_OK;
+}
+
+int ohs_engine_set_ir(ohs_engine *e, int path, const float *ir, size_t len)
+{
+    if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    return conv_set_ir(e->conv, e->ctx, path, ir, len, e->st);
+}
+
+int ohs_engine_process_block(ohs_engine *e, const float *in_l, const float *in_r, float *out_l,
+                             float *out_r, size_t n)
+{
+    if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
+    return engine_process(e, in_l, in_r, out_l, out_r, n, nullptr, 1.0f);
+}
+
+int ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out)
+{
+    if (!e || !out || path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "bad argument");
+    *out = (size_t)e->conv.P[path];
+    return OHS_OK;
+}
+
+// ---- eq --------------------------------------------------------------------------------
+int ohs_biquad_coeffs(int filter_type, float fs, float fc, float q, float gain_db, float out[5])
+{
+    if (!out) return fail(OHS_ERR_INVALID_ARG, "out is NULL");
+    return rbj(filter_type, fs, fc, q, gain_db, out);
+}
+
+int ohs_eq_create(int device, size_t num_bands, float fs, ohs_eq **out)
+{
+    if (!out) return fail(OHS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    DeviceCtx *ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    ohs_eq *q = new (std::nothrow) ohs_eq();
+    if (!q) return fail(OHS_ERR_ALLOC, "out of host memory");
+    q->device = device; q->ctx = ctx; q->fs = fs;
+    if (hipStreamCreateWithFlags(&q->st, hipStreamNonBlocking) != hipSuccess) {
+        delete q;
+        return fail(OHS_ERR_HIP, "hipStreamCreate failed");
+    }
+    rc = eq_init(q->eq, num_bands, 2, fs, q->st);
+    if (rc == OHS_OK && hipStreamSynchronize(q->st) != hipSuccess) rc = fail(OHS_ERR_HIP, "sync failed");
+    if (rc) { ohs_eq_destroy(q); return rc; }
+    *out = q;
+    return OHS_OK;
+}
+
+void ohs_eq_destroy(ohs_eq *q)
+{
+    if (!q) return;
+    hipSetDevice(q->device);
+    if (q->st) hipStreamSynchronize(q->st);
+    if (q->eq.d_state) hipFree(q->eq.d_state);
+    if (q->d_buf) hipFree(q->d_buf);
+    if (q->st) hipStreamDestroy(q->st);
+    delete q;
+}
+
+int ohs_eq_update_band(ohs_eq *q, size_t band, float fs, int filter_type, float fc, float qv,
+                       float gain_db, int enabled)
+{
+    if (!q) return fail(OHS_ERR_INVALID_ARG, "eq is NULL");
+    if (band >= q->eq.nb) return OHS_OK;    // parametric_eq.rs:145 silently ignored
+    float c[5];
+    int rc = rbj(filter_type, fs, fc, qv, gain_db, c);
+    if (rc) return rc;
+    std::memcpy(&q->eq.coeffs[5 * band], c, sizeof(c));
+    q->eq.en[band] = enabled != 0;
+    return OHS_OK;
+}
+
+int ohs_eq_set_band_coeffs(ohs_eq *q, size_t band, const float coeffs[5], int enabled)
+{
+    if (!q || !coeffs) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (band >= q->eq.nb) return OHS_OK;
+    std::memcpy(&q->eq.coeffs[5 * band], coeffs, 5 * sizeof(float));
+    q->eq.en[band] = enabled != 0;
+    return OHS_OK;
+}
+
+int ohs_eq_get_band_coeffs(const ohs_eq *q, size_t band, float coeffs[5], int *enabled)
+{
+    if (!q || !coeffs || band >= q->eq.nb) return fail(OHS_ERR_INVALID_ARG, "bad argument");
+    std::memcpy(coeffs, &q->eq.coeffs[5 * band], 5 * sizeof(float));
+    if (enabled) *enabled = q->eq.en[band];
+    return OHS_OK;
+}
+
+int ohs_eq_process_block(ohs_eq *q, float *left, float *right, size_t n)
+{
+    if (!q) return fail(OHS_ERR_INVALID_ARG, "eq is NULL");
+    if (n == 0) return OHS_OK;
+    if (!left || !right) return fail(OHS_ERR_INVALID_ARG, "NULL audio pointer");
+    HIP_TRY(hipSetDevice(q->device));
+    if (n > q->buf_cap) {
+        size_t ncap = q->buf_cap ? q->buf_cap : 4 * BS;
+        while (ncap < n) ncap *= 2;
+        if (q->d_buf) hipFree(q->d_buf);
+        q->d_buf = nullptr; q->buf_cap = 0;
+        HIP_TRY(hipMalloc(&q->d_buf, 2 * ncap * sizeof(float)));
+        q->buf_cap = ncap;
+    }
+    HIP_TRY(hipMemcpyAsync(q->d_buf, left, n * sizeof(float), hipMemcpyHostToDevice, q->st));
+    HIP_TRY(hipMemcpyAsync(q->d_buf + q->buf_cap, right, n * sizeof(float), hipMemcpyHostToDevice, q->st));
+    int rc = eq_launch(q->eq, q->d_buf, q->d_buf, 0, (long long)q->buf_cap, (long long)n, q->st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(left, q->d_buf, n * sizeof(float), hipMemcpyDeviceToHost, q->st));
+    HIP_TRY(hipMemcpyAsync(right, q->d_buf + q->buf_cap, n * sizeof(float), hipMemcpyDeviceToHost, q->st));
+    HIP_TRY(hipStreamSynchronize(q->st));
+    return OHS_OK;
+}
+
+int ohs_eq_reset(ohs_eq *q)
+{
+    if (!q) return fail(OHS_ERR_INVALID_ARG, "eq is NULL");
+    HIP_TRY(hipSetDevice(q->device));
+    int rc = eq_reset(q->eq, q->st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(q->st));
+    return OHS_OK;
+}
+
+int ohs_eq_frequency_response(const ohs_eq *q, float fs, const float *freqs, size_t n, float *out)
+{
+    if (!q || (n && (!freqs || !out))) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (n == 0) return OHS_OK;
+    HIP_TRY(hipSetDevice(q->device));
+    const size_t nb = q->eq.nb;
+    float *d = nullptr;
+    const size_t words = nb * 5 + nb + 2 * n + 8;
+    HIP_TRY(hipMalloc(&d, words * sizeof(float)));
+    float *d_c = d, *d_f = d + nb * 5 + nb + 4, *d_o = d_f + n;
+    int *d_en = (int *)(d + nb * 5);
+    hipError_t e = hipSuccess;
+    if (nb) {
+        e = hipMemcpyAsync(d_c, q->eq.coeffs.data(), nb * 5 * sizeof(float), hipMemcpyHostToDevice, q->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_en, q->eq.en.data(), nb * sizeof(int), hipMemcpyHostToDevice, q->st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_f, freqs, n * sizeof(float), hipMemcpyHostToDevice, q->st);
+    if (e == hipSuccess) e = launch_eq_freq_response(d_c, d_en, (int)nb, fs, d_f, (int)n, d_o, q->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, n * sizeof(float), hipMemcpyDeviceToHost, q->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(q->st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(OHS_ERR_HIP, hipGetErrorString(e));
+    return OHS_OK;
+}
+
+// ---- chain -----------------------------------------------------------------------------
+int ohs_chain_process(ohs_engine *e, ohs_eq *eq, int bypass, int eq_enable, float gain, float *left,
+                      float *right, size_t n)
+{
+    if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
+    if (bypass) return OHS_OK;                               // lib.rs:1169
+    if (eq_enable && !eq) return fail(OHS_ERR_INVALID_ARG, "eq_enable set but eq is NULL");
+    if (eq_enable && eq->device != e->device) return fail(OHS_ERR_INVALID_ARG, "eq and engine on different devices");
+    return engine_process(e, left, right, left, right, n, eq_enable ? eq : nullptr, gain);
+}
+
+// ---- batch -----------------------------------------------------------------------------
+int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch **out)
+{
+    if (!out) return fail(OHS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_streams == 0 || n_streams > (1u << 20)) return fail(OHS_ERR_INVALID_ARG, "n_streams out of range");
+    DeviceCtx *ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    ohs_batch *b = new (std::nothrow) ohs_batch();
+    if (!b) return fail(OHS_ERR_ALLOC, "out of host memory");
+    b->device = device; b->ctx = ctx;
+    if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) {
+        delete b;
+        return fail(OHS_ERR_HIP, "hipStreamCreate failed");
+    }
+    rc = conv_init(b->conv, n_streams, b->st);
+    if (rc == OHS_OK) rc = eq_init(b->eq, num_bands, 2 * n_streams, 48000.0f, b->st);
+    if (rc == OHS_OK && hipStreamSynchronize(b->st) != hipSuccess) rc = fail(OHS_ERR_HIP, "sync failed");
+    if (rc) { ohs_batch_destroy(b); return rc; }
+    *out = b;
+    return OHS_OK;
+}
+
+void ohs_batch_destroy(ohs_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    conv_free(b->conv);
+    if (b->eq.d_state) hipFree(b->eq.d_state);
+    if (b->st) hipStreamDestroy(b->st);
+    delete b;
+}
+
+int ohs_batch_set_ir(ohs_batch *b, int path, const float *ir, size_t len)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return conv_set_ir(b->conv, b->ctx, path, ir, len, b->st);
+}
+
+int ohs_batch_set_eq_band_coeffs(ohs_batch *b, size_t band, const float coeffs[5], int enabled)
+{
+    if (!b || !coeffs) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (band >= b->eq.nb) return OHS_OK;
+    std::memcpy(&b->eq.coeffs[5 * band], coeffs, 5 * sizeof(float));
+    b->eq.en[band] = enabled != 0;
+    return OHS_OK;
+}
+
+int ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_type, float fc, float q,
+                             float gain_db, int enabled)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    if (band >= b->eq.nb) return OHS_OK;
+    float c[5];
+    int rc = rbj(filter_type, fs, fc, q, gain_db, c);
+    if (rc) return rc;
+    std::memcpy(&b->eq.coeffs[5 * band], c, sizeof(c));
+    b->eq.en[band] = enabled != 0;
+    return OHS_OK;
+}
+
+int ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    b->eq_enable = eq_enable != 0;
+    return OHS_OK;
+}
+
+int ohs_batch_set_gain(ohs_batch *b, float gain)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    b->gain = gain;
+    return OHS_OK;
+}
+
+int ohs_batch_reset(ohs_batch *b)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    ConvState &c = b->conv;
+    HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), b->st));
+    HIP_TRY(hipMemsetAsync(c.d_tails, 0, c.S * 2 * 8 * 64 * sizeof(float2), b->st));
+    c.cnt = 0;
+    for (int p = 0; p < 4; ++p) c.since[p] = 0;
+    int rc = eq_reset(b->eq, b->st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->st));
+    return OHS_OK;
+}
+
+int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                      size_t stream_stride, size_t channel_stride, void *hip_stream)
+{
+    if (!b || !d_in || !d_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (n_blocks == 0) return OHS_OK;
+    if (n_blocks > (size_t)1 << 24) return fail(OHS_ERR_INVALID_ARG, "n_blocks too large");
+    const size_t frames = n_blocks * BS;
+    if (channel_stride < frames || (b->conv.S > 1 && stream_stride < 2 * frames && stream_stride < channel_stride + frames))
+        return fail(OHS_ERR_INVALID_ARG, "strides smaller than the processed region");
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const float *src = d_in;
+    if (b->eq_enable) {       // lib.rs:1179
+        bool did = false;
+        int rc = eq_launch(b->eq, d_in, d_out, (long long)stream_stride, (long long)channel_stride,
+                           (long long)frames, st, &did);
+        if (rc) return rc;
+        if (did) src = d_out;
+    }
+    return conv_launch(b->conv, b->ctx, src, (long long)stream_stride, (long long)channel_stride, d_out,
+                       (long long)stream_stride, (long long)channel_stride, (int)n_blocks, b->gain, st);
+}
+
+int ohs_batch_sync(ohs_batch *b, void *hip_stream)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    return OHS_OK;
+}
+
+int ohs_batch_algorithmic_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *bytes)
+{
+    if (!b || !bytes) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    // SURVEY.md section 8d / DESIGN.md byte model, per 512-frame block per stream:
+    //   audio in 4096 + out 4096, history write 2*4104, history read 2*(P-1)*4104,
+    //   overlap read+write 2*(2048+2048), EQ state + coefficients ~520 (if EQ on),
+    //   HRIR spectra 4*P*4104 once per block-time, shared by all streams.
+    int P = 1;
+    for (int p = 0; p < 4; ++p) P = std::max(P, b->conv.P[p]);
+    const uint64_t per_stream_block = 4096u + 4096u + 2u * 4104u + 2u * (uint64_t)(P - 1) * 4104u +
+                                      2u * (2048u + 2048u) + (b->eq_enable ? 520u : 0u);
+    const uint64_t shared_per_block = 4u * (uint64_t)P * 4104u;
+    *bytes = (uint64_t)n_blocks * ((uint64_t)b->conv.S * per_stream_block + shared_per_block);
+    return OHS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// wave_fft.hpp -- one wavefront (64 lanes x 16 complex registers) computes one
+// complex FFT-1024 entirely in registers + a private 8.5 KiB LDS slab.
+//
+// This is the transform behind rustfft's `Fft::process` call sites in the
+// reference (src/dsp/convolution.rs:129,255,276): unnormalised, forward =
+// e^{-2 pi i jk/N}.  It is a from-scratch gfx950 design, not a port:
+//
+//   1024 = 16 x 16 x 4.  A lane never exchanges data with a butterfly partner;
+//   instead each lane runs whole radix-16 / radix-4 DFTs on its own registers and
+//   the wave re-distributes points twice through LDS (T1, T2).  No workgroup
+//   barrier is involved -- a wave is its own synchronisation domain.
+//
+//   time layout : lane m, reg a          holds z[64a + m]
+//   bin  layout : lane L, reg 4r + j     holds Z[4L + j + 256 r]
+//
+//   forward: DFT16(a->p) . w1024^(m p) . T1 . DFT16(b->q) . w64^(c q) . T2 . DFT4(c->r)
+//   inverse: the same graph run backwards with conjugated twiddles.
+//
+// LDS images (complex = 8 B units), both conflict-free for ds_read_b64/ds_write_b64
+// except a 2-way conflict on the inverse T2 write (tools/proto_wave_fft.py checks
+// the index plan and the bank census on the CPU):
+//   T1: addr = 68 p + m                        (m = 4b + c)
+//   T2: addr = 65 (4 p_lo + c) + sigma(q, p_hi), sigma = 16(p_hi&1) + 8(p_hi>>1) + (q&7) + 32(q>>3)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ohs {
+
+constexpr int kBlock = 512;
+constexpr int kFft = 1024;
+constexpr int kWaveLdsComplex = 16 * 68;   // per-wave LDS slab, in float2 units (8704 B)
+
+// twiddle tables kept in LDS per workgroup (float2 units)
+constexpr int kTabA = 0;              // [16][64]  w1024^(m p)            lane m,  reg p   (forward)
+constexpr int kTabB = 16 * 64;        // [16][64]  w64^((L1&3) q)         lane L1, reg q   (forward)
+constexpr int kTabC = 32 * 64;        // [4][64]   w64^(c (L2>>2))        lane L2, reg c   (inverse, conj)
+constexpr int kTabD = 36 * 64;        // [16][64]  w1024^((4b+c) p)       lane L1, reg b   (inverse, conj)
+constexpr int kTabComplex = 52 * 64;  // 3328 float2 = 26 KiB
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+template <bool CONJ>
+__device__ __forceinline__ float2 ctw(float2 a, float2 w) { return CONJ ? cmulc(a, w) : cmul(a, w); }
+
+// LDS write -> read hand-off inside one wave: DS operations of a wave execute in
+// order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 4-point DFT in place: (a,b,c,d) = inputs 0..3 -> outputs 0..3
+template <bool INV>
+__device__ __forceinline__ void dft4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+    // forward: -j*(b-d); inverse: +j*(b-d)
+    const float2 jb = INV ? make_float2(-bmd.y, bmd.x) : make_float2(bmd.y, -bmd.x);
+    a = cadd(apc, bpd);
+    b = cadd(amc, jb);
+    c = csub(apc, bpd);
+    d = csub(amc, jb);
+}
+
+// multiply by w16^e (forward) or its conjugate (inverse), e a compile-time constant
+template <bool INV, int E>
+__device__ __forceinline__ float2 mul_w16(float2 a)
+{
+    constexpr float C1 = 0.92387953251128674f;  // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977f;  // sin(pi/8)
+    constexpr float R2 = 0.70710678118654752f;  // sqrt(1/2)
+    if constexpr (E == 0) return a;
+    // forward twiddle w = (wr, -wi); inverse = (wr, +wi)
+    else if constexpr (E == 1) return ctw<INV>(a, make_float2(C1, -S1));
+    else if constexpr (E == 2)
+        return INV ? make_float2((a.x - a.y) * R2, (a.x + a.y) * R2)
+                   : make_float2((a.x + a.y) * R2, (a.y - a.x) * R2);
+    else if constexpr (E == 3) return ctw<INV>(a, make_float2(S1, -C1));
+    else if constexpr (E == 4) return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    else if constexpr (E == 6)
+        return INV ? make_float2((-a.x - a.y) * R2, (a.x - a.y) * R2)
+                   : make_float2((a.y - a.x) * R2, (-a.x - a.y) * R2);
+    else /* E == 9 */ return ctw<INV>(a, make_float2(-C1, S1));
+}
+
+// 16-point DFT on registers, natural order in, natural order out.
+template <bool INV>
+__device__ __forceinline__ void dft16(float2 (&v)[16])
+{
+    // n = 4 n1 + n2 ; k = k1 + 4 k2
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    // now v[4 k1 + n2] = t[n2][k1]; twiddle by w16^(n2 k1)
+    v[5] = mul_w16<INV, 1>(v[5]);
+    v[6] = mul_w16<INV, 2>(v[6]);
+    v[7] = mul_w16<INV, 3>(v[7]);
+    v[9] = mul_w16<INV, 2>(v[9]);
+    v[10] = mul_w16<INV, 4>(v[10]);
+    v[11] = mul_w16<INV, 6>(v[11]);
+    v[13] = mul_w16<INV, 3>(v[13]);
+    v[14] = mul_w16<INV, 6>(v[14]);
+    v[15] = mul_w16<INV, 9>(v[15]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    // v[4 k1 + k2] = X[k1 + 4 k2]  -> transpose the 4x4 register grid (pure renaming)
+    float2 t;
+    t = v[1];  v[1] = v[4];   v[4] = t;
+    t = v[2];  v[2] = v[8];   v[8] = t;
+    t = v[3];  v[3] = v[12];  v[12] = t;
+    t = v[6];  v[6] = v[9];   v[9] = t;
+    t = v[7];  v[7] = v[13];  v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// Fill the 26 KiB of per-workgroup twiddle tables from the 1024-entry master
+// table tw[e] = exp(-2 pi i e / 1024) (f64-computed on the host, rounded to f32).
+__device__ __forceinline__ void fill_twiddle_tables(float2 *tab, const float2 *__restrict__ tw,
+                                                    int tid, int nthreads)
+{
+    for (int i = tid; i < 16 * 64; i += nthreads) {
+        const int r = i >> 6, l = i & 63;
+        tab[kTabA + i] = tw[(l * r) & 1023];                            // w1024^(m p)
+        tab[kTabB + i] = tw[(16 * (l & 3) * r) & 1023];                 // w64^(c q)
+        tab[kTabD + i] = tw[((4 * r + (l & 3)) * (l >> 2)) & 1023];     // w1024^((4b+c) p)
+    }
+    for (int i = tid; i < 4 * 64; i += nthreads) {
+        const int c = i >> 6, l = i & 63;
+        tab[kTabC + i] = tw[(16 * c * (l >> 2)) & 1023];                // w64^(c q)
+    }
+}
+
+__device__ __forceinline__ int t2_sigma(int q, int p_hi)
+{
+    return 16 * (p_hi & 1) + 8 * (p_hi >> 1) + (q & 7) + 32 * (q >> 3);
+}
+
+// time layout -> bin layout (unnormalised forward DFT)
+__device__ __forceinline__ void wave_fft_fwd(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
+{
+    dft16<false>(v);                                        // over a -> p
+#pragma unroll
+    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], tab[kTabA + p * 64 + lane]);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) lds[68 * p + lane] = v[p];  // T1
+    wave_lds_sync();
+    const int pp = lane >> 2, c = lane & 3;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = lds[68 * pp + 4 * b + c];
+    wave_lds_sync();
+    dft16<false>(v);                                        // over b -> q
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tab[kTabB + q * 64 + lane]);
+    const int p_lo = pp & 3, p_hi = pp >> 2;
+    const int wbase = 65 * (4 * p_lo + c) + 16 * (p_hi & 1) + 8 * (p_hi >> 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lds[wbase + (q & 7) + 32 * (q >> 3)] = v[q];  // T2
+    wave_lds_sync();
+    const int rbase = t2_sigma(lane >> 2, lane & 3);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) v[rr] = lds[65 * rr + rbase];   // rr = 4 p_lo + c
+    wave_lds_sync();
+    // DFT4 over c for each j = p_lo; result to reg 4 r + j
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dft4<false>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    float2 t;   // (j, r) -> (r, j): 4x4 register transpose
+    t = v[1];  v[1] = v[4];   v[4] = t;
+    t = v[2];  v[2] = v[8];   v[8] = t;
+    t = v[3];  v[3] = v[12];  v[12] = t;
+    t = v[6];  v[6] = v[9];   v[9] = t;
+    t = v[7];  v[7] = v[13];  v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// bin layout -> time layout (unnormalised inverse DFT)
+__device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
+{
+    float2 t;   // (r, j) -> (j, r)
+    t = v[1];  v[1] = v[4];   v[4] = t;
+    t = v[2];  v[2] = v[8];   v[8] = t;
+    t = v[3];  v[3] = v[12];  v[12] = t;
+    t = v[6];  v[6] = v[9];   v[9] = t;
+    t = v[7];  v[7] = v[13];  v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        const float2 w = tab[kTabC + c * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
+    }
+    const int rbase = t2_sigma(lane >> 2, lane & 3);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) lds[65 * rr + rbase] = v[rr];     // T2'
+    wave_lds_sync();
+    const int pp = lane >> 2, c = lane & 3;
+    const int p_lo = pp & 3, p_hi = pp >> 2;
+    const int wbase = 65 * (4 * p_lo + c) + 16 * (p_hi & 1) + 8 * (p_hi >> 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = lds[wbase + (q & 7) + 32 * (q >> 3)];
+    wave_lds_sync();
+    dft16<true>(v);                                         // over q -> b
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], tab[kTabD + b * 64 + lane]);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds[68 * pp + 4 * b + c] = v[b];    // T1'
+    wave_lds_sync();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) v[p] = lds[68 * p + lane];
+    wave_lds_sync();
+    dft16<true>(v);                                         // over p -> a
+}
+
+// Fetch, for every register of the bin layout, the value at bin (N - k).
+__device__ __forceinline__ void wave_mirror(const float2 (&z)[16], float2 (&zm)[16], int lane)
+{
+    const int srcA = (63 - lane) << 2;          // j = 1..3 : lane 63-L
+    const int srcB = ((64 - lane) & 63) << 2;   // j = 0    : lane 64-L (lane 0 -> itself)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const float2 s = z[4 * (3 - r) + (4 - j)];
+            zm[4 * r + j].x = __int_as_float(__builtin_amdgcn_ds_bpermute(srcA, __float_as_int(s.x)));
+            zm[4 * r + j].y = __int_as_float(__builtin_amdgcn_ds_bpermute(srcA, __float_as_int(s.y)));
+        }
+        // j == 0: lanes 1..63 take reg 4(3-r) of lane 64-L; lane 0 takes its own reg 4((4-r)&3)
+        const float2 s = z[4 * (3 - r)];
+        const float2 own = z[4 * ((4 - r) & 3)];
+        float2 g;
+        g.x = __int_as_float(__builtin_amdgcn_ds_bpermute(srcB, __float_as_int(s.x)));
+        g.y = __int_as_float(__builtin_amdgcn_ds_bpermute(srcB, __float_as_int(s.y)));
+        zm[4 * r] = (lane == 0) ? own : g;
+    }
+}
+
+}  // namespace ohs

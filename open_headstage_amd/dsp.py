@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's `src/dsp` interface over the C ABI.
+
+Same names, argument meaning and error behaviour as the Rust types so that the
+parity tests read like the reference's own tests:
+
+  ConvolutionPath        src/dsp/convolution.rs:28-33
+  ConvolutionEngine      src/dsp/convolution.rs:68-295    new / set_ir / process_block / clone
+  FilterType, BandConfig src/dsp/parametric_eq.rs:23-44
+  StereoParametricEQ     src/dsp/parametric_eq.rs:125-210
+  process_chain          src/lib.rs:1169-1207             (EQ -> convolution -> gain)
+
+Where the reference panics (slice-length mismatch convolution.rs:164; `unwrap`
+on OutsideNyquist / NegativeQ parametric_eq.rs:111) these raise.
+All arithmetic runs in the HIP kernels behind libohs_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, fp, lib
+
+BLOCK_SIZE = 512   # convolution.rs:22
+FFT_SIZE = 1024    # convolution.rs:23
+NUM_EQ_BANDS = 10  # lib.rs:40
+
+
+class ConvolutionPath(enum.IntEnum):
+    Lsl = 0
+    Lsr = 1
+    Rsl = 2
+    Rsr = 3
+
+
+class FilterType(enum.IntEnum):
+    Peak = 0
+    LowShelf = 1
+    HighShelf = 2
+    LowPass = 3
+    HighPass = 4
+    BandPass = 5
+    Notch = 6
+    AllPass = 7
+
+
+@dataclass
+class BandConfig:
+    filter_type: FilterType = FilterType.Peak
+    center_freq: float = 1000.0
+    q: float = 0.7
+    gain_db: float = 0.0
+    enabled: bool = False
+
+
+def _in(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).ravel()
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(fp)
+
+
+def _out(a, n: int, name: str) -> np.ndarray:
+    if a is None:
+        return np.empty(n, np.float32)
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous and a.ndim == 1):
+        raise TypeError(f"{name} must be a contiguous 1-D float32 ndarray")
+    if a.size != n:   # copy_from_slice panics on a length mismatch (convolution.rs:164,170)
+        raise ValueError(f"{name} has {a.size} frames, input has {n}")
+    return a
+
+
+class ConvolutionEngine:
+    def __init__(self, device: int = 0, _handle=None):
+        self.device = device
+        if _handle is None:
+            h = C.c_void_p()
+            check(lib().ohs_engine_create(device, C.byref(h)))
+            _handle = h
+        self._h = _handle
+
+    @classmethod
+    def new(cls, device: int = 0) -> "ConvolutionEngine":
+        return cls(device)
+
+    def clone(self) -> "ConvolutionEngine":
+        h = C.c_void_p()
+        check(lib().ohs_engine_clone(self._h, C.byref(h)))
+        return ConvolutionEngine(self.device, h)
+
+    def set_ir(self, path, ir_data) -> None:
+        ir = _in(ir_data)
+        check(lib().ohs_engine_set_ir(self._h, int(path), _ptr(ir), ir.size))
+
+    def num_partitions(self, path) -> int:
+        n = C.c_size_t()
+        check(lib().ohs_engine_num_partitions(self._h, int(path), C.byref(n)))
+        return int(n.value)
+
+    def process_block(self, input_left, input_right, output_left=None, output_right=None):
+        il, ir = _in(input_left), _in(input_right)
+        if il.size != ir.size:
+            raise ValueError("input_left / input_right length mismatch")
+        ol = _out(output_left, il.size, "output_left")
+        orr = _out(output_right, il.size, "output_right")
+        check(lib().ohs_engine_process_block(self._h, _ptr(il), _ptr(ir), _ptr(ol), _ptr(orr), il.size))
+        return ol, orr
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().ohs_engine_destroy(h)
+            except Exception:
+                pass
+
+
+def biquad_coefficients(filter_type, sample_rate: float, center_freq: float, q: float,
+                        gain_db: float) -> np.ndarray:
+    """biquad::Coefficients::<f32>::from_params -> [b0, b1, b2, a1, a2]."""
+    out = np.zeros(5, np.float32)
+    check(lib().ohs_biquad_coeffs(int(filter_type), sample_rate, center_freq, q, gain_db, _ptr(out)))
+    return out
+
+
+class StereoParametricEQ:
+    def __init__(self, num_bands: int, initial_sample_rate: float, device: int = 0):
+        self.num_bands = int(num_bands)
+        self.device = device
+        h = C.c_void_p()
+        check(lib().ohs_eq_create(device, self.num_bands, initial_sample_rate, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def new(cls, num_bands: int, initial_sample_rate: float, device: int = 0):
+        return cls(num_bands, initial_sample_rate, device)
+
+    def update_band_coeffs(self, band_idx: int, sample_rate: float, config: BandConfig) -> None:
+        check(lib().ohs_eq_update_band(self._h, int(band_idx), sample_rate, int(config.filter_type),
+                                       config.center_freq, config.q, config.gain_db,
+                                       int(bool(config.enabled))))
+
+    def set_band_coeffs(self, band_idx: int, coeffs, enabled: bool) -> None:
+        c = _in(coeffs)
+        if c.size != 5:
+            raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
+        check(lib().ohs_eq_set_band_coeffs(self._h, int(band_idx), _ptr(c), int(bool(enabled))))
+
+    def get_band_coeffs(self, band_idx: int):
+        c = np.zeros(5, np.float32)
+        en = C.c_int()
+        check(lib().ohs_eq_get_band_coeffs(self._h, int(band_idx), _ptr(c), C.byref(en)))
+        return c, bool(en.value)
+
+    def process_block(self, input_left: np.ndarray, input_right: np.ndarray) -> None:
+        """In place, like `process_block(&mut [f32], &mut [f32])`."""
+        for a in (input_left, input_right):
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous):
+                raise TypeError("in-place EQ needs contiguous float32 ndarrays")
+        if input_left.size != input_right.size:
+            raise ValueError("left / right length mismatch")
+        check(lib().ohs_eq_process_block(self._h, _ptr(input_left), _ptr(input_right), input_left.size))
+
+    def reset_all_bands_state(self) -> None:
+        check(lib().ohs_eq_reset(self._h))
+
+    def calculate_frequency_response(self, sample_rate: float, frequencies) -> np.ndarray:
+        f = _in(frequencies)
+        out = np.empty(f.size, np.float32)
+        check(lib().ohs_eq_frequency_response(self._h, sample_rate, _ptr(f), f.size, _ptr(out)))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().ohs_eq_destroy(h)
+            except Exception:
+                pass
+
+
+def process_chain(engine: ConvolutionEngine, eq: StereoParametricEQ | None, left: np.ndarray,
+                  right: np.ndarray, *, master_bypass: bool = False, eq_enable: bool = False,
+                  output_gain: float = 1.0) -> None:
+    """The DSP part of `Plugin::process` (lib.rs:1169-1207), in place on left/right."""
+    for a in (left, right):
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous):
+            raise TypeError("process_chain needs contiguous float32 ndarrays")
+    if left.size != right.size:
+        raise ValueError("Mismatched channel length")
+    check(lib().ohs_chain_process(engine._h, eq._h if eq is not None else None, int(master_bypass),
+                                  int(eq_enable), output_gain, _ptr(left), _ptr(right), left.size))

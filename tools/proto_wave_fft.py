@@ -1,0 +1,162 @@
+"""numpy prototype of the per-wave FFT-1024 index plan used by csrc/wave_fft.hpp.
+
+One wavefront (64 lanes) x 16 complex registers per lane = 1024 points.
+Forward:  time layout  lane m, reg a  : z[64a+m]
+          A: DFT16 over a -> p ; twiddle w1024^(m p) ; T1 (LDS) ;
+          B: DFT16 over b -> q ; twiddle w64^(c q)   ; T2 (LDS) ;
+          C: DFT4  over c -> r
+          bin layout   lane L=4q+p_hi, reg 4r+j   : Z[4L + j + 256 r]
+Inverse runs the same steps backwards with conjugated twiddles.
+Run: python tools/proto_wave_fft.py   (asserts, prints max errors)
+"""
+import numpy as np
+
+N = 1024
+def w(n, e):  # exp(-2 pi i e / n)
+    return np.exp(-2j * np.pi * e / n)
+
+def addr1(p, m):            # T1 image, complex units
+    return 68 * p + m
+def sigma(q, p_hi):
+    return 16 * (p_hi & 1) + 8 * (p_hi >> 1) + (q & 7) + 32 * (q >> 3)
+def addr2(p_lo, c, q, p_hi):  # T2 image
+    return 65 * (4 * p_lo + c) + sigma(q, p_hi)
+
+def dft_small(v, n, sign):
+    k = np.arange(n)
+    M = np.exp(sign * -2j * np.pi * np.outer(k, k) / n)
+    return M @ v
+
+def fwd(z):
+    regs = np.zeros((64, 16), complex)
+    for m in range(64):
+        for a in range(16):
+            regs[m, a] = z[64 * a + m]
+    # A + twiddle 1
+    for m in range(64):
+        u = dft_small(regs[m], 16, +1)
+        for p in range(16):
+            u[p] *= w(1024, m * p)
+        regs[m] = u
+    lds = np.zeros(16 * 68, complex)
+    for m in range(64):
+        for p in range(16):
+            lds[addr1(p, m)] = regs[m, p]
+    for L1 in range(64):
+        p, c = L1 >> 2, L1 & 3
+        for b in range(16):
+            regs[L1, b] = lds[addr1(p, 4 * b + c)]
+    # B + twiddle 2
+    for L1 in range(64):
+        c = L1 & 3
+        u = dft_small(regs[L1], 16, +1)
+        for q in range(16):
+            u[q] *= w(64, c * q)
+        regs[L1] = u
+    lds = np.zeros(16 * 65 + 64, complex)
+    for L1 in range(64):
+        p, c = L1 >> 2, L1 & 3
+        p_hi, p_lo = p >> 2, p & 3
+        for q in range(16):
+            lds[addr2(p_lo, c, q, p_hi)] = regs[L1, q]
+    for L2 in range(64):
+        q, p_hi = L2 >> 2, L2 & 3
+        for p_lo in range(4):
+            for c in range(4):
+                regs[L2, 4 * p_lo + c] = lds[addr2(p_lo, c, q, p_hi)]
+    # C: DFT4 over c for each p_lo; result stored reg 4r + j (j = p_lo)
+    out = np.zeros((64, 16), complex)
+    for L2 in range(64):
+        for j in range(4):
+            u = dft_small(regs[L2, 4 * j:4 * j + 4], 4, +1)
+            for r in range(4):
+                out[L2, 4 * r + j] = u[r]
+    return out
+
+def bins_of(L, reg):
+    r, j = reg >> 2, reg & 3
+    return 4 * L + j + 256 * r
+
+def inv(W):  # W in bin layout -> time layout (unnormalised)
+    regs = np.zeros((64, 16), complex)
+    for L2 in range(64):
+        for j in range(4):
+            v = np.array([W[L2, 4 * r + j] for r in range(4)])
+            u = dft_small(v, 4, -1)               # over r -> c
+            q = L2 >> 2
+            for c in range(4):
+                regs[L2, 4 * j + c] = u[c] * np.conj(w(64, c * q))
+    lds = np.zeros(16 * 65 + 64, complex)
+    for L2 in range(64):
+        q, p_hi = L2 >> 2, L2 & 3
+        for p_lo in range(4):
+            for c in range(4):
+                lds[addr2(p_lo, c, q, p_hi)] = regs[L2, 4 * p_lo + c]
+    for L1 in range(64):
+        p, c = L1 >> 2, L1 & 3
+        for q in range(16):
+            regs[L1, q] = lds[addr2(p & 3, c, q, p >> 2)]
+    for L1 in range(64):
+        p, c = L1 >> 2, L1 & 3
+        u = dft_small(regs[L1], 16, -1)           # over q -> b
+        for b in range(16):
+            u[b] *= np.conj(w(1024, (4 * b + c) * p))
+        regs[L1] = u
+    lds = np.zeros(16 * 68, complex)
+    for L1 in range(64):
+        p, c = L1 >> 2, L1 & 3
+        for b in range(16):
+            lds[addr1(p, 4 * b + c)] = regs[L1, b]
+    for m in range(64):
+        for p in range(16):
+            regs[m, p] = lds[addr1(p, m)]
+    out = np.zeros((64, 16), complex)
+    for m in range(64):
+        out[m] = dft_small(regs[m], 16, -1)       # over p -> a
+    return out
+
+def mirror_src(L, reg):
+    """(lane, reg) holding bin N-k for the bin k held at (L, reg)."""
+    r, j = reg >> 2, reg & 3
+    if j:
+        return 63 - L, 4 * (3 - r) + (4 - j)
+    if L:
+        return 64 - L, 4 * (3 - r)
+    return 0, 4 * ((4 - r) & 3)
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    z = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    Z = fwd(z)
+    ref = np.fft.fft(z)
+    err = max(abs(Z[L, g] - ref[bins_of(L, g)]) for L in range(64) for g in range(16))
+    print("fwd max err", err); assert err < 1e-9
+    for L in range(64):
+        for g in range(16):
+            sl, sg = mirror_src(L, g)
+            assert bins_of(sl, sg) == (N - bins_of(L, g)) % N
+    y = inv(Z)
+    err = max(abs(y[m, a] / N - z[64 * a + m]) for m in range(64) for a in range(16))
+    print("roundtrip max err", err); assert err < 1e-9
+    # LDS bank-conflict census (b64 accesses; complex address = bank pair)
+    def worst(groups, f, nb):
+        wv = 0
+        for g in groups:
+            for reg in range(16):
+                cnt = {}
+                for lane in g:
+                    bk = f(lane, reg) % nb
+                    cnt[bk] = cnt.get(bk, 0) + 1
+                wv = max(wv, max(cnt.values()))
+        return wv
+    halves = [range(0, 32), range(32, 64)]
+    g16 = [range(i, i + 16) for i in range(0, 64, 16)]
+    print("T1 fwd write", worst(g16, lambda m, p: addr1(p, m), 16),
+          "read", worst(halves, lambda L, b: addr1(L >> 2, 4 * b + (L & 3)), 32))
+    print("T2 fwd write", worst(g16, lambda L, q: addr2((L >> 2) & 3, L & 3, q, L >> 4), 16),
+          "read", worst(halves, lambda L, g: addr2(g >> 2, g & 3, L >> 2, L & 3), 32))
+    print("T2 inv write", worst(g16, lambda L, g: addr2(g >> 2, g & 3, L >> 2, L & 3), 16),
+          "read", worst(halves, lambda L, q: addr2((L >> 2) & 3, L & 3, q, L >> 4), 32))
+    print("T1 inv write", worst(g16, lambda L, b: addr1(L >> 2, 4 * b + (L & 3)), 16),
+          "read", worst(halves, lambda m, p: addr1(p, m), 32))
+    print("OK")
