@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json `metric` on its configs[2] workload.
+
+  workload : 256 concurrent stereo streams per GPU, 4 x 512-tap HRIR partitioned FFT convolution
+             + 10-band parametric EQ + output gain, 48 kHz f32, synthetic white noise
+             (SURVEY.md section 8d generators), data resident in HBM.
+  step     : one pass of the hot path over one batch = every stream advanced by
+             `--frames` frames (default 480256 = 938 internal blocks ~ 10 s of audio).
+  value    : whole-job stereo frames per second, in Msamples/s (1 sample = one L+R frame).
+  scaling  : weak -- 256 streams per GPU; streams are sharded by contiguous id range, no
+             data-path collective; the shared HRIR set + EQ table is broadcast once from
+             rank 0 (RCCL over xGMI via torch.distributed "nccl").
+
+Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STREAMS_PER_GPU = 256
+TAPS = 512
+FS = 48000.0
+
+
+def cpu_baseline(frames: int, target_seconds: float = 12.0):
+    """Times the CPU oracle (oracle/ohs_oracle.c, kind "port": a C restatement that keeps the
+    reference's structure -- 4 forward + 4 inverse complex FFT-1024 per block, four per-path
+    histories, serial DF2T cascade) on this box's host cores.  Bounded sample of the same
+    workload: whole streams of `frames` frames, host block 1024 (lib.rs process cadence)."""
+    from oracle import ohs_oracle as orc
+    from open_headstage_amd import synth
+
+    orc.build()
+    irs = synth.hrir_set(TAPS)
+    bands = synth.eq_table()
+    coeffs = [orc.biquad_coeffs(int(b.filter_type), FS, b.center_freq, b.q, b.gain_db) for b in bands]
+    sample_frames = min(frames, 480256)
+    sample_frames -= sample_frames % 1024
+
+    def run_stream(sid: int) -> None:
+        eng = orc.ConvolutionEngine()
+        for p in range(4):
+            eng.set_ir(p, irs[p])
+        eq = orc.StereoParametricEQ(len(bands), FS)
+        for i, b in enumerate(bands):
+            eq.set_band_coeffs(i, coeffs[i], b.enabled)
+        x = synth.white_noise([sid], sample_frames)[0]
+        for c in range(sample_frames // 1024):
+            l = x[0, c * 1024:(c + 1) * 1024]
+            r = x[1, c * 1024:(c + 1) * 1024]
+            orc.chain_process(eng, eq, l, r, eq_enable=True, gain=1.0)
+
+    t0 = time.perf_counter()
+    run_stream(0)
+    t1 = time.perf_counter() - t0
+    single = sample_frames / t1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    per_thread = max(1, int(round(target_seconds / max(t1, 1e-3))))
+    per_thread = min(per_thread, 64)
+
+    def worker(tid: int) -> None:
+        for k in range(per_thread):
+            run_stream(1 + tid * per_thread + k)      # ctypes releases the GIL inside the oracle
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    tm = time.perf_counter() - t0
+    total = cores * per_thread * sample_frames
+    return {
+        "value": round(total / tm / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{cores} threads x {per_thread} streams x {sample_frames} frames "
+                  f"(4x{TAPS}-tap + 10-band EQ, host block 1024), oracle/ohs_oracle.c -O3 -mavx2 "
+                  f"-ffp-contract=off",
+        "single_thread_value": round(single / 1e6, 4),
+        "x_realtime_per_core": round(single / FS, 1),
+    }
+
+
+def load_traffic(kernel: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/pmc_latest.json),
+    written by tools/pmc_summary.py with the gfx950 FETCH_SIZE x2 correction; None if absent."""
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+        return d.get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=480256, help="frames per stream per step (multiple of 512)")
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    import open_headstage_amd as ohs
+    from open_headstage_amd import sharding, synth
+
+    frames = args.frames - args.frames % 512
+    n_blocks = frames // 512
+    S = args.streams
+    bands = synth.eq_table()
+    nb = len(bands)
+
+    # ---- shared tables: built on rank 0, one RCCL broadcast (HRIR set + EQ coefficients) ----
+    if rank == 0:
+        irs = synth.hrir_set(TAPS)
+        coeffs = np.stack([ohs.biquad_coefficients(b.filter_type, FS, b.center_freq, b.q, b.gain_db)
+                           for b in bands])
+        enabled = np.array([b.enabled for b in bands])
+    else:
+        irs = coeffs = enabled = None
+    if distributed:
+        irs, coeffs, enabled = sharding.broadcast_tables(irs, coeffs, enabled, TAPS, nb, device, src=0)
+
+    bp = ohs.BatchProcessor(S, num_bands=nb, device=local_rank)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i in range(nb):
+        bp.set_band_coeffs(i, coeffs[i], bool(enabled[i]))
+    bp.set_eq_enabled(True)
+    bp.set_gain(0.8912509)      # -1 dB output gain (lib.rs:1202-1207)
+
+    # ---- this rank's shard of the stream ids, synthetic audio generated in HBM ----
+    ids = sharding.shard_range(S * world, rank, world)
+    x = synth.white_noise_torch(ids.start, len(ids), frames, device)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+
+    def step():
+        bp.process(x, out=y)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    bp.set_profiling(True)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    eq_ms, conv_ms, n_calls = bp.profile_read()
+    bp.set_profiling(False)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ok = bool(torch.isfinite(y).all().item())
+    total_frames = float(S) * world * frames * args.steps
+    value = total_frames / elapsed / 1e6
+
+    if rank == 0:
+        eq_b, conv_b = bp.kernel_bytes(n_blocks)
+        kernels = {
+            "k_eq_pass": (eq_ms / max(n_calls, 1), eq_b),
+            "k_conv_general": (conv_ms / max(n_calls, 1), conv_b),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dom_ms, dom_bytes = kernels[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        whole = bp.algorithmic_bytes(n_blocks)
+        out = {
+            "metric": "Msamples/s stereo 48 kHz (4x512-tap HRIR conv + 10-band EQ); % HBM3E peak",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: 256 concurrent stereo streams per GPU, 4x512-tap HRIR "
+                            "partitioned FFT conv (block 512, FFT 1024, P=1) + 10-band EQ + gain, 48 kHz",
+                "streams_per_gpu": S,
+                "frames_per_stream_per_step": frames,
+                "taps": TAPS,
+                "eq_bands": nb,
+                "parallelism": f"streams sharded x{world}, HRIR+EQ tables broadcast once (RCCL)",
+            },
+            "x_realtime_per_gpu": round(value * 1e6 / world / FS, 1),
+            "hbm_frac_whole_path": round(whole * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBS, 5),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": load_traffic(dom),
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "avg_launch_ms": round(dom_ms, 4),
+                "kernels_ms": {k: round(v[0], 4) for k, v in kernels.items()},
+            },
+            "finite": ok,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -81,6 +81,20 @@ class BatchProcessor:
     def sync(self, hip_stream: int = 0) -> None:
         check(lib().ohs_batch_sync(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
+    def set_profiling(self, enable: bool) -> None:
+        check(lib().ohs_batch_set_profiling(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """(eq_ms, conv_ms, n_calls) accumulated since the last read; waits for the events."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
+        check(lib().ohs_batch_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, int(n.value)
+
+    def kernel_bytes(self, n_blocks: int):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().ohs_batch_kernel_bytes(self._h, int(n_blocks), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def algorithmic_bytes(self, n_blocks: int) -> int:
         v = C.c_uint64()
         check(lib().ohs_batch_algorithmic_bytes(self._h, int(n_blocks), C.byref(v)))

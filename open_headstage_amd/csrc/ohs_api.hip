@@ -402,6 +402,11 @@ struct ohs_batch {
     EqState eq;
     int eq_enable = 0;
     float gain = 1.0f;
+    // optional per-kernel timing
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;      // triples: before EQ, between, after conv
+    std::vector<char> ev_has_eq;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
@@ -797,6 +802,8 @@ void ohs_batch_destroy(ohs_batch *b)
     hipDeviceSynchronize();
     conv_free(b->conv);
     if (b->eq.d_state) hipFree(b->eq.d_state);
+    for (hipEvent_t e : b->ev) hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_pool) hipEventDestroy(e);
     if (b->st) hipStreamDestroy(b->st);
     delete b;
 }
@@ -872,16 +879,58 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
         return fail(OHS_ERR_INVALID_ARG, "strides smaller than the processed region");
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)hip_stream;
+    hipEvent_t e3[3] = {nullptr, nullptr, nullptr};
+    if (b->profiling) {
+        for (int i = 0; i < 3; ++i) {
+            if (!b->ev_pool.empty()) { e3[i] = b->ev_pool.back(); b->ev_pool.pop_back(); }
+            else HIP_TRY(hipEventCreate(&e3[i]));
+        }
+        HIP_TRY(hipEventRecord(e3[0], st));
+    }
     const float *src = d_in;
+    bool did = false;
     if (b->eq_enable) {       // lib.rs:1179
-        bool did = false;
         int rc = eq_launch(b->eq, d_in, d_out, (long long)stream_stride, (long long)channel_stride,
                            (long long)frames, st, &did);
         if (rc) return rc;
         if (did) src = d_out;
     }
-    return conv_launch(b->conv, b->ctx, src, (long long)stream_stride, (long long)channel_stride, d_out,
-                       (long long)stream_stride, (long long)channel_stride, (int)n_blocks, b->gain, st);
+    if (b->profiling) HIP_TRY(hipEventRecord(e3[1], st));
+    int rc = conv_launch(b->conv, b->ctx, src, (long long)stream_stride, (long long)channel_stride, d_out,
+                         (long long)stream_stride, (long long)channel_stride, (int)n_blocks, b->gain, st);
+    if (b->profiling) {
+        HIP_TRY(hipEventRecord(e3[2], st));
+        for (int i = 0; i < 3; ++i) b->ev.push_back(e3[i]);
+        b->ev_has_eq.push_back(did ? 1 : 0);
+    }
+    return rc;
+}
+
+int ohs_batch_set_profiling(ohs_batch *b, int enable)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    b->profiling = enable != 0;
+    return OHS_OK;
+}
+
+int ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls)
+{
+    if (!b || !eq_ms || !conv_ms || !n_calls) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(b->device));
+    double te = 0.0, tc = 0.0;
+    const size_t n = b->ev.size() / 3;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(b->ev[3 * i + 2]));
+        if (b->ev_has_eq[i]) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[3 * i], b->ev[3 * i + 1])); te += ms; }
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[3 * i + 1], b->ev[3 * i + 2]));
+        tc += ms;
+    }
+    for (hipEvent_t e : b->ev) b->ev_pool.push_back(e);
+    b->ev.clear();
+    b->ev_has_eq.clear();
+    *eq_ms = te; *conv_ms = tc; *n_calls = n;
+    return OHS_OK;
 }
 
 int ohs_batch_sync(ohs_batch *b, void *hip_stream)
@@ -905,6 +954,20 @@ int ohs_batch_algorithmic_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *b
                                       2u * (2048u + 2048u) + (b->eq_enable ? 520u : 0u);
     const uint64_t shared_per_block = 4u * (uint64_t)P * 4104u;
     *bytes = (uint64_t)n_blocks * ((uint64_t)b->conv.S * per_stream_block + shared_per_block);
+    return OHS_OK;
+}
+
+int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_bytes, uint64_t *conv_bytes)
+{
+    if (!b || !eq_bytes || !conv_bytes) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    int P = 1;
+    for (int p = 0; p < 4; ++p) P = std::max(P, b->conv.P[p]);
+    // EQ kernel: audio in + out, state + coefficients.  Convolution kernel: audio in + out,
+    // history write + read, overlap read + write, HRIR spectra once per block-time.
+    const uint64_t eq_sb = 4096u + 4096u + 520u;
+    const uint64_t conv_sb = 4096u + 4096u + 2u * 4104u + 2u * (uint64_t)(P - 1) * 4104u + 2u * (2048u + 2048u);
+    *eq_bytes = b->eq_enable ? (uint64_t)n_blocks * b->conv.S * eq_sb : 0;
+    *conv_bytes = (uint64_t)n_blocks * ((uint64_t)b->conv.S * conv_sb + 4u * (uint64_t)P * 4104u);
     return OHS_OK;
 }
 
