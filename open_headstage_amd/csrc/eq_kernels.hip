@@ -15,61 +15,181 @@
 //   sample t-j-1.  The arithmetic each band performs, and its order, are those
 //   of the reference's sample-major / band-minor loop.
 //
-// Samples enter at lane 0 and leave at lane 15, 16 at a time: each row loads /
-// stores 64 contiguous bytes per 16 steps.  More than 16 bands = several passes.
+// Samples enter at lane 0 and leave at lane NB-1; a second register per lane (the "conveyor")
+// carries 16 inputs in and 16 outputs out per chunk with one more DPP move per step, so each
+// row loads / stores 64 contiguous bytes per 16 steps and the inner loop has no LDS or memory
+// instruction at all.  More than 16 bands = several passes.
 #include "kernels.h"
+
+#include <cstdlib>
 
 namespace ohs {
 
-__device__ __forceinline__ float row_bcast(float v, int src_lane)
-{
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// lane j of each 16-lane row receives lane j-1's `v`; lane 0 of the row receives `feed`.
-__device__ __forceinline__ float row_shift_in(float v, float feed)
+// DPP move: lanes whose source lane lies outside their 16-lane row keep `old`.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float src)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(feed), __float_as_int(v),
-                                                      0x111 /* row_shr:1 */, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL,
+                                                      0xf, 0xf, false));
 }
+constexpr int kRowShr1 = 0x111;   // lane j <- lane j-1
+constexpr int kRowShl1 = 0x101;   // lane j <- lane j+1
 
-template <bool GATED>
-__device__ __forceinline__ void eq_chunk(long long t0, long long n, int j, int rowbase, bool en,
+// One chunk = 16 systolic steps.  Register roles per lane j of a row:
+//   prev : this band's output of the previous step (what lane j+1 filters next)
+//   c    : the row's conveyor.  It enters a chunk holding 16 input samples (lane i = x[t0+i]),
+//          moves one lane to the left per step so that lane 0 always sees the next input, and
+//          takes one finished sample per step in at lane 15; it leaves the chunk holding 16
+//          finished samples (lane i = y[t0 + i - NB]).
+// SHR = 16 - NB brings the last band's (lane NB-1) output to lane 15; lanes >= NB are don't-care.
+// SEL  : some band of this pass is disabled -> pass-through select (parametric_eq.rs:118-120).
+// GATED: first / last chunks, where a lane's sample index t - j can fall outside [0, n).
+template <int SHR, bool SEL, bool GATED>
+__device__ __forceinline__ void eq_chunk(long long t0, long long n, int j, bool en,
                                          float b0, float b1, float b2, float a1, float a2,
-                                         float &s1, float &s2, float &prev, float xchunk, float &ychunk)
+                                         float &s1, float &s2, float &prev, float &c)
 {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        // lane 15's output of the previous step is y[t0 + k - 16]
-        const float ydone = row_bcast(prev, rowbase + 15);
-        ychunk = (j == k) ? ydone : ychunk;
-        const float feed = row_bcast(xchunk, rowbase + k);
-        const float x = row_shift_in(prev, feed);
+        float yv = prev;
+        if constexpr (SHR != 0) yv = dpp_mov<0x110 + SHR>(prev, prev);
+        const float x = dpp_mov<kRowShr1>(c, prev);    // lane 0 <- c (next input sample)
+        c = dpp_mov<kRowShl1>(yv, c);                  // lane 15 <- finished sample
         const float out = s1 + b0 * x;
         const float n1 = (s2 + b1 * x) - a1 * out;
         const float n2 = b2 * x - a2 * out;
-        bool upd = en;
-        if (GATED) {
-            const long long u = t0 + k - j;        // sample index this lane is filtering
-            upd = en && u >= 0 && u < n;
+        if constexpr (GATED || SEL) {
+            bool upd = en;
+            if constexpr (GATED) {
+                const long long u = t0 + k - j;        // sample index this lane is filtering
+                upd = en && u >= 0 && u < n;
+            }
+            s1 = upd ? n1 : s1;
+            s2 = upd ? n2 : s2;
+            prev = upd ? out : x;
+        } else {
+            s1 = n1; s2 = n2; prev = out;
         }
-        s1 = upd ? n1 : s1;
-        s2 = upd ? n2 : s2;
-        prev = upd ? out : x;                      // disabled band = identity (parametric_eq.rs:118-120)
     }
 }
 
+// Steady-state chunk (every lane's sample index valid, every band of the pass enabled): 16 steps
+// in ONE hand-scheduled asm block.  A step is 9 VALU instructions in two 3-deep dependency chains
+//     out(t) -> row_shr:1 -> b0*x -> s1 + .            (hand-over to the next band)
+//     out(t) -> (a1,a2)*out -> (t2,b2x) - .  -> s1(t+1) (this band's recurrence)
+// On gfx950 a lone wave issues a VALU op every ~4.5 cycles but a DEPENDENT op waits ~8 cycles
+// (measured: tools/ubench.hip), so the chains are interleaved with the side work (conveyor moves,
+// b1/b2 products): ~41 cycles per sample instead of the ~100 hipcc's own order reaches.
+// The arithmetic is the reference's, operand for operand: 5 products and 4 sums, each rounded
+// separately (v_pk_mul_f32 / v_pk_add_f32 are two independent IEEE f32 operations).
+//   v100 = out        v[108:109] = (b1 x -> t2, b2 x)      v[112:113] = (s1, s2)
+//   v114 = b0 x       v[110:111] = (a1 out, a2 out)
+//   v102 / v104 / v106 rotate through the roles conveyor -> x -> scratch, so that the conveyor shift
+//   itself provides the "old" lanes of the next DPP move and no register copy is needed.
+#define EQ_NOP "s_nop 0\n"
+#define EQ_YS(RY) "v_mov_b32_dpp " RY ", v100 row_shr:%[shr] row_mask:0xf bank_mask:0xf\n"
+#define EQ_Y0(RY) "v_mov_b32 " RY ", v100\n"
+#define EQ_C(RY, RC) "v_mov_b32_dpp " RY ", " RC " row_shl:1 row_mask:0xf bank_mask:0xf\n"
+#define EQ_D(RC) "v_mov_b32_dpp " RC ", v100 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define EQ_M(RX) "v_mul_f32 v114, %[b0], " RX "\n"
+#define EQ_P(RXP) "v_pk_mul_f32 v[108:109], %[b12], " RXP " op_sel_hi:[1,0]\n"
+#define EQ_O "v_add_f32 v100, v112, v114\n"
+#define EQ_T "v_add_f32 v108, v113, v108\n"
+#define EQ_A "v_pk_mul_f32 v[110:111], %[a12], v[100:101] op_sel_hi:[1,0]\n"
+#define EQ_N "v_pk_add_f32 v[112:113], v[108:109], v[110:111] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define EQ_BODY \
+        EQ_Y("v104") EQ_C("v104", "v102") EQ_D("v102") EQ_M("v102") EQ_P("v[102:103]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v106") EQ_A EQ_C("v106", "v104") EQ_D("v104") EQ_N EQ_M("v104") EQ_P("v[104:105]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v102") EQ_A EQ_C("v102", "v106") EQ_D("v106") EQ_N EQ_M("v106") EQ_P("v[106:107]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v104") EQ_A EQ_C("v104", "v102") EQ_D("v102") EQ_N EQ_M("v102") EQ_P("v[102:103]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v106") EQ_A EQ_C("v106", "v104") EQ_D("v104") EQ_N EQ_M("v104") EQ_P("v[104:105]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v102") EQ_A EQ_C("v102", "v106") EQ_D("v106") EQ_N EQ_M("v106") EQ_P("v[106:107]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v104") EQ_A EQ_C("v104", "v102") EQ_D("v102") EQ_N EQ_M("v102") EQ_P("v[102:103]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v106") EQ_A EQ_C("v106", "v104") EQ_D("v104") EQ_N EQ_M("v104") EQ_P("v[104:105]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v102") EQ_A EQ_C("v102", "v106") EQ_D("v106") EQ_N EQ_M("v106") EQ_P("v[106:107]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v104") EQ_A EQ_C("v104", "v102") EQ_D("v102") EQ_N EQ_M("v102") EQ_P("v[102:103]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v106") EQ_A EQ_C("v106", "v104") EQ_D("v104") EQ_N EQ_M("v104") EQ_P("v[104:105]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v102") EQ_A EQ_C("v102", "v106") EQ_D("v106") EQ_N EQ_M("v106") EQ_P("v[106:107]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v104") EQ_A EQ_C("v104", "v102") EQ_D("v102") EQ_N EQ_M("v102") EQ_P("v[102:103]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v106") EQ_A EQ_C("v106", "v104") EQ_D("v104") EQ_N EQ_M("v104") EQ_P("v[104:105]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v102") EQ_A EQ_C("v102", "v106") EQ_D("v106") EQ_N EQ_M("v106") EQ_P("v[106:107]") \
+        EQ_O EQ_T EQ_NOP EQ_Y("v104") EQ_A EQ_C("v104", "v102") EQ_D("v102") EQ_N EQ_M("v102") EQ_P("v[102:103]") \
+        EQ_O EQ_T EQ_A EQ_N
+
+#define EQ_IN "v_mov_b32 v100, %[o]\n v_mov_b32 v112, %[s1]\n v_mov_b32 v113, %[s2]\n v_mov_b32 v102, %[c]\n"
+#define EQ_OUT "v_mov_b32 %[s1], v112\n v_mov_b32 %[s2], v113\n v_mov_b32 %[o], v100\n v_mov_b32 %[c], v104\n"
+#define EQ_CLOBBERS "v100", "v102", "v104", "v106", "v108", "v109", "v110", "v111", "v112", "v113", "v114"
+template <int SHR>
+__device__ __forceinline__ void eq_chunk_fast(float b0, v2f b12, v2f a12, float &s1, float &s2, float &o, float &c)
+{
+    if constexpr (SHR != 0) {
+#define EQ_Y(RY) EQ_YS(RY)
+        asm volatile(EQ_IN EQ_BODY EQ_OUT
+                     : [s1] "+v"(s1), [s2] "+v"(s2), [o] "+v"(o), [c] "+v"(c)
+                     : [b0] "v"(b0), [b12] "v"(b12), [a12] "v"(a12), [shr] "n"(SHR)
+                     : EQ_CLOBBERS);
+#undef EQ_Y
+    } else {
+#define EQ_Y(RY) EQ_Y0(RY)
+        asm volatile(EQ_IN EQ_BODY EQ_OUT
+                     : [s1] "+v"(s1), [s2] "+v"(s2), [o] "+v"(o), [c] "+v"(c)
+                     : [b0] "v"(b0), [b12] "v"(b12), [a12] "v"(a12)
+                     : EQ_CLOBBERS);
+#undef EQ_Y
+    }
+}
+
+// Untracked (inline-asm) global accesses for the interior of the stream.  hipcc cannot count
+// vmcnt across the chunk loop and falls back to `s_waitcnt vmcnt(0)` in front of every chunk,
+// which serialises each chunk behind the store it has just issued (+~500 cycles per 16 samples).
+// Here the queue is counted by hand: per group of G = 8 chunks one wave issues 8 prefetch loads,
+// then 8 stores, and `s_waitcnt vmcnt(8)` (all but the 8 youngest = the stores) retires the loads.
+__device__ __forceinline__ void eq_load8(float (&v)[8], const float *p)
+{
+    asm volatile("global_load_dword %0, %8, off\n"
+                 "global_load_dword %1, %8, off offset:64\n"
+                 "global_load_dword %2, %8, off offset:128\n"
+                 "global_load_dword %3, %8, off offset:192\n"
+                 "global_load_dword %4, %8, off offset:256\n"
+                 "global_load_dword %5, %8, off offset:320\n"
+                 "global_load_dword %6, %8, off offset:384\n"
+                 "global_load_dword %7, %8, off offset:448\n"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]),
+                   "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p)
+                 : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void eq_store1(float *p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off offset:%2" : : "v"(p), "v"(v), "n"(OFF) : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding; ties the loaded
+// registers to the wait so that no use of them can be scheduled above it
+template <int N>
+__device__ __forceinline__ void eq_wait_loads(float (&v)[8])
+{
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "n"(N)
+                 : "memory");
+}
+
+template <int SHR, bool SEL>
 __global__ __launch_bounds__(64) void k_eq_pass(const float *in, float *out,
                                                 long long stream_stride, long long ch_stride,
                                                 long long n, int n_chains, const EqPassTable tab,
                                                 float *__restrict__ state)
 {
+    constexpr int NB = 16 - SHR;
+    constexpr int G = 8;            // chunks per group (128 samples per chain)
     const int lane = threadIdx.x;
     const int j = lane & 15;
-    const int rowbase = lane & 48;
     const long long chain = (long long)blockIdx.x * 4 + (lane >> 4);
     const bool live = chain < n_chains;
-    const long long cc = live ? chain : 0;
+    const long long cc = live ? chain : 0;      // dead rows shadow chain 0 but never store
     const float *src = in + (cc >> 1) * stream_stride + (cc & 1) * ch_stride;
     float *dst = out + (cc >> 1) * stream_stride + (cc & 1) * ch_stride;
 
@@ -77,37 +197,102 @@ __global__ __launch_bounds__(64) void k_eq_pass(const float *in, float *out,
     const bool en = tab.en[j] != 0;
     float s1 = state[(cc * 16 + j) * 2 + 0];
     float s2 = state[(cc * 16 + j) * 2 + 1];
-    float prev = 0.0f, ychunk = 0.0f;
+    float prev = 0.0f, c = 0.0f;
 
-    // steps t = 0 .. n+15; chunk q covers steps 16q .. 16q+15 and completes y[16(q-1) .. 16q-1]
-    const long long n_chunks = (n + 16 + 15) / 16;
-    for (long long q = 0; q < n_chunks; ++q) {
-        const long long t0 = q * 16;
-        const long long xi = t0 + j;
-        const float xchunk = (live && xi < n) ? src[xi] : 0.0f;
-        // a chunk needs gating when some lane's sample index t0+k-j can fall outside [0, n)
-        if (t0 >= 16 && t0 + 16 <= n) eq_chunk<false>(t0, n, j, rowbase, en, b0, b1, b2, a1, a2, s1, s2, prev, xchunk, ychunk);
-        else                          eq_chunk<true>(t0, n, j, rowbase, en, b0, b1, b2, a1, a2, s1, s2, prev, xchunk, ychunk);
-        // after step 16q+15, ychunk (lane j) = y[16(q-1) + j]
-        if (q >= 1) {
-            const long long yi = t0 - 16 + j;
-            if (live && yi < n) dst[yi] = ychunk;
-        }
+    // the finished sample y[i] enters the conveyor at step i + NB; chunk q covers steps 16q..16q+15
+    const long long n_chunks = (n - 1 + NB) / 16 + 1;
+    const long long n_groups = (n_chunks + G - 1) / G;
+    // groups [1, g_fast_end) are "interior": all 8 chunks ungated, the prefetch of the next group and
+    // every store in bounds, every row of the wave live
+    long long g_fast_end = n / (16 * G) - 1;            // (g + 2) * 128 <= n
+    const bool all_live = ((long long)blockIdx.x * 4 + 3) < n_chains;
+    if (SEL || !all_live) g_fast_end = 0;
+
+    float cur[G], nxt[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) {
+        const long long xi = (long long)e * 16 + j;
+        cur[e] = (live && xi < n) ? src[xi] : 0.0f;
     }
-    if (live) {
+    for (long long g = 0; g < n_groups; ++g) {
+        if (g >= 1 && g < g_fast_end) {
+            if constexpr (!SEL) {
+                const float *lp = src + (g + 1) * (16 * G) + j;
+                float *sp = dst + g * (16 * G) - 16 - NB + j;
+                eq_load8(nxt, lp);
+#define OHS_EQ_FAST_CHUNK(E)                                                             \
+                eq_store1<64 * E>(sp, c);                                                \
+                c = cur[E];                                                              \
+                eq_chunk_fast<SHR>(b0, (v2f){b1, b2}, (v2f){a1, a2}, s1, s2, prev, c);
+                OHS_EQ_FAST_CHUNK(0) OHS_EQ_FAST_CHUNK(1) OHS_EQ_FAST_CHUNK(2) OHS_EQ_FAST_CHUNK(3)
+                OHS_EQ_FAST_CHUNK(4) OHS_EQ_FAST_CHUNK(5) OHS_EQ_FAST_CHUNK(6) OHS_EQ_FAST_CHUNK(7)
+#undef OHS_EQ_FAST_CHUNK
+                eq_wait_loads<8>(nxt);
+            }
+        } else {
+            if (g == g_fast_end && g_fast_end > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const long long xi = ((g + 1) * G + e) * 16 + j;
+                nxt[e] = (live && xi < n) ? src[xi] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const long long q = g * G + e;
+                if (q < n_chunks) {
+                    const long long t0 = q * 16;
+                    // conveyor hand-over: drain 16 finished samples y[t0 - 16 - NB + i], refill with inputs
+                    const long long yi = t0 - 16 - NB + j;
+                    if (live && yi >= 0 && yi < n) dst[yi] = c;
+                    c = cur[e];
+                    if (t0 >= 16 && t0 + 16 <= n)
+                        eq_chunk<SHR, SEL, false>(t0, n, j, en, b0, b1, b2, a1, a2, s1, s2, prev, c);
+                    else
+                        eq_chunk<SHR, SEL, true>(t0, n, j, en, b0, b1, b2, a1, a2, s1, s2, prev, c);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < G; ++e) cur[e] = nxt[e];
+    }
+    {
+        const long long yi = n_chunks * 16 - 16 - NB + j;
+        if (live && yi >= 0 && yi < n) dst[yi] = c;
+    }
+    if (live && j < NB) {
         state[(cc * 16 + j) * 2 + 0] = s1;
         state[(cc * 16 + j) * 2 + 1] = s2;
     }
 }
 
+template <int SHR>
+static hipError_t launch_eq_shr(bool sel, int blocks, hipStream_t st, const float *in, float *out,
+                                long long ss, long long cs, long long n, int n_chains,
+                                const EqPassTable &tab, float *state)
+{
+    if (sel) hipLaunchKernelGGL((k_eq_pass<SHR, true>), dim3(blocks), dim3(64), 0, st, in, out, ss, cs, n, n_chains, tab, state);
+    else     hipLaunchKernelGGL((k_eq_pass<SHR, false>), dim3(blocks), dim3(64), 0, st, in, out, ss, cs, n, n_chains, tab, state);
+    return hipGetLastError();
+}
+
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
-                          long long n, int n_chains, const EqPassTable &tab, float *state, hipStream_t st)
+                          long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
+                          hipStream_t st)
 {
     if (n <= 0 || n_chains <= 0) return hipSuccess;
+    if (n_bands < 1 || n_bands > 16) return hipErrorInvalidValue;
     const int blocks = (n_chains + 3) / 4;
-    hipLaunchKernelGGL(k_eq_pass, dim3(blocks), dim3(64), 0, st, in, out, stream_stride, ch_stride, n,
-                       n_chains, tab, state);
-    return hipGetLastError();
+    bool sel = false;       // some band of this pass disabled -> pass-through select variant
+    for (int j = 0; j < n_bands; ++j) sel = sel || !tab.en[j];
+#define OHS_EQ_CASE(NBV) \
+    case NBV: return launch_eq_shr<16 - NBV>(sel, blocks, st, in, out, stream_stride, ch_stride, n, n_chains, tab, state);
+    switch (n_bands) {
+        OHS_EQ_CASE(1) OHS_EQ_CASE(2) OHS_EQ_CASE(3) OHS_EQ_CASE(4) OHS_EQ_CASE(5) OHS_EQ_CASE(6)
+        OHS_EQ_CASE(7) OHS_EQ_CASE(8) OHS_EQ_CASE(9) OHS_EQ_CASE(10) OHS_EQ_CASE(11) OHS_EQ_CASE(12)
+        OHS_EQ_CASE(13) OHS_EQ_CASE(14) OHS_EQ_CASE(15) OHS_EQ_CASE(16)
+    }
+#undef OHS_EQ_CASE
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------

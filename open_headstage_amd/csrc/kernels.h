@@ -49,8 +49,9 @@ struct EqPassTable {
 };
 // chains = streams * 2 (L, R); chain c -> stream c>>1, channel c&1.
 // state: [chain][16][2] (s1, s2) for this pass.
+// n_bands = bands of this pass (1..16, lanes >= n_bands are unused).
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
-                          long long n, int n_chains, const EqPassTable &tab, float *state,
+                          long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
                           hipStream_t st);
 
 // |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]

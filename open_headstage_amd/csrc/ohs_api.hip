@@ -250,16 +250,18 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
         EqPassTable t;
         std::memset(&t, 0, sizeof(t));
         bool any = false;
+        int nbp = 0;
         for (int j = 0; j < 16; ++j) {
             const size_t b = (size_t)pass * 16 + j;
             if (b >= e.nb) break;
+            nbp = j + 1;
             t.b0[j] = e.coeffs[5 * b + 0]; t.b1[j] = e.coeffs[5 * b + 1]; t.b2[j] = e.coeffs[5 * b + 2];
             t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
             t.en[j] = e.en[b];
             any = any || e.en[b];
         }
         if (!any) continue;   // a pass of disabled bands is the identity, bit for bit (parametric_eq.rs:118-120)
-        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t,
+        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp,
                                         e.d_state + (size_t)pass * e.chains * 16 * 2, st);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
