@@ -172,6 +172,184 @@ hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStrea
 }
 
 // ---------------------------------------------------------------------------------
+// P = 1 fast path (BASELINE configs 2, 3, 5: 4 x 512-tap HRIRs).
+//
+//   Z  = FFT(x_l + j x_r)                        one forward transform for both channels
+//   W  = Z C + conj(Z[N-k]) D                    = Y_l + j Y_r  (all four paths, both ears)
+//   w  = IFFT(W):  re = out_l, im = out_r        one inverse transform for both ears
+//
+// Blocks of one stream only couple through the 512-sample overlap tail, so a stream is cut
+// into `chunks` contiguous block ranges that run as independent waves; the tail leaving each
+// chunk goes to a scratch slab and k_conv_p1_fixup adds it to the next chunk's first block.
+// The spectrum history ring is not written: with one partition it is never read
+// (convolution.rs:261-273 with P = 1 touches history[idx] only in the block that wrote it).
+// The last block of the launch keeps the reference's four separate overlap buffers (two
+// packed inverse transforms) so that the state at rest is the general kernel's format and a
+// later per-path set_ir can zero exactly one path's overlap (convolution.rs:138).
+// ---------------------------------------------------------------------------------
+__global__ void k_build_cd(const float2 *__restrict__ h0, const float2 *__restrict__ h1,
+                           const float2 *__restrict__ h2, const float2 *__restrict__ h3,
+                           float2 *__restrict__ cd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kFft) return;
+    const float2 a = make_float2(h0[i].x - h1[i].y, h0[i].y + h1[i].x);   // A = H0 + j H1
+    const float2 b = make_float2(h2[i].x - h3[i].y, h2[i].y + h3[i].x);   // B = H2 + j H3
+    cd[i] = make_float2(0.5f * (a.x + b.y), 0.5f * (a.y - b.x));          // (A - jB)/2
+    cd[kFft + i] = make_float2(0.5f * (a.x - b.y), 0.5f * (a.y + b.x));   // (A + jB)/2
+}
+hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
+                           float2 *cd, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_build_cd, dim3(kFft / 256), dim3(256), 0, st, h0, h1, h2, h3, cd);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_conv_p1(const ConvP1Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    if (gw >= (long long)A.n_streams * A.chunks) return;
+    const size_t s = (size_t)(gw / A.chunks);
+    const int ck = (int)(gw % A.chunks);
+    const int b0 = (int)((long long)ck * A.n_blocks / A.chunks);
+    const int b1 = (int)((long long)(ck + 1) * A.n_blocks / A.chunks);
+    if (b0 >= b1) return;
+
+    const float *in_l = A.in + s * A.in_stream_stride;
+    const float *in_r = in_l + A.in_ch_stride;
+    float *out_l = A.out + s * A.out_stream_stride;
+    float *out_r = out_l + A.out_ch_stride;
+    const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
+    float2 *tails_out = A.tails_out + s * (size_t)(2 * 8 * 64);
+    const float scale = 1.0f / (float)kFft;
+
+    float2 C[16], D[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        C[r] = A.CD[r * 64 + lane];
+        D[r] = A.CD[kFft + r * 64 + lane];
+    }
+    float2 tail[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        if (b0 == 0) {
+            const float2 t1 = tails[a * 64 + lane], t2 = tails[(8 + a) * 64 + lane];
+            tail[a] = make_float2(t1.x + t2.x, t1.y + t2.y);
+        } else {
+            tail[a] = make_float2(0.0f, 0.0f);      // k_conv_p1_fixup adds the previous chunk's tail
+        }
+    }
+
+    float2 xn[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const size_t idx = (size_t)b0 * kBlock + 64 * a + lane;
+        xn[a] = make_float2(in_l[idx], in_r[idx]);
+    }
+    for (int t = b0; t < b1; ++t) {
+        float2 v[16];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { v[a] = xn[a]; v[a + 8] = make_float2(0.0f, 0.0f); }
+        if (t + 1 < b1) {        // prefetch the next block's input under this block's transforms
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const size_t idx = (size_t)(t + 1) * kBlock + 64 * a + lane;
+                xn[a] = make_float2(in_l[idx], in_r[idx]);
+            }
+        }
+        wave_fft_fwd(v, lds, tab, lane);
+        float2 zm[16];
+        wave_mirror(v, zm, lane);
+        if (t != A.n_blocks - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // W = Z C + conj(Zm) D
+                const float2 z = v[r], m = zm[r];
+                float2 w;
+                w.x = z.x * C[r].x - z.y * C[r].y + m.x * D[r].x + m.y * D[r].y;
+                w.y = z.x * C[r].y + z.y * C[r].x + m.x * D[r].y - m.y * D[r].x;
+                v[r] = w;
+            }
+            wave_fft_inv(v, lds, tab, lane);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+                out_l[idx] = (v[a].x * scale + tail[a].x) * A.gain;
+                out_r[idx] = (v[a].y * scale + tail[a].y) * A.gain;
+                tail[a] = make_float2(v[a + 8].x * scale, v[a + 8].y * scale);
+            }
+        } else {
+            // last block of the launch: four separate overlap tails, as the general kernel keeps them
+            float2 acc1[16], acc2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 xl = make_float2(0.5f * (v[r].x + zm[r].x), 0.5f * (v[r].y - zm[r].y));
+                const float2 xr = make_float2(0.5f * (v[r].y + zm[r].y), -0.5f * (v[r].x - zm[r].x));
+                const float2 y0 = cmul(xl, A.H[0][r * 64 + lane]);
+                const float2 y1 = cmul(xl, A.H[1][r * 64 + lane]);
+                const float2 y2 = cmul(xr, A.H[2][r * 64 + lane]);
+                const float2 y3 = cmul(xr, A.H[3][r * 64 + lane]);
+                acc1[r] = make_float2(y0.x - y1.y, y0.y + y1.x);
+                acc2[r] = make_float2(y2.x - y3.y, y2.y + y3.x);
+            }
+            wave_fft_inv(acc1, lds, tab, lane);
+            wave_fft_inv(acc2, lds, tab, lane);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+                out_l[idx] = ((acc1[a].x * scale + tail[a].x) + acc2[a].x * scale) * A.gain;
+                out_r[idx] = ((acc1[a].y * scale + tail[a].y) + acc2[a].y * scale) * A.gain;
+                // new state goes to a second slab: another chunk's wave may still be reading `tails`
+                tails_out[a * 64 + lane] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
+                tails_out[(8 + a) * 64 + lane] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
+            }
+        }
+    }
+    if (b1 != A.n_blocks) {
+        float2 *ct = A.chunk_tails + (s * A.chunks + ck) * (size_t)(8 * 64);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) ct[a * 64 + lane] = tail[a];
+    }
+}
+
+// out[first block of chunk ck] += gain * (tail leaving chunk ck-1), ck = 1..chunks-1
+__global__ __launch_bounds__(256) void k_conv_p1_fixup(const ConvP1Args A)
+{
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;   // over S * (K-1) * 512
+    const long long per_stream = (long long)(A.chunks - 1) * 512;
+    if (gid >= (long long)A.n_streams * per_stream) return;
+    const size_t s = (size_t)(gid / per_stream);
+    const int rem = (int)(gid % per_stream);
+    const int ck = 1 + rem / 512, i = rem % 512;
+    const int b0 = (int)((long long)ck * A.n_blocks / A.chunks);
+    // chunks <= n_blocks (host-checked), so every chunk is non-empty and wrote its tail
+    const float2 t = A.chunk_tails[(s * A.chunks + (ck - 1)) * (size_t)512 + i];
+    float *out_l = A.out + s * A.out_stream_stride;
+    float *out_r = out_l + A.out_ch_stride;
+    const size_t idx = (size_t)b0 * kBlock + i;
+    out_l[idx] += t.x * A.gain;
+    out_r[idx] += t.y * A.gain;
+}
+
+hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
+    const long long waves = (long long)a.n_streams * a.chunks;
+    hipLaunchKernelGGL(k_conv_p1, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.chunks <= 1) return e;
+    const long long n = (long long)a.n_streams * (a.chunks - 1) * 512;
+    hipLaunchKernelGGL(k_conv_p1_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // Diagnostic: natural-order complex FFT-1024 through wave_fft_fwd / wave_fft_inv
 // (one wave per transform).  Used by the tests to measure the primitive's accuracy.
 // ---------------------------------------------------------------------------------

@@ -26,6 +26,30 @@ struct ConvGeneralArgs {
 };
 hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st);
 
+// Fast path when every path has exactly one partition (taps <= 512): time-parallel over
+// `chunks` contiguous block ranges per stream, one forward + one inverse FFT per block, the
+// combined spectra C = (A - jB)/2, D = (A + jB)/2 (A = H0 + jH1, B = H2 + jH3) held in registers.
+struct ConvP1Args {
+    const float *in;
+    float *out;
+    long long in_stream_stride, in_ch_stride;
+    long long out_stream_stride, out_ch_stride;
+    int n_blocks;
+    int n_streams;
+    int chunks;                 // K contiguous block ranges per stream
+    const float2 *CD;           // [2][16][64]: C then D, bin layout
+    const float2 *H[4];         // single-partition spectra (used for the last block: split tails)
+    const float2 *tails;        // [stream][2][8][64] state in, same format as the general kernel
+    float2 *tails_out;          // state out (a different slab; the host swaps them after the launch)
+    float2 *chunk_tails;        // [stream][chunks][8][64] scratch: tail leaving each chunk
+    const float2 *tw;
+    float gain;
+};
+hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
+// CD[0][..] = (A - jB)/2, CD[1][..] = (A + jB)/2 from four single-partition spectra
+hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
+                           float2 *cd, hipStream_t st);
+
 // IR chunk -> spectrum: dst[part][16][64], one wave per partition.
 hipError_t launch_ir_spectrum(const float *d_ir, int len, int n_parts, float2 *dst,
                               const float2 *tw, hipStream_t st);

@@ -99,6 +99,12 @@ struct ConvState {
     int cap = 1;
     unsigned long long cnt = 0;
     float2 *d_tails = nullptr;      // [S][2][8][64]
+    // P = 1 fast path
+    float2 *d_tails_alt = nullptr;  // second state slab (k_conv_p1 writes its new tails here)
+    float2 *d_cd = nullptr;         // [2][1024] combined spectra C, D
+    bool cd_valid = false;
+    float2 *d_chunk_tails = nullptr;
+    size_t chunk_tails_cap = 0;     // in chunks per stream
 };
 
 void conv_free(ConvState &c)
@@ -106,7 +112,10 @@ void conv_free(ConvState &c)
     for (int p = 0; p < 4; ++p) { if (c.d_H[p]) hipFree(c.d_H[p]); c.d_H[p] = nullptr; }
     if (c.d_hist) hipFree(c.d_hist);
     if (c.d_tails) hipFree(c.d_tails);
-    c.d_hist = nullptr; c.d_tails = nullptr;
+    if (c.d_tails_alt) hipFree(c.d_tails_alt);
+    if (c.d_cd) hipFree(c.d_cd);
+    if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
+    c.d_hist = nullptr; c.d_tails = nullptr; c.d_tails_alt = nullptr; c.d_cd = nullptr; c.d_chunk_tails = nullptr;
 }
 
 int conv_init(ConvState &c, size_t S, hipStream_t st)
@@ -125,6 +134,9 @@ int conv_init(ConvState &c, size_t S, hipStream_t st)
     HIP_TRY(hipMemsetAsync(c.d_hist, 0, S * (size_t)c.cap * NF * sizeof(float2), st));
     HIP_TRY(hipMalloc(&c.d_tails, S * 2 * 8 * 64 * sizeof(float2)));
     HIP_TRY(hipMemsetAsync(c.d_tails, 0, S * 2 * 8 * 64 * sizeof(float2), st));
+    HIP_TRY(hipMalloc(&c.d_tails_alt, S * 2 * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c.d_cd, 2 * NF * sizeof(float2)));
+    c.cd_valid = false;
     return OHS_OK;
 }
 
@@ -179,6 +191,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     hipFree(c.d_H[path]);
     c.d_H[path] = nH;
     c.P[path] = P;
+    c.cd_valid = false;
     c.since[path] = 0;      // :135-137 that path's history is "all zero" again
     // :138 that path's overlap := 0.  Tails are (lsl + j lsr) and (rsl + j rsr).
     const int which = path >> 1, comp = path & 1;
@@ -188,18 +201,52 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
 }
 
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
-                float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st)
+                float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
+                bool allow_fast = true)
 {
-    ConvGeneralArgs a;
-    a.in = in; a.out = out;
-    a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
-    a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
-    a.n_blocks = n_blocks;
-    for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
-    a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
-    a.tails = c.d_tails; a.tw = ctx->d_tw; a.gain = gain;
-    hipError_t e = launch_conv_general(a, (int)c.S, st);
-    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+    const bool p1 = c.P[0] == 1 && c.P[1] == 1 && c.P[2] == 1 && c.P[3] == 1;
+    if (p1 && allow_fast) {
+        // every path has one partition: time-parallel single-FFT-pair kernel
+        if (!c.cd_valid) {
+            hipError_t e = launch_build_cd(c.d_H[0], c.d_H[1], c.d_H[2], c.d_H[3], c.d_cd, st);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("build_cd: ") + hipGetErrorString(e));
+            c.cd_valid = true;
+        }
+        // enough waves to fill 256 CUs x 8 resident waves a couple of times over
+        long long K = (4096 + (long long)c.S - 1) / (long long)c.S;
+        if (K > n_blocks) K = n_blocks;
+        if (K < 1) K = 1;
+        if ((size_t)K > c.chunk_tails_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
+            c.d_chunk_tails = nullptr; c.chunk_tails_cap = 0;
+            HIP_TRY(hipMalloc(&c.d_chunk_tails, c.S * (size_t)K * 512 * sizeof(float2)));
+            c.chunk_tails_cap = (size_t)K;
+        }
+        ConvP1Args a;
+        a.in = in; a.out = out;
+        a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+        a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+        a.n_blocks = n_blocks; a.n_streams = (int)c.S; a.chunks = (int)K;
+        a.CD = c.d_cd;
+        for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
+        a.tails = c.d_tails; a.tails_out = c.d_tails_alt; a.chunk_tails = c.d_chunk_tails;
+        a.tw = ctx->d_tw; a.gain = gain;
+        hipError_t e = launch_conv_p1(a, st);
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
+        std::swap(c.d_tails, c.d_tails_alt);
+    } else {
+        ConvGeneralArgs a;
+        a.in = in; a.out = out;
+        a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+        a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+        a.n_blocks = n_blocks;
+        for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
+        a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
+        a.tails = c.d_tails; a.tw = ctx->d_tw; a.gain = gain;
+        hipError_t e = launch_conv_general(a, (int)c.S, st);
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+    }
     c.cnt += (unsigned long long)n_blocks;
     for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;
     return OHS_OK;
@@ -450,8 +497,9 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     if (k) {
         rc = fifo_reserve(e->out, e->out.len + k * BS, st);
         if (rc) return rc;
+        // a couple of blocks: one launch of the general kernel; long offline calls: time-parallel path
         rc = conv_launch(e->conv, e->ctx, e->in.d, 0, (long long)e->in.cap, e->out.d + e->out.len, 0,
-                         (long long)e->out.cap, (int)k, 1.0f, st);
+                         (long long)e->out.cap, (int)k, 1.0f, st, /*allow_fast=*/k >= 4);
         if (rc) return rc;
         e->out.len += k * BS;
         rc = fifo_drop_front(e->in, k * BS, e->scratch, st);
