@@ -1,0 +1,176 @@
+"""CPU suite (no GPU): the C-ABI library loads and exports what include/ohs_hip.h declares, fails
+loudly without a device, and the host-side helpers (synthetic generators, stream sharding, table
+packing, world_size-2 gloo broadcast + sharded run) behave."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from open_headstage_amd import build
+    build.build()
+    from open_headstage_amd import _ffi
+    return _ffi.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "ohs_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(ohs_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    from open_headstage_amd import _ffi
+    assert sorted(_ffi.PROTOTYPES) == declared, "ctypes prototypes and header disagree"
+    for name in declared:
+        assert hasattr(lib, name), name
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "open_headstage_amd", "libohs_hip.so")],
+                        capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ohs_[a-z0-9_]+)", nm))
+    assert set(declared) <= exported
+
+
+def test_no_cpu_fallback_without_device(lib):
+    """On a box without a GPU every create call must fail with OHS_ERR_NO_DEVICE (never compute)."""
+    import ctypes as C
+    from open_headstage_amd import _ffi
+    n = C.c_int()
+    rc = lib.ohs_device_count(C.byref(n))
+    if rc == _ffi.OHS_OK:
+        pytest.skip("a GPU is visible here")
+    assert rc == _ffi.OHS_ERR_NO_DEVICE
+    import open_headstage_amd as ohs
+    for ctor in (lambda: ohs.ConvolutionEngine.new(), lambda: ohs.StereoParametricEQ.new(10, 48000.0),
+                 lambda: ohs.BatchProcessor(4)):
+        with pytest.raises(ohs.OhsError) as ei:
+            ctor()
+        assert ei.value.status == _ffi.OHS_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.ohs_last_error()
+
+
+def test_host_coefficients_match_oracle_bits(lib, oracle):
+    """ohs_biquad_coeffs is host code (no device needed): both restatements agree bit for bit."""
+    from open_headstage_amd import FilterType, OhsError, biquad_coefficients
+    for t in range(8):
+        for fc, q, g in [(20.0, 0.707, 0.0), (105.0, 0.7, 4.0), (1000.0, 1.41, -3.0), (23999.0, 10.0, 16.0)]:
+            a = biquad_coefficients(FilterType(t), 48000.0, fc, q, g)
+            b = oracle.biquad_coeffs(t, 48000.0, fc, q, g)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (t, fc, q, g)
+    with pytest.raises(OhsError):
+        biquad_coefficients(FilterType.Peak, 48000.0, 24001.0, 1.0, 0.0)   # OutsideNyquist
+    with pytest.raises(OhsError):
+        biquad_coefficients(FilterType.Peak, 48000.0, 1000.0, -1.0, 0.0)    # NegativeQ
+
+
+def test_synth_generators_are_deterministic():
+    from open_headstage_amd import synth
+    assert int(synth.splitmix64(0, 1)[0]) == 0xE220A8397B1DCDAF       # published splitmix64 vector
+    assert int(synth.splitmix64(0, 3)[2]) == int(synth.splitmix64(0, 1, offset=2)[0])
+    x = synth.white_noise([0, 1], 4096)
+    assert x.dtype == np.float32 and x.shape == (2, 2, 4096)
+    assert x.min() >= -1.0 and x.max() < 1.0 and abs(float(x.mean())) < 0.02
+    assert not np.array_equal(x[0, 0], x[0, 1]) and not np.array_equal(x[0, 0], x[1, 0])
+    y = synth.white_noise([1], 100, offset=50)
+    assert np.array_equal(y[0], x[1, :, 50:150])
+    for taps in (128, 512, 16384):
+        h = synth.hrir_set(taps)
+        assert all(a.size == taps and a.dtype == np.float32 for a in h)
+        assert abs(np.abs(h[0]).sum() + np.abs(h[2]).sum() - 1) < 1e-5      # |y| <= 1 for |x| <= 1
+        assert abs(np.abs(h[1]).sum() + np.abs(h[3]).sum() - 1) < 1e-5
+    bands = synth.eq_table()
+    assert len(bands) == 10 and all(b.enabled for b in bands)
+
+
+def test_shard_range_partitions_streams():
+    from open_headstage_amd.sharding import shard_range
+    for n, w in [(2048, 8), (2048, 1), (10, 4), (3, 8), (0, 2)]:
+        got = [i for r in range(w) for i in shard_range(n, r, w)]
+        assert got == list(range(n))
+        sizes = [len(shard_range(n, r, w)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def test_table_pack_roundtrip():
+    from open_headstage_amd import sharding, synth
+    irs = synth.hrir_set(128)
+    c = np.arange(50, dtype=np.float32).reshape(10, 5)
+    en = np.array([1, 0, 1, 1, 1, 0, 1, 1, 1, 1], bool)
+    buf = sharding.pack_tables(irs, c, en)
+    assert buf.size == sharding.table_numel(128, 10)
+    irs2, c2, en2 = sharding.unpack_tables(buf)
+    assert all(np.array_equal(a, b) for a, b in zip(irs, irs2))
+    assert np.array_equal(c, c2) and np.array_equal(en, en2)
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from open_headstage_amd import sharding, synth
+from oracle import ohs_oracle as orc     # tests may use the oracle as the stand-in executor
+
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+TAPS, NB, S, FRAMES = 128, 10, 6, 2048
+if rank == 0:
+    irs = synth.hrir_set(TAPS)
+    bands = synth.eq_table()
+    coeffs = np.stack([orc.biquad_coeffs(int(b.filter_type), synth.FS, b.center_freq, b.q, b.gain_db) for b in bands])
+    en = np.array([b.enabled for b in bands])
+else:
+    irs = coeffs = en = None
+irs, coeffs, en = sharding.broadcast_tables(irs, coeffs, en, TAPS, NB, torch.device("cpu"), src=0)
+ids = sharding.shard_range(S, rank, world)
+x = synth.white_noise(ids, FRAMES)
+out = np.zeros((S, 2, FRAMES), np.float32)
+for k, sid in enumerate(ids):
+    eng = orc.ConvolutionEngine()
+    for p in range(4): eng.set_ir(p, irs[p])
+    eq = orc.StereoParametricEQ(NB, synth.FS)
+    for i in range(NB): eq.set_band_coeffs(i, coeffs[i], bool(en[i]))
+    l, r = x[k, 0].copy(), x[k, 1].copy()
+    orc.chain_process(eng, eq, l, r, eq_enable=True, gain=1.0)
+    out[sid, 0], out[sid, 1] = l, r
+t = torch.from_numpy(out)
+dist.all_reduce(t)            # test-only gather of the disjoint shards (the data path has no collective)
+if rank == 0:
+    np.save({outfile!r}, t.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_gloo_sharded_run_matches_single_process(tmp_path, oracle):
+    """N > 1 plan on CPU: rank 0 broadcasts the HRIR set + EQ table, each rank processes its
+    contiguous shard of stream ids, and the union equals the single-process result."""
+    from open_headstage_amd import synth
+    outfile = str(tmp_path / "sharded.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, outfile=outfile))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = np.load(outfile)
+    TAPS, NB, S, FRAMES = 128, 10, 6, 2048
+    irs = synth.hrir_set(TAPS)
+    bands = synth.eq_table()
+    x = synth.white_noise(range(S), FRAMES)
+    for sid in range(S):
+        eng = oracle.ConvolutionEngine()
+        for p in range(4):
+            eng.set_ir(p, irs[p])
+        eq = oracle.StereoParametricEQ(NB, synth.FS)
+        for i, b in enumerate(bands):
+            eq.set_band_coeffs(i, oracle.biquad_coeffs(int(b.filter_type), synth.FS, b.center_freq, b.q, b.gain_db), b.enabled)
+        l, r = x[sid, 0].copy(), x[sid, 1].copy()
+        oracle.chain_process(eng, eq, l, r, eq_enable=True, gain=1.0)
+        assert np.array_equal(got[sid, 0], l) and np.array_equal(got[sid, 1], r), sid
