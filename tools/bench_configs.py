@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Times the other BASELINE.json configs (not the headline bench): C2 single stream, C4 long IR.
+Prints one JSON line per config.  Usage: python tools/bench_configs.py [c2] [c4] [c3noeq]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import open_headstage_amd as ohs  # noqa: E402
+from open_headstage_amd import synth  # noqa: E402
+
+
+def run_batch(name, S, taps, frames, eq_on, steps=5, warmup=2):
+    dev = torch.device("cuda:0")
+    bp = ohs.BatchProcessor(S, num_bands=10)
+    irs = synth.hrir_set(taps)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i, b in enumerate(synth.eq_table()):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(eq_on)
+    x = synth.white_noise_torch(0, S, frames, dev)
+    y = torch.empty_like(x)
+    for _ in range(warmup):
+        bp.process(x, out=y)
+    torch.cuda.synchronize()
+    bp.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bp.process(x, out=y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eq_ms, conv_ms, n = bp.profile_read()
+    eb, cb = bp.kernel_bytes(frames // 512)
+    print(json.dumps({"config": name, "streams": S, "taps": taps, "frames": frames, "eq": eq_on,
+                      "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(S * frames / dt / 1e6, 1),
+                      "x_realtime": round(S * frames / dt / 48000.0, 0),
+                      "eq_ms": round(eq_ms / n, 3), "conv_ms": round(conv_ms / n, 3),
+                      "conv_model_GBps": round(cb / (conv_ms / n * 1e-3) / 1e9, 1)}), flush=True)
+
+
+def run_engine_c2(calls=200):
+    """C2: one stream, 1024-frame host blocks through the blocking engine API (PCIe + launches)."""
+    e = ohs.ConvolutionEngine.new()
+    irs = synth.hrir_set(512)
+    for p in range(4):
+        e.set_ir(p, irs[p])
+    x = synth.white_noise([0], 1024 * calls)[0]
+    ol = np.empty(1024, np.float32); orr = np.empty(1024, np.float32)
+    for c in range(10):
+        e.process_block(x[0, c * 1024:(c + 1) * 1024], x[1, c * 1024:(c + 1) * 1024], ol, orr)
+    t0 = time.perf_counter()
+    for c in range(calls):
+        e.process_block(x[0, c * 1024:(c + 1) * 1024], x[1, c * 1024:(c + 1) * 1024], ol, orr)
+    dt = (time.perf_counter() - t0) / calls
+    print(json.dumps({"config": "c2_engine_1024_blocking", "us_per_call": round(dt * 1e6, 1),
+                      "x_realtime": round(1024 / dt / 48000.0, 0)}), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c4", "c3noeq"]
+    if "c2" in which:
+        run_engine_c2()
+        run_batch("c2_batch_1stream", 1, 512, 480256, False)
+    if "c3noeq" in which:
+        run_batch("c3_noeq", 256, 512, 480256, False)
+    if "c4" in which:
+        run_batch("c4_p32_64streams", 64, 16384, 512 * 256, False, steps=3, warmup=1)
