@@ -68,13 +68,14 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
     float *out_l = A.out + s * A.out_stream_stride;
     float *out_r = out_l + A.out_ch_stride;
     float2 *hist = A.hist + s * (size_t)A.cap * kFft;
-    float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
+    const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
+    float2 *tails_out = A.tails_out + s * (size_t)(2 * 8 * 64);
 
     float2 tail1[8], tail2[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-        tail1[a] = tails[a * 64 + lane];
-        tail2[a] = tails[(8 + a) * 64 + lane];
+        tail1[a] = A.zero_tails_in ? make_float2(0.f, 0.f) : tails[a * 64 + lane];
+        tail2[a] = A.zero_tails_in ? make_float2(0.f, 0.f) : tails[(8 + a) * 64 + lane];
     }
     int maxP = A.P[0];
 #pragma unroll
@@ -153,14 +154,16 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
             tail1[a] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
             tail2[a] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
             const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-            out_l[idx] = (lsl + rsl) * A.gain;
-            out_r[idx] = (lsr + rsr) * A.gain;
+            if (t >= A.skip_store) {
+                out_l[idx] = (lsl + rsl) * A.gain;
+                out_r[idx] = (lsr + rsr) * A.gain;
+            }
         }
     }
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-        tails[a * 64 + lane] = tail1[a];
-        tails[(8 + a) * 64 + lane] = tail2[a];
+        tails_out[a * 64 + lane] = tail1[a];
+        tails_out[(8 + a) * 64 + lane] = tail2[a];
     }
 }
 
@@ -346,6 +349,189 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
     if (e != hipSuccess || a.chunks <= 1) return e;
     const long long n = (long long)a.n_streams * (a.chunks - 1) * 512;
     hipLaunchKernelGGL(k_conv_p1_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Time-parallel long-IR path (BASELINE config 4: 4 x 16384 taps, P = 32).
+//
+// convolve_path_partitioned (convolution.rs:236-289) is a P-tap FIR along the BLOCK axis, per
+// frequency bin:  W_t[k] = sum_i ( Z_{t-i}[k] C_i[k] + conj(Z_{t-i}[N-k]) D_i[k] ).  Nothing in
+// it is sequential, so the three stages run over all blocks of a segment at once, and the MAC
+// keeps a (time x partition) tile in registers so that each history spectrum is fetched
+// ~(TB + 7)/TB^2 times per use instead of once per use: the 2(P-1) x 4104 B per block that a
+// block-at-a-time engine streams from HBM become L2 hits on an 8 KiB-per-block ring.
+// ---------------------------------------------------------------------------------
+__global__ void k_build_cd_multi(const float2 *__restrict__ h0, const float2 *__restrict__ h1,
+                                 const float2 *__restrict__ h2, const float2 *__restrict__ h3,
+                                 int p0, int p1, int p2, int p3, int Ppad, float2 *__restrict__ cd)
+{
+    const int i = blockIdx.y;                                  // partition
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;       // layout position
+    if (i >= Ppad || b >= kFft) return;
+    const float2 z = make_float2(0.f, 0.f);
+    const float2 a0 = i < p0 ? h0[(size_t)i * kFft + b] : z;
+    const float2 a1 = i < p1 ? h1[(size_t)i * kFft + b] : z;
+    const float2 a2 = i < p2 ? h2[(size_t)i * kFft + b] : z;
+    const float2 a3 = i < p3 ? h3[(size_t)i * kFft + b] : z;
+    const float2 A_ = make_float2(a0.x - a1.y, a0.y + a1.x);
+    const float2 B_ = make_float2(a2.x - a3.y, a2.y + a3.x);
+    cd[((size_t)i * 2 + 0) * kFft + b] = make_float2(0.5f * (A_.x + B_.y), 0.5f * (A_.y - B_.x));
+    cd[((size_t)i * 2 + 1) * kFft + b] = make_float2(0.5f * (A_.x - B_.y), 0.5f * (A_.y + B_.x));
+}
+hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
+                                 int p0, int p1, int p2, int p3, int Ppad, float2 *cd, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_build_cd_multi, dim3(kFft / 256, Ppad), dim3(256), 0, st, h0, h1, h2, h3, p0, p1,
+                       p2, p3, Ppad, cd);
+    return hipGetLastError();
+}
+
+// F: one wave per (stream, block)
+__global__ __launch_bounds__(256) void k_conv_tp_forward(const ConvTpArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    if (gw >= (long long)A.n_streams * A.seg_blocks) return;
+    const size_t s = (size_t)(gw / A.seg_blocks);
+    const int t = (int)(gw % A.seg_blocks);
+    const float *in_l = A.in + s * A.in_stream_stride;
+    const float *in_r = in_l + A.in_ch_stride;
+    float2 v[16];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+        v[a] = make_float2(in_l[idx], in_r[idx]);
+        v[a + 8] = make_float2(0.f, 0.f);
+    }
+    wave_fft_fwd(v, lds, tab, lane);
+    float2 *hs = A.hist + (s * (size_t)A.cap + (size_t)((A.cnt + (unsigned long long)t) & (unsigned long long)(A.cap - 1))) * kFft;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hs[r * 64 + lane] = v[r];
+}
+hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
+    const long long waves = (long long)a.n_streams * a.seg_blocks;
+    hipLaunchKernelGGL(k_conv_tp_forward, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+
+// position in the bin layout holding bin N-k of the bin held at position b
+__device__ __forceinline__ int mirror_position(int b)
+{
+    const int r = b >> 6, L = b & 63;
+    const int j = r & 3, q = r >> 2;
+    if (j) return (4 * (3 - q) + (4 - j)) * 64 + (63 - L);
+    if (L) return (4 * (3 - q)) * 64 + (64 - L);
+    return (4 * ((4 - q) & 3)) * 64;
+}
+
+// M: thread = one layout position; block = (quarter of the spectrum, 8-block time tile, stream)
+constexpr int kTB = 8;
+__global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * kTB;
+    const size_t s = blockIdx.z;
+    const int mb = mirror_position(b);
+    const float2 *hist = A.hist + s * (size_t)A.cap * kFft;
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+    const unsigned long long base = A.cnt + (unsigned long long)t0;
+
+    float2 acc[kTB];
+#pragma unroll
+    for (int t = 0; t < kTB; ++t) acc[t] = make_float2(0.f, 0.f);
+
+    for (int i0 = 0; i0 < A.Ppad; i0 += 8) {
+        // window of blocks u = t - i, t in [0,8), i in [i0, i0+8): w = (t - i) + i0 + 7 in [0, 15)
+        float2 zw[15], zm[15];
+#pragma unroll
+        for (int w = 0; w < 15; ++w) {
+            const unsigned long long u = base + (unsigned long long)(long long)(w - 7 - i0);
+            const float2 *hs = hist + (size_t)(u & mask) * kFft;
+            zw[w] = hs[b];
+            zm[w] = hs[mb];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const float2 c = A.CD[((size_t)(i0 + ii) * 2 + 0) * kFft + b];
+            const float2 d = A.CD[((size_t)(i0 + ii) * 2 + 1) * kFft + b];
+#pragma unroll
+            for (int t = 0; t < kTB; ++t) {
+                const float2 z = zw[t - ii + 7], m = zm[t - ii + 7];
+                acc[t].x += z.x * c.x - z.y * c.y + m.x * d.x + m.y * d.y;
+                acc[t].y += z.x * c.y + z.y * c.x + m.x * d.y - m.y * d.x;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kTB; ++t)
+        if (t0 + t < A.n_mac) A.W[(s * (size_t)A.n_mac + (size_t)(t0 + t)) * kFft + b] = acc[t];
+}
+hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
+{
+    if (a.n_mac <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_conv_tp_mac, dim3(kFft / 256, (a.n_mac + kTB - 1) / kTB, a.n_streams), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// I: one wave per (stream, block < n_mac)
+__global__ __launch_bounds__(256) void k_conv_tp_inverse(const ConvTpArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    if (gw >= (long long)A.n_streams * A.n_mac) return;
+    const size_t s = (size_t)(gw / A.n_mac);
+    const int t = (int)(gw % A.n_mac);
+    const float2 *Wt = A.W + (s * (size_t)A.n_mac + (size_t)t) * kFft;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = Wt[r * 64 + lane];
+    if (t > 0) {
+        // fold the previous block's overlap in: IFFT((-1)^k W_{t-1})[n] = w_{t-1}[n + 512];
+        // bin k = 4 lane + (r & 3) + 256 (r >> 2) is odd exactly when r is odd
+        const float2 *Wp = Wt - kFft;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 p = Wp[r * 64 + lane];
+            if (r & 1) { v[r].x -= p.x; v[r].y -= p.y; } else { v[r].x += p.x; v[r].y += p.y; }
+        }
+    }
+    wave_fft_inv(v, lds, tab, lane);
+    const float scale = 1.0f / (float)kFft;
+    float *out_l = A.out + s * A.out_stream_stride;
+    float *out_r = out_l + A.out_ch_stride;
+    const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        float ol = v[a].x * scale, orr = v[a].y * scale;
+        if (t == 0) {       // first block of the segment: overlap left by the previous call
+            const float2 t1 = tails[a * 64 + lane], t2 = tails[(8 + a) * 64 + lane];
+            ol += t1.x + t2.x;
+            orr += t1.y + t2.y;
+        }
+        const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+        out_l[idx] = ol * A.gain;
+        out_r[idx] = orr * A.gain;
+    }
+}
+hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st)
+{
+    if (a.n_mac <= 0) return hipSuccess;
+    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
+    const long long waves = (long long)a.n_streams * a.n_mac;
+    hipLaunchKernelGGL(k_conv_tp_inverse, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
     return hipGetLastError();
 }
 

@@ -20,7 +20,10 @@ struct ConvGeneralArgs {
     float2 *hist;               // [stream][cap][16][64] packed spectra ring Z = FFT(x_l + j x_r)
     int cap;                    // ring capacity, power of two >= max P
     unsigned long long cnt;     // absolute block counter at launch start
-    float2 *tails;              // [stream][2][8][64]: (lsl + j lsr) tail, (rsl + j rsr) tail
+    const float2 *tails;        // [stream][2][8][64] state in: (lsl + j lsr) tail, (rsl + j rsr) tail
+    float2 *tails_out;          // state out (may equal `tails`)
+    int skip_store;             // leading blocks whose output is NOT stored (time-parallel path hand-over)
+    int zero_tails_in;          // start from zero overlap instead of `tails`
     const float2 *tw;           // master twiddle table, 1024 entries
     float gain;
 };
@@ -49,6 +52,35 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
 // CD[0][..] = (A - jB)/2, CD[1][..] = (A + jB)/2 from four single-partition spectra
 hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
                            float2 *cd, hipStream_t st);
+
+// ---- time-parallel long-IR path (any P, no per-path gating needed) ----------------------------
+// F: Z_t = FFT(x_l + j x_r) for every (stream, block) of the segment -> history ring
+// M: W_t = sum_i Z_{t-i} C_i + conj(Z_{t-i}[N-k]) D_i, register-tiled over (time x partition)
+// I: out_t = IFFT(W_t + (-1)^k W_{t-1})[0..512) -- the overlap-add folded in the spectral domain
+struct ConvTpArgs {
+    const float *in;
+    float *out;
+    long long in_stream_stride, in_ch_stride;
+    long long out_stream_stride, out_ch_stride;
+    int n_streams;
+    int seg_blocks;             // blocks whose spectra F writes
+    int n_mac;                  // blocks M / I produce (seg_blocks - 1: the last block goes to the general kernel)
+    int Ppad;                   // partitions, padded to a multiple of 8 (CD zero beyond the real count)
+    const float2 *CD;           // [Ppad][2][1024] combined spectra C_i, D_i (bin layout)
+    float2 *hist;               // [stream][cap][1024] ring
+    int cap;
+    unsigned long long cnt;     // absolute index of the segment's first block
+    float2 *W;                  // [stream][n_mac][1024] scratch
+    const float2 *tails;        // state in (sum of the two packed tails feeds block 0)
+    const float2 *tw;
+    float gain;
+};
+hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st);
+hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st);
+hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st);
+// CD[i][0] = (A_i - jB_i)/2, CD[i][1] = (A_i + jB_i)/2 for i < Ppad; H_p,i := 0 for i >= P_p
+hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
+                                 int p0, int p1, int p2, int p3, int Ppad, float2 *cd, hipStream_t st);
 
 // IR chunk -> spectrum: dst[part][16][64], one wave per partition.
 hipError_t launch_ir_spectrum(const float *d_ir, int len, int n_parts, float2 *dst,

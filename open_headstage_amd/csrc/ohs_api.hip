@@ -105,6 +105,12 @@ struct ConvState {
     bool cd_valid = false;
     float2 *d_chunk_tails = nullptr;
     size_t chunk_tails_cap = 0;     // in chunks per stream
+    // time-parallel long-IR path
+    float2 *d_cdm = nullptr;        // [Ppad][2][1024] combined spectra per partition
+    int cdm_ppad = 0;
+    bool cdm_valid = false;
+    float2 *d_W = nullptr;          // [S][w_blocks][1024] MAC output scratch
+    size_t w_blocks = 0;
 };
 
 void conv_free(ConvState &c)
@@ -115,6 +121,9 @@ void conv_free(ConvState &c)
     if (c.d_tails_alt) hipFree(c.d_tails_alt);
     if (c.d_cd) hipFree(c.d_cd);
     if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
+    if (c.d_cdm) hipFree(c.d_cdm);
+    if (c.d_W) hipFree(c.d_W);
+    c.d_cdm = nullptr; c.d_W = nullptr;
     c.d_hist = nullptr; c.d_tails = nullptr; c.d_tails_alt = nullptr; c.d_cd = nullptr; c.d_chunk_tails = nullptr;
 }
 
@@ -192,7 +201,13 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     c.d_H[path] = nH;
     c.P[path] = P;
     c.cd_valid = false;
+    c.cdm_valid = false;
     c.since[path] = 0;      // :135-137 that path's history is "all zero" again
+    if (c.since[0] == 0 && c.since[1] == 0 && c.since[2] == 0 && c.since[3] == 0) {
+        // every path has forgotten its past: the ring holds nothing any path may still see.  Zeroing
+        // it lets the gate-free time-parallel kernels run right away (all `since` equal).
+        HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), st));
+    }
     // :138 that path's overlap := 0.  Tails are (lsl + j lsr) and (rsl + j rsr).
     const int which = path >> 1, comp = path & 1;
     HIP_TRY(launch_zero_tail_component(c.d_tails, (long long)c.S, which, comp, st));
@@ -236,16 +251,91 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
         std::swap(c.d_tails, c.d_tails_alt);
     } else {
-        ConvGeneralArgs a;
-        a.in = in; a.out = out;
-        a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
-        a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
-        a.n_blocks = n_blocks;
-        for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
-        a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
-        a.tails = c.d_tails; a.tw = ctx->d_tw; a.gain = gain;
-        hipError_t e = launch_conv_general(a, (int)c.S, st);
-        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+        int Pmax = 1;
+        for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
+        const bool since_equal = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3];
+        bool since_old = true;
+        for (int p = 0; p < 4; ++p) since_old = since_old && c.since[p] >= Pmax - 1;
+        // gate-free condition of the time-parallel kernels: no path may have blocks in the ring that
+        // it must not see (either every path is older than the longest IR, or all were reset together
+        // -- conv_set_ir zeroed the ring then)
+        const bool tp = allow_fast && n_blocks >= 4 && (since_old || since_equal);
+        auto general = [&](const float *gin, float *gout, int nb, unsigned long long cnt, int since_add,
+                           int skip_store, int zero_in, float2 *tails_out) -> int {
+            ConvGeneralArgs a;
+            a.in = gin; a.out = gout;
+            a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+            a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+            a.n_blocks = nb;
+            for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p] + since_add; }
+            a.hist = c.d_hist; a.cap = c.cap; a.cnt = cnt;
+            a.tails = c.d_tails; a.tails_out = tails_out;
+            a.skip_store = skip_store; a.zero_tails_in = zero_in;
+            a.tw = ctx->d_tw; a.gain = gain;
+            hipError_t e = launch_conv_general(a, (int)c.S, st);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+            return OHS_OK;
+        };
+        if (!tp) {
+            int rc = general(in, out, n_blocks, c.cnt, 0, 0, 0, c.d_tails);
+            if (rc) return rc;
+        } else {
+            // segment size: keep the MAC scratch around 128 MiB
+            long long SEG = 16384 / (long long)c.S;
+            SEG = std::max<long long>(8, std::min<long long>(SEG, 1024));
+            const long long seg_max = std::min<long long>(SEG, n_blocks);
+            int rc = conv_grow_ring(c, (int)(seg_max + Pmax - 1), st);
+            if (rc) return rc;
+            const int Ppad = (Pmax + 7) / 8 * 8;
+            if (!c.cdm_valid || c.cdm_ppad != Ppad) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (c.d_cdm) hipFree(c.d_cdm);
+                c.d_cdm = nullptr;
+                HIP_TRY(hipMalloc(&c.d_cdm, (size_t)Ppad * 2 * NF * sizeof(float2)));
+                hipError_t e = launch_build_cd_multi(c.d_H[0], c.d_H[1], c.d_H[2], c.d_H[3], c.P[0], c.P[1],
+                                                     c.P[2], c.P[3], Ppad, c.d_cdm, st);
+                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("build_cd_multi: ") + hipGetErrorString(e));
+                c.cdm_ppad = Ppad; c.cdm_valid = true;
+            }
+            if ((size_t)seg_max > c.w_blocks) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (c.d_W) hipFree(c.d_W);
+                c.d_W = nullptr; c.w_blocks = 0;
+                HIP_TRY(hipMalloc(&c.d_W, c.S * (size_t)seg_max * NF * sizeof(float2)));
+                c.w_blocks = (size_t)seg_max;
+            }
+            long long done = 0;
+            while (done < n_blocks) {
+                const int seg = (int)std::min<long long>(SEG, n_blocks - done);
+                const float *sin_ = in + done * BS;
+                float *sout = out + done * BS;
+                const unsigned long long cnt = c.cnt + (unsigned long long)done;
+                if (seg == 1) {
+                    rc = general(sin_, sout, 1, cnt, (int)done, 0, 0, c.d_tails_alt);
+                    if (rc) return rc;
+                } else {
+                    ConvTpArgs a;
+                    a.in = sin_; a.out = sout;
+                    a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+                    a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+                    a.n_streams = (int)c.S; a.seg_blocks = seg; a.n_mac = seg - 1; a.Ppad = Ppad;
+                    a.CD = c.d_cdm; a.hist = c.d_hist; a.cap = c.cap; a.cnt = cnt;
+                    a.W = c.d_W; a.tails = c.d_tails; a.tw = ctx->d_tw; a.gain = gain;
+                    hipError_t e = launch_conv_tp_forward(a, st);
+                    if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
+                    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp: ") + hipGetErrorString(e));
+                    // last block through the general kernel (keeps the four separate overlaps); it
+                    // re-runs block seg-2 without storing it to obtain that block's overlap
+                    rc = general(sin_ + (long long)(seg - 2) * BS, sout + (long long)(seg - 2) * BS, 2,
+                                 cnt + (unsigned long long)(seg - 2), (int)done + seg - 2, 1, 1, c.d_tails_alt);
+                    if (rc) return rc;
+                    e = launch_conv_tp_inverse(a, st);     // reads the OLD state (c.d_tails) for block 0
+                    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp inverse: ") + hipGetErrorString(e));
+                }
+                std::swap(c.d_tails, c.d_tails_alt);
+                done += seg;
+            }
+        }
     }
     c.cnt += (unsigned long long)n_blocks;
     for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;

@@ -335,6 +335,49 @@ def test_batch_p1_no_eq_inplace(ohs, synth, oracle):
 def test_batch_long_ir_p32(ohs, synth, oracle):
     w = _batch_vs_oracle(ohs, synth, oracle, S=3, taps=16384, n_blocks=20, eq_on=False, calls=2)
     print("batch P=32 worst rel RMS", w)
+    # in place (EQ on => the convolution runs in place on the EQ output), odd segment sizes
+    w = _batch_vs_oracle(ohs, synth, oracle, S=2, taps=6000, n_blocks=37, eq_on=True, calls=2, gain=0.9)
+    print("batch P=12 +EQ worst rel RMS", w)
+
+
+def test_batch_mixed_partitions_and_midstream_set_ir(ohs, synth, oracle):
+    """Different partition counts per path, a per-path set_ir between calls (transitional gating ->
+    general kernel, then back to the time-parallel kernels), segments longer than one tile."""
+    import torch
+    S = 2
+    irs = [synth.hrir_set(3000)[0], synth.hrir_set(700)[1], synth.hrir_set(5000)[2], synth.hrir_set(512)[3]]
+    bp = ohs.BatchProcessor(S, num_bands=10)
+    engs = [oracle.ConvolutionEngine() for _ in range(S)]
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+        for e in engs:
+            e.set_ir(p, irs[p])
+    x = synth.white_noise(range(S), 512 * 75)
+    plan = [(0, 23), (23, 30), (30, 37), (37, 75)]     # block ranges per call
+    outs = []
+    for k, (b0, b1) in enumerate(plan):
+        if k == 1:      # reset one path mid-stream with a longer IR
+            new = synth.hrir_set(4100)[1]
+            bp.set_ir(ohs.ConvolutionPath.Lsr, new)
+            for e in engs:
+                e.set_ir(oracle.LSR, new)
+        xt = torch.from_numpy(np.ascontiguousarray(x[:, :, b0 * 512:b1 * 512])).cuda()
+        outs.append(bp.process(xt).cpu().numpy())
+    g = np.concatenate(outs, axis=2)
+    for s_ in range(S):
+        o = np.stack(engs[s_].process_block(x[s_, 0], x[s_, 1])) if False else None
+    # oracle: same call pattern (set_ir at the same point)
+    engs = [oracle.ConvolutionEngine() for _ in range(S)]
+    for p in range(4):
+        for e in engs:
+            e.set_ir(p, irs[p])
+    for s_ in range(S):
+        ref = []
+        for k, (b0, b1) in enumerate(plan):
+            if k == 1:
+                engs[s_].set_ir(oracle.LSR, synth.hrir_set(4100)[1])
+            ref.append(np.stack(engs[s_].process_block(x[s_, 0, b0 * 512:b1 * 512], x[s_, 1, b0 * 512:b1 * 512])))
+        assert_parity(g[s_], np.concatenate(ref, axis=1), f"mixed P stream {s_}")
 
 
 def test_batch_reset_and_linearity(ohs, synth, oracle):
