@@ -447,6 +447,12 @@ __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
     float2 acc[kTB];
 #pragma unroll
     for (int t = 0; t < kTB; ++t) acc[t] = make_float2(0.f, 0.f);
+    // the tile holding the segment's last block also accumulates its L-speaker part
+    // W1 = sum_i X_l A_i with X_l = (Z + conj(Zm))/2 and A_i = H_lsl + j H_lsr = C_i + D_i, so that the
+    // four per-path overlaps of the state at rest can be rebuilt (W2 = W - W1)
+    const int tl = A.n_mac - 1 - t0;                // index of the last block inside this tile
+    const bool has_last = tl >= 0 && tl < kTB;
+    float2 acc1 = make_float2(0.f, 0.f);
 
     for (int i0 = 0; i0 < A.Ppad; i0 += 8) {
         // window of blocks u = t - i, t in [0,8), i in [i0, i0+8): w = (t - i) + i0 + 7 in [0, 15)
@@ -467,12 +473,19 @@ __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
                 const float2 z = zw[t - ii + 7], m = zm[t - ii + 7];
                 acc[t].x += z.x * c.x - z.y * c.y + m.x * d.x + m.y * d.y;
                 acc[t].y += z.x * c.y + z.y * c.x + m.x * d.y - m.y * d.x;
+                if (has_last && t == tl) {
+                    const float2 xl = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+                    const float2 a_ = make_float2(c.x + d.x, c.y + d.y);
+                    acc1.x += xl.x * a_.x - xl.y * a_.y;
+                    acc1.y += xl.x * a_.y + xl.y * a_.x;
+                }
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < kTB; ++t)
         if (t0 + t < A.n_mac) A.W[(s * (size_t)A.n_mac + (size_t)(t0 + t)) * kFft + b] = acc[t];
+    if (has_last) A.W1[s * (size_t)kFft + b] = acc1;
 }
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
 {
@@ -526,6 +539,42 @@ __global__ __launch_bounds__(256) void k_conv_tp_inverse(const ConvTpArgs A)
         out_r[idx] = orr * A.gain;
     }
 }
+// new state: overlaps of the segment's last block, (lsl + j lsr) from W1 and (rsl + j rsr) from W - W1
+__global__ __launch_bounds__(256) void k_conv_tp_tails(const ConvTpArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    if (gw >= (long long)A.n_streams * 2) return;
+    const size_t s = (size_t)(gw >> 1);
+    const int which = (int)(gw & 1);
+    const float2 *Wl = A.W + (s * (size_t)A.n_mac + (size_t)(A.n_mac - 1)) * kFft;
+    const float2 *W1 = A.W1 + s * (size_t)kFft;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float2 w1 = W1[r * 64 + lane];
+        if (which == 0) v[r] = w1;
+        else { const float2 w = Wl[r * 64 + lane]; v[r] = make_float2(w.x - w1.x, w.y - w1.y); }
+    }
+    wave_fft_inv(v, lds, tab, lane);
+    const float scale = 1.0f / (float)kFft;
+    float2 *to = A.tails_out + s * (size_t)(2 * 8 * 64) + (size_t)which * (8 * 64);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) to[a * 64 + lane] = make_float2(v[a + 8].x * scale, v[a + 8].y * scale);
+}
+hipError_t launch_conv_tp_tails(const ConvTpArgs &a, hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
+    const long long waves = (long long)a.n_streams * 2;
+    hipLaunchKernelGGL(k_conv_tp_tails, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st)
 {
     if (a.n_mac <= 0) return hipSuccess;

@@ -64,20 +64,23 @@ struct ConvTpArgs {
     long long out_stream_stride, out_ch_stride;
     int n_streams;
     int seg_blocks;             // blocks whose spectra F writes
-    int n_mac;                  // blocks M / I produce (seg_blocks - 1: the last block goes to the general kernel)
+    int n_mac;                  // blocks M / I produce (= seg_blocks)
     int Ppad;                   // partitions, padded to a multiple of 8 (CD zero beyond the real count)
     const float2 *CD;           // [Ppad][2][1024] combined spectra C_i, D_i (bin layout)
     float2 *hist;               // [stream][cap][1024] ring
     int cap;
     unsigned long long cnt;     // absolute index of the segment's first block
     float2 *W;                  // [stream][n_mac][1024] scratch
+    float2 *W1;                 // [stream][1024]: L-speaker part (lsl + j lsr) of the LAST block's spectrum
     const float2 *tails;        // state in (sum of the two packed tails feeds block 0)
+    float2 *tails_out;          // state out: the last block's four overlaps, general-kernel format
     const float2 *tw;
     float gain;
 };
 hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st);
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st);
 hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st);
+hipError_t launch_conv_tp_tails(const ConvTpArgs &a, hipStream_t st);
 // CD[i][0] = (A_i - jB_i)/2, CD[i][1] = (A_i + jB_i)/2 for i < Ppad; H_p,i := 0 for i >= P_p
 hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
                                  int p0, int p1, int p2, int p3, int Ppad, float2 *cd, hipStream_t st);

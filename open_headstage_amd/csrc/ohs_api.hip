@@ -82,6 +82,9 @@ int get_ctx(int device, DeviceCtx **out)
     return OHS_OK;
 }
 
+// the MAC reads up to Ppad - 1 blocks back (zero C/D beyond the real partition count)
+int Ppad_for_ring(int Pmax) { return (Pmax + 7) / 8 * 8; }
+
 int next_pow2(int v)
 {
     int p = 1;
@@ -111,6 +114,7 @@ struct ConvState {
     bool cdm_valid = false;
     float2 *d_W = nullptr;          // [S][w_blocks][1024] MAC output scratch
     size_t w_blocks = 0;
+    float2 *d_W1 = nullptr;         // [S][1024]
 };
 
 void conv_free(ConvState &c)
@@ -123,7 +127,8 @@ void conv_free(ConvState &c)
     if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
     if (c.d_cdm) hipFree(c.d_cdm);
     if (c.d_W) hipFree(c.d_W);
-    c.d_cdm = nullptr; c.d_W = nullptr;
+    if (c.d_W1) hipFree(c.d_W1);
+    c.d_cdm = nullptr; c.d_W = nullptr; c.d_W1 = nullptr;
     c.d_hist = nullptr; c.d_tails = nullptr; c.d_tails_alt = nullptr; c.d_cd = nullptr; c.d_chunk_tails = nullptr;
 }
 
@@ -284,7 +289,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             long long SEG = 16384 / (long long)c.S;
             SEG = std::max<long long>(8, std::min<long long>(SEG, 1024));
             const long long seg_max = std::min<long long>(SEG, n_blocks);
-            int rc = conv_grow_ring(c, (int)(seg_max + Pmax - 1), st);
+            int rc = conv_grow_ring(c, (int)(seg_max + Ppad_for_ring(Pmax) - 1), st);
             if (rc) return rc;
             const int Ppad = (Pmax + 7) / 8 * 8;
             if (!c.cdm_valid || c.cdm_ppad != Ppad) {
@@ -304,34 +309,23 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 HIP_TRY(hipMalloc(&c.d_W, c.S * (size_t)seg_max * NF * sizeof(float2)));
                 c.w_blocks = (size_t)seg_max;
             }
+            if (!c.d_W1) HIP_TRY(hipMalloc(&c.d_W1, c.S * (size_t)NF * sizeof(float2)));
             long long done = 0;
             while (done < n_blocks) {
                 const int seg = (int)std::min<long long>(SEG, n_blocks - done);
-                const float *sin_ = in + done * BS;
-                float *sout = out + done * BS;
-                const unsigned long long cnt = c.cnt + (unsigned long long)done;
-                if (seg == 1) {
-                    rc = general(sin_, sout, 1, cnt, (int)done, 0, 0, c.d_tails_alt);
-                    if (rc) return rc;
-                } else {
-                    ConvTpArgs a;
-                    a.in = sin_; a.out = sout;
-                    a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
-                    a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
-                    a.n_streams = (int)c.S; a.seg_blocks = seg; a.n_mac = seg - 1; a.Ppad = Ppad;
-                    a.CD = c.d_cdm; a.hist = c.d_hist; a.cap = c.cap; a.cnt = cnt;
-                    a.W = c.d_W; a.tails = c.d_tails; a.tw = ctx->d_tw; a.gain = gain;
-                    hipError_t e = launch_conv_tp_forward(a, st);
-                    if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
-                    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp: ") + hipGetErrorString(e));
-                    // last block through the general kernel (keeps the four separate overlaps); it
-                    // re-runs block seg-2 without storing it to obtain that block's overlap
-                    rc = general(sin_ + (long long)(seg - 2) * BS, sout + (long long)(seg - 2) * BS, 2,
-                                 cnt + (unsigned long long)(seg - 2), (int)done + seg - 2, 1, 1, c.d_tails_alt);
-                    if (rc) return rc;
-                    e = launch_conv_tp_inverse(a, st);     // reads the OLD state (c.d_tails) for block 0
-                    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp inverse: ") + hipGetErrorString(e));
-                }
+                ConvTpArgs a;
+                a.in = in + done * BS; a.out = out + done * BS;
+                a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+                a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+                a.n_streams = (int)c.S; a.seg_blocks = seg; a.n_mac = seg; a.Ppad = Ppad;
+                a.CD = c.d_cdm; a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt + (unsigned long long)done;
+                a.W = c.d_W; a.W1 = c.d_W1; a.tails = c.d_tails; a.tails_out = c.d_tails_alt;
+                a.tw = ctx->d_tw; a.gain = gain;
+                hipError_t e = launch_conv_tp_forward(a, st);
+                if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
+                if (e == hipSuccess) e = launch_conv_tp_inverse(a, st);   // block 0 reads the OLD state
+                if (e == hipSuccess) e = launch_conv_tp_tails(a, st);     // new state -> the other slab
+                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp: ") + hipGetErrorString(e));
                 std::swap(c.d_tails, c.d_tails_alt);
                 done += seg;
             }
