@@ -150,10 +150,12 @@ int  ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_b
 int  ohs_batch_sync(ohs_batch *b, void *hip_stream);
 /* Per-kernel timing for the roofline report: when enabled, every ohs_batch_process call brackets
  * its kernels with hipEvents on the caller's stream.  ohs_batch_profile_read waits for them,
- * returns the accumulated milliseconds per kernel and the number of calls since the last read,
- * and clears the accumulators. */
+ * returns the accumulated milliseconds per kernel, the number of ohs_batch_process calls and the
+ * number of timed EQ / convolution launches since the last read, and clears the accumulators.
+ * (With the EQ || convolution overlap a call issues 4 EQ launches and 4 convolution launches.) */
 int  ohs_batch_set_profiling(ohs_batch *b, int enable);
-int  ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls);
+int  ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls,
+                            uint64_t *eq_launches, uint64_t *conv_launches);
 /* algorithmic HBM bytes one ohs_batch_process call of n_blocks moves (DESIGN.md byte model) */
 int  ohs_batch_algorithmic_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *bytes);
 /* the same, split per kernel: eq_bytes for the EQ kernel, conv_bytes for the convolution kernel */

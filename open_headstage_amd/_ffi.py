@@ -60,6 +60,7 @@ PROTOTYPES = {
     "ohs_batch_sync": (C.c_int, [vp, vp]),
     "ohs_batch_set_profiling": (C.c_int, [vp, C.c_int]),
     "ohs_batch_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]),
     "ohs_batch_algorithmic_bytes": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_uint64)]),
     "ohs_batch_kernel_bytes": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

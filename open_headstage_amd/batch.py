@@ -85,10 +85,11 @@ class BatchProcessor:
         check(lib().ohs_batch_set_profiling(self._h, int(bool(enable))))
 
     def profile_read(self):
-        """(eq_ms, conv_ms, n_calls) accumulated since the last read; waits for the events."""
-        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
-        check(lib().ohs_batch_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
-        return a.value, b.value, int(n.value)
+        """(eq_ms, conv_ms, n_calls, eq_launches, conv_launches) since the last read; waits for the events."""
+        a, b, n, ne, nc = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().ohs_batch_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n), C.byref(ne),
+                                           C.byref(nc)))
+        return a.value, b.value, int(n.value), int(ne.value), int(nc.value)
 
     def kernel_bytes(self, n_blocks: int):
         a, b = C.c_uint64(), C.c_uint64()

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -535,11 +536,15 @@ struct ohs_batch {
     EqState eq;
     int eq_enable = 0;
     float gain = 1.0f;
-    // optional per-kernel timing
+    hipStream_t st2 = nullptr;  // convolution of time chunk i runs here while the EQ of chunk i+1 runs on the caller's stream
+    bool overlap = true;
+    // optional per-kernel timing: (begin, end, kind) event pairs; kind 0 = EQ, 1 = convolution
     bool profiling = false;
-    std::vector<hipEvent_t> ev;      // triples: before EQ, between, after conv
-    std::vector<char> ev_has_eq;
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    uint64_t prof_calls = 0;
     std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> ev_inflight;   // ordering events of the current / previous calls
 };
 
 namespace {
@@ -921,6 +926,15 @@ int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch *
         delete b;
         return fail(OHS_ERR_HIP, "hipStreamCreate failed");
     }
+    if (hipStreamCreateWithFlags(&b->st2, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamDestroy(b->st);
+        delete b;
+        return fail(OHS_ERR_HIP, "hipStreamCreate failed");
+    }
+    {
+        const char *e = getenv("OHS_NO_OVERLAP");
+        b->overlap = !(e && e[0] == '1');
+    }
     rc = conv_init(b->conv, n_streams, b->st);
     if (rc == OHS_OK) rc = eq_init(b->eq, num_bands, 2 * n_streams, 48000.0f, b->st);
     if (rc == OHS_OK && hipStreamSynchronize(b->st) != hipSuccess) rc = fail(OHS_ERR_HIP, "sync failed");
@@ -936,8 +950,10 @@ void ohs_batch_destroy(ohs_batch *b)
     hipDeviceSynchronize();
     conv_free(b->conv);
     if (b->eq.d_state) hipFree(b->eq.d_state);
-    for (hipEvent_t e : b->ev) hipEventDestroy(e);
+    for (auto &sp : b->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t e : b->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_inflight) hipEventDestroy(e);
+    if (b->st2) hipStreamDestroy(b->st2);
     if (b->st) hipStreamDestroy(b->st);
     delete b;
 }
@@ -1013,31 +1029,81 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
         return fail(OHS_ERR_INVALID_ARG, "strides smaller than the processed region");
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    hipEvent_t e3[3] = {nullptr, nullptr, nullptr};
-    if (b->profiling) {
-        for (int i = 0; i < 3; ++i) {
-            if (!b->ev_pool.empty()) { e3[i] = b->ev_pool.back(); b->ev_pool.pop_back(); }
-            else HIP_TRY(hipEventCreate(&e3[i]));
-        }
-        HIP_TRY(hipEventRecord(e3[0], st));
+    auto get_event = [&](hipEvent_t *e) -> int {
+        if (!b->ev_pool.empty()) { *e = b->ev_pool.back(); b->ev_pool.pop_back(); return OHS_OK; }
+        HIP_TRY(hipEventCreate(e));
+        return OHS_OK;
+    };
+    // ordering events of earlier calls that have completed go back to the pool
+    for (size_t i = 0; i < b->ev_inflight.size();) {
+        if (hipEventQuery(b->ev_inflight[i]) == hipSuccess) {
+            b->ev_pool.push_back(b->ev_inflight[i]);
+            b->ev_inflight[i] = b->ev_inflight.back();
+            b->ev_inflight.pop_back();
+        } else ++i;
     }
-    const float *src = d_in;
-    bool did = false;
-    if (b->eq_enable) {       // lib.rs:1179
-        int rc = eq_launch(b->eq, d_in, d_out, (long long)stream_stride, (long long)channel_stride,
-                           (long long)frames, st, &did);
+    auto span_begin = [&](hipStream_t s_, int kind) -> int {
+        if (!b->profiling) return OHS_OK;
+        ohs_batch::Span sp; sp.kind = kind; sp.a = nullptr; sp.b = nullptr;
+        int rc = get_event(&sp.a); if (rc) return rc;
+        rc = get_event(&sp.b); if (rc) return rc;
+        HIP_TRY(hipEventRecord(sp.a, s_));
+        b->spans.push_back(sp);
+        return OHS_OK;
+    };
+    auto span_end = [&](hipStream_t s_) -> int {
+        if (!b->profiling) return OHS_OK;
+        HIP_TRY(hipEventRecord(b->spans.back().b, s_));
+        return OHS_OK;
+    };
+    if (b->profiling) b->prof_calls++;
+
+    bool eq_active = false;
+    if (b->eq_enable)
+        for (size_t i = 0; i < b->eq.nb; ++i) eq_active = eq_active || b->eq.en[i];
+
+    const long long ss = (long long)stream_stride, cs = (long long)channel_stride;
+    int rc;
+    if (!eq_active) {     // lib.rs:1179 eq_enable false (or every band disabled: identity)
+        rc = span_begin(st, 1); if (rc) return rc;
+        rc = conv_launch(b->conv, b->ctx, d_in, ss, cs, d_out, ss, cs, (int)n_blocks, b->gain, st);
         if (rc) return rc;
-        if (did) src = d_out;
+        return span_end(st);
     }
-    if (b->profiling) HIP_TRY(hipEventRecord(e3[1], st));
-    int rc = conv_launch(b->conv, b->ctx, src, (long long)stream_stride, (long long)channel_stride, d_out,
-                         (long long)stream_stride, (long long)channel_stride, (int)n_blocks, b->gain, st);
-    if (b->profiling) {
-        HIP_TRY(hipEventRecord(e3[2], st));
-        for (int i = 0; i < 3; ++i) b->ev.push_back(e3[i]);
-        b->ev_has_eq.push_back(did ? 1 : 0);
+    // The EQ is a serial recurrence (latency-bound, ~128 waves at 256 streams) and leaves most of the
+    // chip idle, so the convolution of time chunk i runs on a second stream underneath the EQ of
+    // chunk i+1.  Chunks touch disjoint frame ranges; state (EQ s1/s2, overlaps) chains per stream.
+    const int nch = (b->overlap && n_blocks >= 64) ? 4 : 1;
+    for (int i = 0; i < nch; ++i) {
+        const size_t blk0 = (size_t)i * n_blocks / nch, blk1 = (size_t)(i + 1) * n_blocks / nch;
+        const size_t off = blk0 * BS;
+        const int nb_i = (int)(blk1 - blk0);
+        rc = span_begin(st, 0); if (rc) return rc;
+        rc = eq_launch(b->eq, d_in + off, d_out + off, ss, cs, (long long)nb_i * BS, st);
+        if (rc) return rc;
+        rc = span_end(st); if (rc) return rc;
+        hipStream_t cst = st;
+        if (nch > 1) {
+            hipEvent_t ev;
+            rc = get_event(&ev); if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev, st));
+            HIP_TRY(hipStreamWaitEvent(b->st2, ev, 0));
+            b->ev_inflight.push_back(ev);
+            cst = b->st2;
+        }
+        rc = span_begin(cst, 1); if (rc) return rc;
+        rc = conv_launch(b->conv, b->ctx, d_out + off, ss, cs, d_out + off, ss, cs, nb_i, b->gain, cst);
+        if (rc) return rc;
+        rc = span_end(cst); if (rc) return rc;
     }
-    return rc;
+    if (nch > 1) {      // join: the caller's stream continues only after the last convolution
+        hipEvent_t ev;
+        rc = get_event(&ev); if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev, b->st2));
+        HIP_TRY(hipStreamWaitEvent(st, ev, 0));
+        b->ev_inflight.push_back(ev);
+    }
+    return OHS_OK;
 }
 
 int ohs_batch_set_profiling(ohs_batch *b, int enable)
@@ -1047,23 +1113,27 @@ int ohs_batch_set_profiling(ohs_batch *b, int enable)
     return OHS_OK;
 }
 
-int ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls)
+int ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls,
+                           uint64_t *eq_launches, uint64_t *conv_launches)
 {
-    if (!b || !eq_ms || !conv_ms || !n_calls) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (!b || !eq_ms || !conv_ms || !n_calls || !eq_launches || !conv_launches)
+        return fail(OHS_ERR_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(b->device));
-    double te = 0.0, tc = 0.0;
-    const size_t n = b->ev.size() / 3;
-    for (size_t i = 0; i < n; ++i) {
+    double t[2] = {0.0, 0.0};
+    uint64_t cntk[2] = {0, 0};
+    for (auto &sp : b->spans) {
+        cntk[sp.kind]++;
         float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(b->ev[3 * i + 2]));
-        if (b->ev_has_eq[i]) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[3 * i], b->ev[3 * i + 1])); te += ms; }
-        HIP_TRY(hipEventElapsedTime(&ms, b->ev[3 * i + 1], b->ev[3 * i + 2]));
-        tc += ms;
+        HIP_TRY(hipEventSynchronize(sp.b));
+        HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+        t[sp.kind] += ms;
+        b->ev_pool.push_back(sp.a);
+        b->ev_pool.push_back(sp.b);
     }
-    for (hipEvent_t e : b->ev) b->ev_pool.push_back(e);
-    b->ev.clear();
-    b->ev_has_eq.clear();
-    *eq_ms = te; *conv_ms = tc; *n_calls = n;
+    b->spans.clear();
+    *eq_ms = t[0]; *conv_ms = t[1]; *n_calls = b->prof_calls;
+    *eq_launches = cntk[0]; *conv_launches = cntk[1];
+    b->prof_calls = 0;
     return OHS_OK;
 }
 

@@ -36,7 +36,7 @@ def run_batch(name, S, taps, frames, eq_on, steps=5, warmup=2):
         bp.process(x, out=y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    eq_ms, conv_ms, n = bp.profile_read()
+    eq_ms, conv_ms, n, _, _ = bp.profile_read()
     eb, cb = bp.kernel_bytes(frames // 512)
     print(json.dumps({"config": name, "streams": S, "taps": taps, "frames": frames, "eq": eq_on,
                       "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(S * frames / dt / 1e6, 1),
