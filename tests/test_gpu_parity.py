@@ -402,3 +402,65 @@ def test_synth_torch_generator_matches_numpy(synth):
     a = synth.white_noise(range(5, 8), 1000, offset=17)
     b = synth.white_noise_torch(5, 3, 1000, torch.device("cuda:0"), offset=17).cpu().numpy()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ------------------------------------------------------------------ edge cases of the fast paths
+@pytest.mark.parametrize("taps,n_blocks", [(512, 1), (512, 2), (512, 3), (512, 5), (512, 67),
+                                           (2000, 1), (2000, 3), (2000, 4), (2000, 9), (2000, 17)])
+def test_batch_small_block_counts_every_kernel_path(ohs, synth, oracle, taps, n_blocks):
+    """P=1: chunks <= n_blocks, fix-up kernel; P>1: general kernel below 4 blocks, time-parallel
+    kernels from 4 (tile of 8 partially filled), three consecutive calls chaining the state."""
+    _batch_vs_oracle(ohs, synth, oracle, S=3, taps=taps, n_blocks=n_blocks, eq_on=False, calls=3)
+
+
+@pytest.mark.parametrize("nb", [1, 16, 17, 32])
+def test_eq_band_counts_bit_exact(ohs, synth, oracle, nb):
+    """16 bands = the full DPP row (no output shift), 17 / 32 = two passes, 1 = shift by 15."""
+    from open_headstage_amd import BandConfig, FilterType
+    bands = [BandConfig(FilterType.Peak, 60.0 * (i + 1.5), 0.9 + 0.05 * i, (-1.0) ** i * (1.0 + 0.2 * i), True)
+             for i in range(nb)]
+    eg, eo = _mk_eqs(ohs, oracle, bands)
+    x = synth.white_noise([8], 5000)[0]
+    gl, gr = x[0].copy(), x[1].copy(); ol, orr = x[0].copy(), x[1].copy()
+    eg.process_block(gl, gr); eo.process_block(ol, orr)
+    assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32))
+    assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32))
+
+
+def test_batch_eq_long_stream_bit_exact_then_conv(ohs, synth, oracle):
+    """The asm steady-state groups + hand-counted vmcnt of k_eq_pass over a long stream (several
+    hundred groups), chained across two calls, with the EQ||convolution overlap active."""
+    w = _batch_vs_oracle(ohs, synth, oracle, S=5, taps=512, n_blocks=130, eq_on=True, calls=2, gain=1.0)
+    print("long stream worst rel RMS", w)
+
+
+def test_batch_strided_buffers(ohs, synth, oracle):
+    """process_ptr with strides larger than the processed region (a window into a bigger buffer)."""
+    import torch
+    S, frames, pad = 3, 2048, 384
+    irs = synth.hrir_set(512)
+    bp = ohs.BatchProcessor(S, num_bands=10)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i, b in enumerate(synth.eq_table()):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(True)
+    x = synth.white_noise(range(S), frames)
+    big = torch.full((S, 2, frames + pad), 7.0, device="cuda")
+    big[:, :, :frames] = torch.from_numpy(x).cuda()
+    out = torch.full_like(big, -3.0)
+    bp.process_ptr(big.data_ptr(), out.data_ptr(), frames // 512, 2 * (frames + pad), frames + pad,
+                   torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert np.all(o[:, :, frames:] == -3.0), "wrote outside the processed region"
+    for s_ in range(S):
+        eo = oracle.ConvolutionEngine()
+        for p in range(4):
+            eo.set_ir(p, irs[p])
+        qo = oracle.StereoParametricEQ(10, synth.FS)
+        for i, b in enumerate(synth.eq_table()):
+            qo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+        l, r = x[s_, 0].copy(), x[s_, 1].copy()
+        oracle.chain_process(eo, qo, l, r, eq_enable=True, gain=1.0)
+        assert_parity(o[s_, :, :frames], np.stack([l, r]), f"strided stream {s_}")
