@@ -42,7 +42,9 @@ enum {
     OHS_ERR_HIP = 3,              /* a HIP runtime call failed; see ohs_last_error() */
     OHS_ERR_OUTSIDE_NYQUIST = 4,  /* biquad::Errors::OutsideNyquist (the reference unwrap()s: parametric_eq.rs:111) */
     OHS_ERR_NEGATIVE_Q = 5,       /* biquad::Errors::NegativeQ */
-    OHS_ERR_ALLOC = 6
+    OHS_ERR_ALLOC = 6,
+    OHS_ERR_IO = 7,               /* a file could not be opened / read */
+    OHS_ERR_PARSE = 8             /* malformed CSV / unsupported filter type; see ohs_last_error() */
 };
 
 /* ConvolutionPath discriminants -- src/dsp/convolution.rs:28-33.
@@ -114,6 +116,26 @@ int  ohs_eq_reset(ohs_eq *eq);
 /* calculate_frequency_response(fs, &[f32]) -> Vec<f32>  parametric_eq.rs:190-209
  * (|H| of the enabled LEFT bands). */
 int  ohs_eq_frequency_response(const ohs_eq *eq, float fs, const float *freqs, size_t n, float *out);
+
+/* ---- AutoEQ profile ingestion  (src/autoeq_parser.rs:21-70) -- SURVEY section 8 row f3 ---------- */
+/* BandSetting  autoeq_parser.rs:34-41 */
+typedef struct ohs_band_setting {
+    int   enabled;       /* always 1 for parsed rows (autoeq_parser.rs:60) */
+    int   filter_type;   /* OHS_FILTER_PEAK / LOWSHELF / HIGHSHELF ("PK" / "LS" / "HS", :43-50) */
+    float frequency;     /* column "Fc"   */
+    float q;             /* column "Q"    */
+    float gain;          /* column "Gain" */
+} ohs_band_setting;
+/* parse_autoeq_csv(path) -> Vec<BandSetting>  autoeq_parser.rs:52-70: CSV with a header row naming
+ * the columns Filter-Type, Fc, Q, Gain (any order, extra columns ignored, RFC-4180 quoting, empty
+ * lines skipped -- the `csv` crate's defaults).  Writes at most `capacity` rows to `out`, the number
+ * of rows in the file to `*count`.  OHS_ERR_IO if the file cannot be opened, OHS_ERR_PARSE for a
+ * missing column, a field that is not an f32, a row of the wrong width or a filter type other than
+ * PK / LS / HS ("Unsupported filter type: X", :48). */
+int  ohs_autoeq_parse_csv(const char *path, ohs_band_setting *out, size_t capacity, size_t *count);
+/* the same on an in-memory buffer */
+int  ohs_autoeq_parse_csv_text(const char *text, size_t len, ohs_band_setting *out, size_t capacity,
+                               size_t *count);
 
 /* ---- Plugin::process DSP chain  (src/lib.rs:1169-1207) ----------------------- */
 /* In place on left/right: bypass => untouched; [eq_enable => EQ in place] ->

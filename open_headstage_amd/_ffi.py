@@ -18,6 +18,14 @@ OHS_ERR_HIP = 3
 OHS_ERR_OUTSIDE_NYQUIST = 4
 OHS_ERR_NEGATIVE_Q = 5
 OHS_ERR_ALLOC = 6
+OHS_ERR_IO = 7
+OHS_ERR_PARSE = 8
+
+class BandSettingC(C.Structure):
+    """ohs_band_setting (include/ohs_hip.h) = BandSetting, autoeq_parser.rs:34-41"""
+    _fields_ = [("enabled", C.c_int), ("filter_type", C.c_int), ("frequency", C.c_float),
+                ("q", C.c_float), ("gain", C.c_float)]
+
 
 fp = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -46,6 +54,10 @@ PROTOTYPES = {
     "ohs_eq_process_block": (C.c_int, [vp, fp, fp, C.c_size_t]),
     "ohs_eq_reset": (C.c_int, [vp]),
     "ohs_eq_frequency_response": (C.c_int, [vp, C.c_float, fp, C.c_size_t, fp]),
+    "ohs_autoeq_parse_csv": (C.c_int, [C.c_char_p, C.POINTER(BandSettingC), C.c_size_t,
+                                       C.POINTER(C.c_size_t)]),
+    "ohs_autoeq_parse_csv_text": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(BandSettingC), C.c_size_t,
+                                            C.POINTER(C.c_size_t)]),
     "ohs_chain_process": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, fp, fp, C.c_size_t]),
     "ohs_batch_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, vpp]),
     "ohs_batch_destroy": (None, [vp]),

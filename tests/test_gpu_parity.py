@@ -464,3 +464,21 @@ def test_batch_strided_buffers(ohs, synth, oracle):
         l, r = x[s_, 0].copy(), x[s_, 1].copy()
         oracle.chain_process(eo, qo, l, r, eq_enable=True, gain=1.0)
         assert_parity(o[s_, :, :frames], np.stack([l, r]), f"strided stream {s_}")
+
+
+def test_autoeq_profile_drives_the_eq_bit_exact(ohs, synth, oracle):
+    """f3 end to end: CSV -> bands -> coefficients -> EQ kernel, bit-exact against the oracle fed the
+    same parsed rows."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "autoeq_sample.csv")
+    bands = ohs.parse_autoeq_csv(path)
+    eg = ohs.StereoParametricEQ.new(10, 48000.0)
+    ohs.apply_bands(eg, bands, 48000.0)
+    eo = oracle.StereoParametricEQ(10, 48000.0)
+    for i, b in enumerate(bands):
+        eo.update_band_coeffs(i, 48000.0, int(b.filter_type), b.frequency, b.q, b.gain, b.enabled)
+    x = synth.white_noise([12], 4096)[0]
+    gl, gr = x[0].copy(), x[1].copy(); ol, orr = x[0].copy(), x[1].copy()
+    eg.process_block(gl, gr); eo.process_block(ol, orr)
+    assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32))
+    assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32))
