@@ -137,6 +137,35 @@ int  ohs_autoeq_parse_csv(const char *path, ohs_band_setting *out, size_t capaci
 int  ohs_autoeq_parse_csv_text(const char *text, size_t len, ohs_band_setting *out, size_t capacity,
                                size_t *count);
 
+/* ---- SOFA HRIR source  (src/sofa/loader.rs:79-199 + system libmysofa) -- SURVEY section 8 row f1 -- */
+/* A minimal reader for AES69 SimpleFreeFieldHRIR files (HDF5 subset, see csrc/sofa_reader.cpp).
+ * Deliberately NOT libmysofa's extras: no loudness normalisation, no neighbour interpolation, no
+ * resampling inside open (use ohs_sofa_resample_ir).  Angles are DEGREES, AES69 convention: azimuth
+ * counter-clockwise from the front (positive = left), elevation up; radius in metres. */
+typedef struct ohs_sofa ohs_sofa;
+/* MySofa::open(path, ..)  loader.rs:79-130.  OHS_ERR_IO when the file cannot be opened
+ * (SofaError::FileOpen, tested at loader.rs:244-257), OHS_ERR_PARSE when it is not a readable SOFA file. */
+int  ohs_sofa_open(const char *path, ohs_sofa **out);
+void ohs_sofa_close(ohs_sofa *s);                                   /* Drop -> mysofa_close  loader.rs:64-73 */
+/* M measurements x R receivers x N taps, Data.SamplingRate (hrtf.N / DataSamplingRate, loader.rs:102-118) */
+int  ohs_sofa_info(const ohs_sofa *s, size_t *M, size_t *R, size_t *N, float *fs);
+int  ohs_sofa_position(const ohs_sofa *s, size_t m, float az_el_r[3]);
+/* MySofa::spherical_to_cartesian / cartesian_to_spherical  loader.rs:203-229 ([az deg, el deg, r m] <-> xyz) */
+int  ohs_sofa_spherical_to_cartesian(const float az_el_r[3], float xyz[3]);
+int  ohs_sofa_cartesian_to_spherical(const float xyz[3], float az_el_r[3]);
+/* nearest measurement in Cartesian space (what mysofa_lookup's kd-tree returns) */
+int  ohs_sofa_nearest(const ohs_sofa *s, float az_deg, float el_deg, float radius_m, size_t *index);
+int  ohs_sofa_get_ir(const ohs_sofa *s, size_t m, size_t receiver, float *out, size_t capacity);
+/* MySofa::get_hrtf_irs(az, el, r) -> (left_ir, right_ir)  loader.rs:136-199; also returns the
+ * per-ear Data.Delay values the reference leaves as a TODO (loader.rs:193-196).  Degrees, not the
+ * radians the reference hands to mysofa_s2c (loader.rs:158-165). */
+int  ohs_sofa_get_hrtf_irs(const ohs_sofa *s, float az_deg, float el_deg, float radius_m, float *left,
+                           float *right, size_t capacity, float *delay_left, float *delay_right);
+/* Kaiser-windowed-sinc resampling of one IR, e.g. 44.1 -> 48 kHz (libmysofa does this inside
+ * mysofa_open, loader.rs:83-90).  out == NULL: only *out_len = ceil(n * fs_out / fs_in) is written. */
+int  ohs_sofa_resample_ir(const float *in, size_t n, float fs_in, float fs_out, float *out, size_t capacity,
+                          size_t *out_len);
+
 /* ---- Plugin::process DSP chain  (src/lib.rs:1169-1207) ----------------------- */
 /* In place on left/right: bypass => untouched; [eq_enable => EQ in place] ->
  * convolution -> every sample *= gain.  One H2D + one D2H per call; the caller

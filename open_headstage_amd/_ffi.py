@@ -58,6 +58,18 @@ PROTOTYPES = {
                                        C.POINTER(C.c_size_t)]),
     "ohs_autoeq_parse_csv_text": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(BandSettingC), C.c_size_t,
                                             C.POINTER(C.c_size_t)]),
+    "ohs_sofa_open": (C.c_int, [C.c_char_p, vpp]),
+    "ohs_sofa_close": (None, [vp]),
+    "ohs_sofa_info": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_float)]),
+    "ohs_sofa_position": (C.c_int, [vp, C.c_size_t, fp]),
+    "ohs_sofa_spherical_to_cartesian": (C.c_int, [fp, fp]),
+    "ohs_sofa_cartesian_to_spherical": (C.c_int, [fp, fp]),
+    "ohs_sofa_nearest": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_size_t)]),
+    "ohs_sofa_get_ir": (C.c_int, [vp, C.c_size_t, C.c_size_t, fp, C.c_size_t]),
+    "ohs_sofa_get_hrtf_irs": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, fp, fp, C.c_size_t, fp, fp]),
+    "ohs_sofa_resample_ir": (C.c_int, [fp, C.c_size_t, C.c_float, C.c_float, fp, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]),
     "ohs_chain_process": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, fp, fp, C.c_size_t]),
     "ohs_batch_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, vpp]),
     "ohs_batch_destroy": (None, [vp]),

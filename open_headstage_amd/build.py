@@ -24,6 +24,7 @@ UNITS = [
     ("conv_kernels.hip", []),
     ("eq_kernels.hip", ["-ffp-contract=off"]),
     ("ohs_api.hip", []),
+    ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-value", "-Wno-unused-result"]
@@ -50,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     relink = force or not os.path.exists(LIB)
     for src, extra in UNITS:
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         stale = force or not os.path.exists(obj) or any(
             os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
@@ -61,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.run(cmd, check=True)
             relink = True
     if relink or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -621,6 +621,9 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
 // =======================================================================================
 extern "C" {
 
+// shared with sofa_reader.cpp (not part of the public header)
+void ohs_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+
 int ohs_version(void) { return (0 << 16) | (1 << 8) | 0; }
 
 const char *ohs_status_string(int s)

@@ -482,3 +482,26 @@ def test_autoeq_profile_drives_the_eq_bit_exact(ohs, synth, oracle):
     eg.process_block(gl, gr); eo.process_block(ol, orr)
     assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32))
     assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32))
+
+
+def test_real_hrirs_cipic_subject_003(ohs, synth, oracle):
+    """f1 end to end with measured HRIRs (CIPIC subject 003, +/-30 deg, resampled to 48 kHz; fixture
+    made by tools/make_sofa_fixture.py from the reference's data asset): engine and batch vs oracle / f64."""
+    import os
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cipic003_pm30.npz"))
+    irs = list(g["irs_48000"])
+    eg = ohs.ConvolutionEngine.new()
+    eo = setup_engines(oracle, eg, irs)
+    x = synth.white_noise([21], 8192)[0]
+    outs_g = [np.stack(eg.process_block(x[0, c * 1024:(c + 1) * 1024], x[1, c * 1024:(c + 1) * 1024])) for c in range(8)]
+    o = np.stack(eo.process_block(x[0], x[1]))
+    gg = np.concatenate(outs_g, axis=1)
+    f = np.stack(oracle.binaural_f64(x[0], x[1], irs))
+    assert_parity(gg, o, "CIPIC engine vs oracle")
+    assert_parity(gg, f, "CIPIC engine vs f64")
+    bp = ohs.BatchProcessor(1, num_bands=10)
+    from open_headstage_amd import sofa
+    sofa.load_into(bp, irs)
+    y = bp.process(torch.from_numpy(x[None].copy()).cuda()).cpu().numpy()[0]
+    assert_parity(y, f, "CIPIC batch vs f64")
