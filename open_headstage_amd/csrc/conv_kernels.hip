@@ -53,20 +53,50 @@ hipError_t launch_ir_spectrum(const float *d_ir, int len, int n_parts, float2 *d
 // ---------------------------------------------------------------------------------
 // General convolution kernel: one wave per stream, blocks in sequence.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
-{
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float2 *tab = smem;
-    float2 *lds = smem + kTabComplex;
-    const int lane = threadIdx.x;
-    const size_t s = blockIdx.x;
-    fill_twiddle_tables(tab, A.tw, lane, 64);
-    __syncthreads();
+// audio access policies of the general kernel ------------------------------------------------
+// PlainIO: planar device buffers (batch mode, multi-launch engine path).
+struct PlainIO {
+    const float *in_l, *in_r;
+    float *out_l, *out_r;
+    float gain;
+    __device__ __forceinline__ void init(const ConvGeneralArgs &A, size_t s)
+    {
+        in_l = A.in + s * A.in_stream_stride; in_r = in_l + A.in_ch_stride;
+        out_l = A.out + s * A.out_stream_stride; out_r = out_l + A.out_ch_stride;
+        gain = A.gain;
+    }
+    __device__ __forceinline__ float2 load(size_t idx) const { return make_float2(in_l[idx], in_r[idx]); }
+    __device__ __forceinline__ void store(size_t idx, float l, float r) const { out_l[idx] = l * gain; out_r[idx] = r * gain; }
+};
 
-    const float *in_l = A.in + s * A.in_stream_stride;
-    const float *in_r = in_l + A.in_ch_stride;
-    float *out_l = A.out + s * A.out_stream_stride;
-    float *out_r = out_l + A.out_ch_stride;
+// EngineIO: the host-block adapter of ConvolutionEngine::process_block (convolution.rs:141-182) folded
+// into the kernel.  Input frame i of this call's block stream comes from the
+// device FIFO (the < 512 frames left over by earlier calls) or from `src` (this call's n new frames,
+// pinned host memory mapped into the device, or the EQ's device output); output frame j goes
+// straight to the mapped host buffer when it is popped by this call, else to its post-pop position
+// in the device FIFO.  One launch, no separate copies.
+struct EngineIO {
+    EngineCallArgs E;
+    __device__ __forceinline__ float2 load(size_t idx) const
+    {
+        if (idx < (size_t)E.in_len) return make_float2(E.in_fifo[idx], E.in_fifo[E.in_cap + idx]);
+        const size_t k = idx - E.in_len;
+        return make_float2(E.src_l[k], E.src_r[k]);
+    }
+    __device__ __forceinline__ void store(size_t idx, float l, float r) const
+    {
+        const size_t j = (size_t)E.out_len + idx;
+        if (E.emit) {
+            if (j < (size_t)E.n) { E.host_l[j] = l * E.gain_pop; E.host_r[j] = r * E.gain_pop; }
+            else { E.out_fifo[j - E.n] = l; E.out_fifo[E.out_cap + j - E.n] = r; }
+        } else { E.out_fifo[j] = l; E.out_fifo[E.out_cap + j] = r; }
+    }
+};
+
+template <class IO>
+__device__ __forceinline__ void conv_general_body(const ConvGeneralArgs &A, const IO &io, float2 *tab, float2 *lds,
+                                                  int lane, size_t s)
+{
     float2 *hist = A.hist + s * (size_t)A.cap * kFft;
     const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
     float2 *tails_out = A.tails_out + s * (size_t)(2 * 8 * 64);
@@ -88,7 +118,7 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-            v[a] = make_float2(in_l[idx], in_r[idx]);
+            v[a] = io.load(idx);
         }
 #pragma unroll
         for (int a = 8; a < 16; ++a) v[a] = make_float2(0.0f, 0.0f);   // zero pad (:248-254)
@@ -154,10 +184,7 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
             tail1[a] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
             tail2[a] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
             const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-            if (t >= A.skip_store) {
-                out_l[idx] = (lsl + rsl) * A.gain;
-                out_r[idx] = (lsr + rsr) * A.gain;
-            }
+            if (t >= A.skip_store) io.store(idx, lsl + rsl, lsr + rsr);
         }
     }
 #pragma unroll
@@ -167,10 +194,76 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
     }
 }
 
+__global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *lds = smem + kTabComplex;
+    const int lane = threadIdx.x;
+    fill_twiddle_tables(tab, A.tw, lane, 64);
+    __syncthreads();
+    PlainIO io;
+    io.init(A, blockIdx.x);
+    conv_general_body(A, io, tab, lds, lane, blockIdx.x);
+}
+
+// One launch = one ConvolutionEngine::process_block call for a single stream (f2).
+__global__ __launch_bounds__(64) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *lds = smem + kTabComplex;
+    const int lane = threadIdx.x;
+    fill_twiddle_tables(tab, A.tw, lane, 64);
+    __syncthreads();
+    // 1. frames already waiting in the output FIFO: pop what this call takes, slide the rest down
+    if (E.out_len > 0 && E.emit) {
+        const int take = E.out_len < E.n ? E.out_len : E.n;
+        for (int i = lane; i < take; i += 64) {
+            E.host_l[i] = E.out_fifo[i] * E.gain_pop;
+            E.host_r[i] = E.out_fifo[E.out_cap + i] * E.gain_pop;
+        }
+        for (int base = E.n; base < E.out_len; base += 64) {      // ascending, read-then-write per 64
+            const int i = base + lane;
+            float l = 0.f, r = 0.f;
+            if (i < E.out_len) { l = E.out_fifo[i]; r = E.out_fifo[E.out_cap + i]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (i < E.out_len) { E.out_fifo[i - E.n] = l; E.out_fifo[E.out_cap + i - E.n] = r; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // 2. every complete 512-block (convolution.rs:152-161)
+    EngineIO io;
+    io.E = E;
+    if (A.n_blocks > 0) conv_general_body(A, io, tab, lds, lane, 0);
+    // 3. what is left of the input (< 512 frames) becomes the FIFO content for the next call
+    const int consumed = A.n_blocks * kBlock;
+    const int rem = E.in_len + E.n - consumed;
+    if (A.n_blocks == 0) {
+        for (int i = lane; i < E.n; i += 64) {
+            E.in_fifo[E.in_len + i] = E.src_l[i];
+            E.in_fifo[E.in_cap + E.in_len + i] = E.src_r[i];
+        }
+    } else {
+        // in_len < 512 <= consumed: the remainder lies entirely in this call's new frames
+        for (int i = lane; i < rem; i += 64) {
+            E.in_fifo[i] = E.src_l[consumed - E.in_len + i];
+            E.in_fifo[E.in_cap + i] = E.src_r[consumed - E.in_len + i];
+        }
+    }
+}
+
 hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st)
 {
     const size_t shmem = (kTabComplex + kWaveLdsComplex) * sizeof(float2);
     hipLaunchKernelGGL(k_conv_general, dim3(n_streams), dim3(64), shmem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + kWaveLdsComplex) * sizeof(float2);
+    hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(64), shmem, st, a, e);
     return hipGetLastError();
 }
 

@@ -29,6 +29,21 @@ struct ConvGeneralArgs {
 };
 hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st);
 
+// One-launch ConvolutionEngine::process_block for a single stream: FIFO
+// adapter, blocks and pop in one kernel; `a` describes the convolution state (in/out fields unused).
+struct EngineCallArgs {
+    float *in_fifo;             // device [2][in_cap]; holds in_len (< 512) frames from earlier calls
+    int in_cap, in_len;
+    float *out_fifo;            // device [2][out_cap]; holds out_len frames not yet popped
+    int out_cap, out_len;
+    const float *src_l, *src_r; // this call's n input frames (mapped pinned host memory or device)
+    float *host_l, *host_r;     // this call's n output frames (mapped pinned host memory)
+    int n;
+    int emit;                   // 1: out_len + 512 k >= n, the call pops n frames; 0: silence (host fills)
+    float gain_pop;             // applied to popped frames only (lib.rs:1202-1207)
+};
+hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st);
+
 // Fast path when every path has exactly one partition (taps <= 512): time-parallel over
 // `chunks` contiguous block ranges per stream, one forward + one inverse FFT per block, the
 // combined spectra C = (A - jB)/2, D = (A + jB)/2 (A = H0 + jH1, B = H2 + jH3) held in registers.

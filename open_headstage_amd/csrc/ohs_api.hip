@@ -6,6 +6,7 @@
 // create call fails with OHS_ERR_NO_DEVICE when no GPU is usable.
 #include "../../include/ohs_hip.h"
 #include "kernels.h"
+#include "wave_fft.hpp"
 
 #include <algorithm>
 #include <cctype>
@@ -70,11 +71,14 @@ int get_ctx(int device, DeviceCtx **out)
         const double ang = -2.0 * 3.14159265358979323846264338327950288 * (double)k / (double)NF;
         tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
     }
-    if (hipMalloc(&c->d_tw, NF * sizeof(float2)) != hipSuccess) {
+    // every kernel receives the EXPANDED, lane-ordered tables (26 KiB) and copies them to LDS
+    std::vector<float2> expanded(kTabComplex);
+    expand_twiddle_tables(tw.data(), expanded.data());
+    if (hipMalloc(&c->d_tw, kTabComplex * sizeof(float2)) != hipSuccess) {
         delete c;
         return fail(OHS_ERR_HIP, "hipMalloc(twiddles) failed");
     }
-    if (hipMemcpy(c->d_tw, tw.data(), NF * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpy(c->d_tw, expanded.data(), kTabComplex * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
         hipFree(c->d_tw);
         delete c;
         return fail(OHS_ERR_HIP, "hipMemcpy(twiddles) failed");
@@ -517,6 +521,11 @@ struct ohs_engine {
     DevFifo in, out, scratch;
     float *d_stage = nullptr;   // [2][stage_cap] pop staging (gain applied here)
     size_t stage_cap = 0;
+    // single-launch call path (f2): pinned host staging mapped into the device + EQ output buffer
+    float *h_in = nullptr, *h_out = nullptr;      // host [2][hcap]
+    float *dm_in = nullptr, *dm_out = nullptr;    // the same memory, device addresses
+    float *d_eqbuf = nullptr;                     // device [2][hcap]
+    size_t hcap = 0;
 };
 
 struct ohs_eq {
@@ -562,6 +571,80 @@ int engine_stage_reserve(ohs_engine *e, size_t n)
     return OHS_OK;
 }
 
+int engine_pinned_reserve(ohs_engine *e, size_t n)
+{
+    if (n <= e->hcap) return OHS_OK;
+    size_t ncap = e->hcap ? e->hcap : 2048;
+    while (ncap < n) ncap *= 2;
+    if (e->h_in) hipHostFree(e->h_in);
+    if (e->h_out) hipHostFree(e->h_out);
+    if (e->d_eqbuf) hipFree(e->d_eqbuf);
+    e->h_in = e->h_out = e->d_eqbuf = nullptr; e->hcap = 0;
+    HIP_TRY(hipHostMalloc((void **)&e->h_in, 2 * ncap * sizeof(float), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&e->h_out, 2 * ncap * sizeof(float), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&e->dm_in, e->h_in, 0));
+    HIP_TRY(hipHostGetDevicePointer((void **)&e->dm_out, e->h_out, 0));
+    HIP_TRY(hipMalloc(&e->d_eqbuf, 2 * ncap * sizeof(float)));
+    e->hcap = ncap;
+    return OHS_OK;
+}
+
+// the whole process_block call -- FIFO adapter, up to 8 internal blocks, pop
+// with gain -- as ONE kernel launch reading / writing pinned host memory directly (plus one EQ
+// launch for the lib.rs chain).  Requires the invariant in.len < 512, which both call paths keep.
+int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *in_r, float *out_l,
+                                 float *out_r, size_t n, ohs_eq *eq, float gain)
+{
+    hipStream_t st = e->st;
+    int rc = engine_pinned_reserve(e, n);
+    if (rc) return rc;
+    std::memcpy(e->h_in, in_l, n * sizeof(float));
+    std::memcpy(e->h_in + e->hcap, in_r, n * sizeof(float));
+    const float *src_l = e->dm_in, *src_r = e->dm_in + e->hcap;
+    if (eq) {   // lib.rs:1194: EQ on this host block before the engine sees it
+        bool did = false;
+        rc = eq_launch(eq->eq, e->dm_in, e->d_eqbuf, 0, (long long)e->hcap, (long long)n, st, &did);
+        if (rc) return rc;
+        if (did) { src_l = e->d_eqbuf; src_r = e->d_eqbuf + e->hcap; }
+    }
+    const size_t k = (e->in.len + n) / BS;
+    const bool emit = e->out.len + k * BS >= n;
+    rc = fifo_reserve(e->in, 2 * BS, st);
+    if (rc) return rc;
+    rc = fifo_reserve(e->out, e->out.len + k * BS + 1, st);
+    if (rc) return rc;
+    ConvState &c = e->conv;
+    ConvGeneralArgs a;
+    a.in = nullptr; a.out = nullptr;
+    a.in_stream_stride = a.in_ch_stride = a.out_stream_stride = a.out_ch_stride = 0;
+    a.n_blocks = (int)k;
+    for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
+    a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
+    a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
+    a.tw = e->ctx->d_tw; a.gain = 1.0f;
+    EngineCallArgs g;
+    g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
+    g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
+    g.src_l = src_l; g.src_r = src_r;
+    g.host_l = e->dm_out; g.host_r = e->dm_out + e->hcap;
+    g.n = (int)n; g.emit = emit ? 1 : 0; g.gain_pop = gain;
+    hipError_t err = launch_engine_call(a, g, st);
+    if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("engine call launch: ") + hipGetErrorString(err));
+    c.cnt += k;
+    for (int p = 0; p < 4; ++p) c.since[p] += (long long)k;
+    e->in.len = e->in.len + n - k * BS;
+    e->out.len = emit ? e->out.len + k * BS - n : e->out.len + k * BS;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (emit) {
+        std::memcpy(out_l, e->h_out, n * sizeof(float));
+        std::memcpy(out_r, e->h_out + e->hcap, n * sizeof(float));
+    } else {            // convolution.rs:176-181
+        std::memset(out_l, 0, n * sizeof(float));
+        std::memset(out_r, 0, n * sizeof(float));
+    }
+    return OHS_OK;
+}
+
 // process_block (convolution.rs:141-182) with the FIFOs on the device; optionally the
 // lib.rs:1179-1207 chain around it (EQ on the freshly appended frames, gain on the popped ones).
 int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *out_l, float *out_r,
@@ -571,6 +654,9 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     if (!in_l || !in_r || !out_l || !out_r) return fail(OHS_ERR_INVALID_ARG, "NULL audio pointer");
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = e->st;
+    // real-time sized calls: everything in one launch; long offline calls: the multi-kernel path below
+    if ((e->in.len + n) / BS <= 8 && n <= 8192 && e->in.len < (size_t)BS)
+        return engine_process_single_launch(e, in_l, in_r, out_l, out_r, n, eq, gain);
     int rc = fifo_reserve(e->in, e->in.len + n, st);
     if (rc) return rc;
     // :149-150 append
@@ -710,6 +796,9 @@ void ohs_engine_destroy(ohs_engine *e)
     if (e->out.d) hipFree(e->out.d);
     if (e->scratch.d) hipFree(e->scratch.d);
     if (e->d_stage) hipFree(e->d_stage);
+    if (e->h_in) hipHostFree(e->h_in);
+    if (e->h_out) hipHostFree(e->h_out);
+    if (e->d_eqbuf) hipFree(e->d_eqbuf);
     if (e->st) hipStreamDestroy(e->st);
     delete e;
 }

@@ -123,20 +123,30 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
     t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
-// Fill the 26 KiB of per-workgroup twiddle tables from the 1024-entry master
-// table tw[e] = exp(-2 pi i e / 1024) (f64-computed on the host, rounded to f32).
-__device__ __forceinline__ void fill_twiddle_tables(float2 *tab, const float2 *__restrict__ tw,
+// The 26 KiB of per-workgroup twiddle tables are expanded ONCE per device on the host
+// (expand_twiddle_tables, from exp(-2 pi i e / 1024) computed in f64 and rounded to f32, as rustfft
+// does); a kernel only copies them into LDS with 16-byte loads.
+__device__ __forceinline__ void fill_twiddle_tables(float2 *tab, const float2 *__restrict__ gtab,
                                                     int tid, int nthreads)
 {
-    for (int i = tid; i < 16 * 64; i += nthreads) {
+    const float4 *src = reinterpret_cast<const float4 *>(gtab);
+    float4 *dst = reinterpret_cast<float4 *>(tab);
+#pragma unroll 4
+    for (int i = tid; i < kTabComplex / 2; i += nthreads) dst[i] = src[i];
+}
+
+// host side: expanded[kTabComplex] from tw[e] = exp(-2 pi i e / 1024)
+inline void expand_twiddle_tables(const float2 *tw, float2 *expanded)
+{
+    for (int i = 0; i < 16 * 64; ++i) {
         const int r = i >> 6, l = i & 63;
-        tab[kTabA + i] = tw[(l * r) & 1023];                            // w1024^(m p)
-        tab[kTabB + i] = tw[(16 * (l & 3) * r) & 1023];                 // w64^(c q)
-        tab[kTabD + i] = tw[((4 * r + (l & 3)) * (l >> 2)) & 1023];     // w1024^((4b+c) p)
+        expanded[kTabA + i] = tw[(l * r) & 1023];                            // w1024^(m p)
+        expanded[kTabB + i] = tw[(16 * (l & 3) * r) & 1023];                 // w64^(c q)
+        expanded[kTabD + i] = tw[((4 * r + (l & 3)) * (l >> 2)) & 1023];     // w1024^((4b+c) p)
     }
-    for (int i = tid; i < 4 * 64; i += nthreads) {
+    for (int i = 0; i < 4 * 64; ++i) {
         const int c = i >> 6, l = i & 63;
-        tab[kTabC + i] = tw[(16 * c * (l >> 2)) & 1023];                // w64^(c q)
+        expanded[kTabC + i] = tw[(16 * c * (l >> 2)) & 1023];                // w64^(c q)
     }
 }
 
