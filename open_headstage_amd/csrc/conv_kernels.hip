@@ -301,20 +301,32 @@ hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2,
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void k_conv_p1(const ConvP1Args A)
+// main kernel: blocks [0, n_main) of every stream in merged form (n_main = n_blocks - 1).
+// 12 waves per workgroup, one workgroup per CU: 17 KiB twiddle tables + 16 KiB combined spectra
+// (C, D) shared in LDS + 12 x 8.5 KiB FFT slabs = 137 KiB; <= 168 VGPRs => 3 waves per SIMD.
+// (Keeping C, D in 64 VGPRs per lane held the kernel at 2 waves per SIMD, latency-bound.)
+constexpr int kP1Waves = 12;
+__global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
-    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    float2 *cd = smem + kTabComplex;                    // [2][16][64]
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kP1Waves);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(A.CD);
+        float4 *dst = reinterpret_cast<float4 *>(cd);
+        for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) dst[i] = src[i];
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
+    float2 *lds = smem + kTabComplex + 2 * kFft + wave * kWaveLdsComplex;
+    const long long gw = (long long)blockIdx.x * kP1Waves + wave;
     if (gw >= (long long)A.n_streams * A.chunks) return;
     const size_t s = (size_t)(gw / A.chunks);
     const int ck = (int)(gw % A.chunks);
-    const int b0 = (int)((long long)ck * A.n_blocks / A.chunks);
-    const int b1 = (int)((long long)(ck + 1) * A.n_blocks / A.chunks);
+    const int n_main = A.n_blocks - 1;
+    const int b0 = (int)((long long)ck * n_main / A.chunks);
+    const int b1 = (int)((long long)(ck + 1) * n_main / A.chunks);
     if (b0 >= b1) return;
 
     const float *in_l = A.in + s * A.in_stream_stride;
@@ -322,15 +334,8 @@ __global__ __launch_bounds__(256) void k_conv_p1(const ConvP1Args A)
     float *out_l = A.out + s * A.out_stream_stride;
     float *out_r = out_l + A.out_ch_stride;
     const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
-    float2 *tails_out = A.tails_out + s * (size_t)(2 * 8 * 64);
     const float scale = 1.0f / (float)kFft;
 
-    float2 C[16], D[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        C[r] = A.CD[r * 64 + lane];
-        D[r] = A.CD[kFft + r * 64 + lane];
-    }
     float2 tail[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
@@ -341,76 +346,101 @@ __global__ __launch_bounds__(256) void k_conv_p1(const ConvP1Args A)
             tail[a] = make_float2(0.0f, 0.0f);      // k_conv_p1_fixup adds the previous chunk's tail
         }
     }
-
-    float2 xn[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const size_t idx = (size_t)b0 * kBlock + 64 * a + lane;
-        xn[a] = make_float2(in_l[idx], in_r[idx]);
-    }
     for (int t = b0; t < b1; ++t) {
         float2 v[16];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) { v[a] = xn[a]; v[a + 8] = make_float2(0.0f, 0.0f); }
-        if (t + 1 < b1) {        // prefetch the next block's input under this block's transforms
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const size_t idx = (size_t)(t + 1) * kBlock + 64 * a + lane;
-                xn[a] = make_float2(in_l[idx], in_r[idx]);
-            }
+        for (int a = 0; a < 8; ++a) {
+            const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+            v[a] = make_float2(in_l[idx], in_r[idx]);
+            v[a + 8] = make_float2(0.0f, 0.0f);
         }
         wave_fft_fwd(v, lds, tab, lane);
-        float2 zm[16];
-        wave_mirror(v, zm, lane);
-        if (t != A.n_blocks - 1) {
+        float2 w[16];
+        wave_mirror(v, w, lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // W = Z C + conj(Zm) D
-                const float2 z = v[r], m = zm[r];
-                float2 w;
-                w.x = z.x * C[r].x - z.y * C[r].y + m.x * D[r].x + m.y * D[r].y;
-                w.y = z.x * C[r].y + z.y * C[r].x + m.x * D[r].y - m.y * D[r].x;
-                v[r] = w;
-            }
-            wave_fft_inv(v, lds, tab, lane);
+        for (int r = 0; r < 16; ++r) {
+            // W = Z C + conj(Zm) D, written over the mirror value
+            const float2 z = v[r], m = w[r];
+            const float2 c = cd[r * 64 + lane], d = cd[kFft + r * 64 + lane];
+            w[r].x = z.x * c.x - z.y * c.y + m.x * d.x + m.y * d.y;
+            w[r].y = z.x * c.y + z.y * c.x + m.x * d.y - m.y * d.x;
+        }
+        wave_fft_inv(w, lds, tab, lane);
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-                out_l[idx] = (v[a].x * scale + tail[a].x) * A.gain;
-                out_r[idx] = (v[a].y * scale + tail[a].y) * A.gain;
-                tail[a] = make_float2(v[a + 8].x * scale, v[a + 8].y * scale);
-            }
-        } else {
-            // last block of the launch: four separate overlap tails, as the general kernel keeps them
-            float2 acc1[16], acc2[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float2 xl = make_float2(0.5f * (v[r].x + zm[r].x), 0.5f * (v[r].y - zm[r].y));
-                const float2 xr = make_float2(0.5f * (v[r].y + zm[r].y), -0.5f * (v[r].x - zm[r].x));
-                const float2 y0 = cmul(xl, A.H[0][r * 64 + lane]);
-                const float2 y1 = cmul(xl, A.H[1][r * 64 + lane]);
-                const float2 y2 = cmul(xr, A.H[2][r * 64 + lane]);
-                const float2 y3 = cmul(xr, A.H[3][r * 64 + lane]);
-                acc1[r] = make_float2(y0.x - y1.y, y0.y + y1.x);
-                acc2[r] = make_float2(y2.x - y3.y, y2.y + y3.x);
-            }
-            wave_fft_inv(acc1, lds, tab, lane);
-            wave_fft_inv(acc2, lds, tab, lane);
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-                out_l[idx] = ((acc1[a].x * scale + tail[a].x) + acc2[a].x * scale) * A.gain;
-                out_r[idx] = ((acc1[a].y * scale + tail[a].y) + acc2[a].y * scale) * A.gain;
-                // new state goes to a second slab: another chunk's wave may still be reading `tails`
-                tails_out[a * 64 + lane] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
-                tails_out[(8 + a) * 64 + lane] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
-            }
+        for (int a = 0; a < 8; ++a) {
+            const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+            out_l[idx] = (w[a].x * scale + tail[a].x) * A.gain;
+            out_r[idx] = (w[a].y * scale + tail[a].y) * A.gain;
+            tail[a] = make_float2(w[a + 8].x * scale, w[a + 8].y * scale);
         }
     }
-    if (b1 != A.n_blocks) {
-        float2 *ct = A.chunk_tails + (s * A.chunks + ck) * (size_t)(8 * 64);
+    // the tail leaving EVERY chunk is published: the next chunk's first block (fix-up kernel) or the
+    // launch's last block (k_conv_p1_last) adds it
+    float2 *ct = A.chunk_tails + (s * A.chunks + ck) * (size_t)(8 * 64);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) ct[a * 64 + lane] = tail[a];
+    for (int a = 0; a < 8; ++a) ct[a * 64 + lane] = tail[a];
+}
+
+// last block of the launch, one wave per stream: four separate overlap tails, as the general kernel
+// keeps them (two packed inverse transforms)
+__global__ __launch_bounds__(256) void k_conv_p1_last(const ConvP1Args A)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
+    const long long s_ = (long long)blockIdx.x * 4 + wave;
+    if (s_ >= A.n_streams) return;
+    const size_t s = (size_t)s_;
+    const int t = A.n_blocks - 1;
+    const float *in_l = A.in + s * A.in_stream_stride;
+    const float *in_r = in_l + A.in_ch_stride;
+    float *out_l = A.out + s * A.out_stream_stride;
+    float *out_r = out_l + A.out_ch_stride;
+    const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
+    float2 *tails_out = A.tails_out + s * (size_t)(2 * 8 * 64);
+    const float scale = 1.0f / (float)kFft;
+    float2 v[16], zm[16];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+        v[a] = make_float2(in_l[idx], in_r[idx]);
+        v[a + 8] = make_float2(0.0f, 0.0f);
+    }
+    wave_fft_fwd(v, lds, tab, lane);
+    wave_mirror(v, zm, lane);
+    float2 acc1[16], acc2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float2 xl = make_float2(0.5f * (v[r].x + zm[r].x), 0.5f * (v[r].y - zm[r].y));
+        const float2 xr = make_float2(0.5f * (v[r].y + zm[r].y), -0.5f * (v[r].x - zm[r].x));
+        const float2 y0 = cmul(xl, A.H[0][r * 64 + lane]);
+        const float2 y1 = cmul(xl, A.H[1][r * 64 + lane]);
+        const float2 y2 = cmul(xr, A.H[2][r * 64 + lane]);
+        const float2 y3 = cmul(xr, A.H[3][r * 64 + lane]);
+        acc1[r] = make_float2(y0.x - y1.y, y0.y + y1.x);
+        acc2[r] = make_float2(y2.x - y3.y, y2.y + y3.x);
+    }
+    wave_fft_inv(acc1, lds, tab, lane);
+    wave_fft_inv(acc2, lds, tab, lane);
+    // incoming overlap: the saved state for a one-block launch, else what the main kernel's last chunk left
+    const float2 *ct = A.chunk_tails + (s * A.chunks + (size_t)(A.chunks - 1)) * (size_t)(8 * 64);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        float2 tin;
+        if (A.n_blocks == 1) {
+            const float2 t1 = tails[a * 64 + lane], t2 = tails[(8 + a) * 64 + lane];
+            tin = make_float2(t1.x + t2.x, t1.y + t2.y);
+        } else {
+            tin = ct[a * 64 + lane];
+        }
+        const size_t idx = (size_t)t * kBlock + 64 * a + lane;
+        out_l[idx] = ((acc1[a].x * scale + tin.x) + acc2[a].x * scale) * A.gain;
+        out_r[idx] = ((acc1[a].y * scale + tin.y) + acc2[a].y * scale) * A.gain;
+        tails_out[a * 64 + lane] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
+        tails_out[(8 + a) * 64 + lane] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
     }
 }
 
@@ -423,8 +453,8 @@ __global__ __launch_bounds__(256) void k_conv_p1_fixup(const ConvP1Args A)
     const size_t s = (size_t)(gid / per_stream);
     const int rem = (int)(gid % per_stream);
     const int ck = 1 + rem / 512, i = rem % 512;
-    const int b0 = (int)((long long)ck * A.n_blocks / A.chunks);
-    // chunks <= n_blocks (host-checked), so every chunk is non-empty and wrote its tail
+    const int b0 = (int)((long long)ck * (A.n_blocks - 1) / A.chunks);
+    // chunks <= n_blocks - 1 (host-checked), so every chunk is non-empty and wrote its tail
     const float2 t = A.chunk_tails[(s * A.chunks + (ck - 1)) * (size_t)512 + i];
     float *out_l = A.out + s * A.out_stream_stride;
     float *out_r = out_l + A.out_ch_stride;
@@ -436,12 +466,29 @@ __global__ __launch_bounds__(256) void k_conv_p1_fixup(const ConvP1Args A)
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
 {
     const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
-    const long long waves = (long long)a.n_streams * a.chunks;
-    hipLaunchKernelGGL(k_conv_p1, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || a.chunks <= 1) return e;
-    const long long n = (long long)a.n_streams * (a.chunks - 1) * 512;
-    hipLaunchKernelGGL(k_conv_p1_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    hipError_t e = hipSuccess;
+    if (a.n_blocks > 1) {       // blocks [0, n_blocks - 1): `chunks` independent waves per stream
+        const long long waves = (long long)a.n_streams * a.chunks;
+        const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
+        static bool attr_done = false;      // > 64 KiB of dynamic LDS needs the opt-in attribute
+        if (!attr_done) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_p1),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_main);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_conv_p1, dim3((unsigned)((waves + kP1Waves - 1) / kP1Waves)), dim3(64 * kP1Waves),
+                           shmem_main, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (a.chunks > 1) {
+            const long long n = (long long)a.n_streams * (a.chunks - 1) * 512;
+            hipLaunchKernelGGL(k_conv_p1_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    }
+    hipLaunchKernelGGL(k_conv_p1_last, dim3((unsigned)((a.n_streams + 3) / 4)), dim3(256), shmem, st, a);
     return hipGetLastError();
 }
 

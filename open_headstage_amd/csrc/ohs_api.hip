@@ -239,8 +239,8 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             c.cd_valid = true;
         }
         // enough waves to fill 256 CUs x 8 resident waves a couple of times over
-        long long K = (4096 + (long long)c.S - 1) / (long long)c.S;
-        if (K > n_blocks) K = n_blocks;
+        long long K = (6144 + (long long)c.S - 1) / (long long)c.S;   // 256 CUs x 12 waves x 2 rounds
+        if (K > n_blocks - 1) K = n_blocks - 1;                        // the last block has its own kernel
         if (K < 1) K = 1;
         if ((size_t)K > c.chunk_tails_cap) {
             HIP_TRY(hipStreamSynchronize(st));

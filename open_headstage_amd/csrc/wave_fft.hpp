@@ -30,12 +30,14 @@ constexpr int kBlock = 512;
 constexpr int kFft = 1024;
 constexpr int kWaveLdsComplex = 16 * 68;   // per-wave LDS slab, in float2 units (8704 B)
 
-// twiddle tables kept in LDS per workgroup (float2 units)
+// twiddle tables kept in LDS per workgroup (float2 units); 17 KiB so that three 4-wave workgroups
+// (3 x (17 + 4 x 8.5) KiB) fit the 160 KiB of a CU
 constexpr int kTabA = 0;              // [16][64]  w1024^(m p)            lane m,  reg p   (forward)
-constexpr int kTabB = 16 * 64;        // [16][64]  w64^((L1&3) q)         lane L1, reg q   (forward)
-constexpr int kTabC = 32 * 64;        // [4][64]   w64^(c (L2>>2))        lane L2, reg c   (inverse, conj)
-constexpr int kTabD = 36 * 64;        // [16][64]  w1024^((4b+c) p)       lane L1, reg b   (inverse, conj)
-constexpr int kTabComplex = 52 * 64;  // 3328 float2 = 26 KiB
+constexpr int kTabD = 16 * 64;        // [16][64]  w1024^((4b+c) p)       lane L1, reg b   (inverse, conj)
+constexpr int kTabB = 32 * 64;        // [16][4]   w64^(c q)   index 4q + c: only 64 distinct values, the
+                                      //           lanes of a wave read 4 addresses (LDS broadcast)
+constexpr int kTabC = 32 * 64 + 64;   // [4][16]   w64^(c q)   index 16c + q (inverse, conj)
+constexpr int kTabComplex = 32 * 64 + 128;  // 2176 float2 = 17 KiB
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -141,13 +143,13 @@ inline void expand_twiddle_tables(const float2 *tw, float2 *expanded)
     for (int i = 0; i < 16 * 64; ++i) {
         const int r = i >> 6, l = i & 63;
         expanded[kTabA + i] = tw[(l * r) & 1023];                            // w1024^(m p)
-        expanded[kTabB + i] = tw[(16 * (l & 3) * r) & 1023];                 // w64^(c q)
         expanded[kTabD + i] = tw[((4 * r + (l & 3)) * (l >> 2)) & 1023];     // w1024^((4b+c) p)
     }
-    for (int i = 0; i < 4 * 64; ++i) {
-        const int c = i >> 6, l = i & 63;
-        expanded[kTabC + i] = tw[(16 * c * (l >> 2)) & 1023];                // w64^(c q)
-    }
+    for (int q = 0; q < 16; ++q)
+        for (int c = 0; c < 4; ++c) {
+            expanded[kTabB + 4 * q + c] = tw[(16 * c * q) & 1023];           // w64^(c q)
+            expanded[kTabC + 16 * c + q] = tw[(16 * c * q) & 1023];
+        }
 }
 
 __device__ __forceinline__ int t2_sigma(int q, int p_hi)
@@ -170,7 +172,7 @@ __device__ __forceinline__ void wave_fft_fwd(float2 (&v)[16], float2 *lds, const
     wave_lds_sync();
     dft16<false>(v);                                        // over b -> q
 #pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tab[kTabB + q * 64 + lane]);
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tab[kTabB + 4 * q + (lane & 3)]);
     const int p_lo = pp & 3, p_hi = pp >> 2;
     const int wbase = 65 * (4 * p_lo + c) + 16 * (p_hi & 1) + 8 * (p_hi >> 1);
 #pragma unroll
@@ -206,7 +208,7 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
-        const float2 w = tab[kTabC + c * 64 + lane];
+        const float2 w = tab[kTabC + 16 * c + (lane >> 2)];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
     }
