@@ -117,12 +117,16 @@ hipError_t launch_scale_copy(const float *src, float *dst, long long n, float ga
 
 // ---- EQ ------------------------------------------------------------------------
 // One pass of up to 16 cascaded DF2T bands (parametric_eq.rs:116-122,166-179).
+// Only ENABLED bands are handed to the kernel (a disabled band is the identity and keeps its state,
+// parametric_eq.rs:118-120), so lane j of a row is the j-th enabled band of this pass and `slot[j]` is
+// that band's index in the per-chain state array.
 struct EqPassTable {
     float b0[16], b1[16], b2[16], a1[16], a2[16];
-    int en[16];
+    int slot[16];
 };
+constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
 // chains = streams * 2 (L, R); chain c -> stream c>>1, channel c&1.
-// state: [chain][16][2] (s1, s2) for this pass.
+// state: [chain][kEqStateSlots][2] (s1, s2), indexed by the band's own index.
 // n_bands = bands of this pass (1..16, lanes >= n_bands are unused).
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
                           long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,

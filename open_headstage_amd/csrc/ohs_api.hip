@@ -348,8 +348,7 @@ struct EqState {
     size_t chains = 2;
     std::vector<float> coeffs;   // nb * 5  {b0,b1,b2,a1,a2}
     std::vector<int> en;         // nb
-    float *d_state = nullptr;    // [passes][chains][16][2]
-    int passes() const { return (int)((nb + 15) / 16); }
+    float *d_state = nullptr;    // [chains][kEqStateSlots][2], indexed by band
 };
 
 int rbj(int type, float fs, float fc, float q, float gain_db, float out[5]);
@@ -364,7 +363,7 @@ int eq_init(EqState &e, size_t nb, size_t chains, float fs, hipStream_t st)
     int rc = rbj(OHS_FILTER_PEAK, fs, 20.0f, 0.707f, 0.0f, c);   // parametric_eq.rs:63-76
     if (rc) return rc;
     for (size_t b = 0; b < nb; ++b) std::memcpy(&e.coeffs[5 * b], c, sizeof(c));
-    const size_t n = (size_t)std::max(1, e.passes()) * chains * 16 * 2;
+    const size_t n = chains * (size_t)kEqStateSlots * 2;
     HIP_TRY(hipMalloc(&e.d_state, n * sizeof(float)));
     HIP_TRY(hipMemsetAsync(e.d_state, 0, n * sizeof(float), st));
     return OHS_OK;
@@ -372,7 +371,7 @@ int eq_init(EqState &e, size_t nb, size_t chains, float fs, hipStream_t st)
 
 int eq_reset(EqState &e, hipStream_t st)
 {
-    const size_t n = (size_t)std::max(1, e.passes()) * e.chains * 16 * 2;
+    const size_t n = e.chains * (size_t)kEqStateSlots * 2;
     HIP_TRY(hipMemsetAsync(e.d_state, 0, n * sizeof(float), st));
     return OHS_OK;
 }
@@ -383,23 +382,24 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
 {
     bool did = false;
     const float *src = in;
-    for (int pass = 0; pass < e.passes(); ++pass) {
+    // enabled bands only, in cascade order, 16 per pass; a disabled band is the identity and keeps its
+    // state (parametric_eq.rs:118-120), so it is simply not given a lane
+    std::vector<size_t> on;
+    for (size_t b = 0; b < e.nb; ++b)
+        if (e.en[b]) on.push_back(b);
+    for (size_t p0 = 0; p0 < on.size(); p0 += 16) {
         EqPassTable t;
         std::memset(&t, 0, sizeof(t));
-        bool any = false;
-        int nbp = 0;
+        const int nbp = (int)std::min<size_t>(16, on.size() - p0);
         for (int j = 0; j < 16; ++j) {
-            const size_t b = (size_t)pass * 16 + j;
-            if (b >= e.nb) break;
-            nbp = j + 1;
-            t.b0[j] = e.coeffs[5 * b + 0]; t.b1[j] = e.coeffs[5 * b + 1]; t.b2[j] = e.coeffs[5 * b + 2];
-            t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
-            t.en[j] = e.en[b];
-            any = any || e.en[b];
+            const size_t b = on[p0 + (size_t)std::min(j, nbp - 1)];      // unused lanes shadow the last band's slot (never stored)
+            t.slot[j] = (int)b;
+            if (j < nbp) {
+                t.b0[j] = e.coeffs[5 * b + 0]; t.b1[j] = e.coeffs[5 * b + 1]; t.b2[j] = e.coeffs[5 * b + 2];
+                t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
+            }
         }
-        if (!any) continue;   // a pass of disabled bands is the identity, bit for bit (parametric_eq.rs:118-120)
-        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp,
-                                        e.d_state + (size_t)pass * e.chains * 16 * 2, st);
+        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
         did = true;

@@ -505,3 +505,18 @@ def test_real_hrirs_cipic_subject_003(ohs, synth, oracle):
     sofa.load_into(bp, irs)
     y = bp.process(torch.from_numpy(x[None].copy()).cuda()).cpu().numpy()[0]
     assert_parity(y, f, "CIPIC batch vs f64")
+
+
+@pytest.mark.parametrize("nb", [1, 5, 10, 16])
+def test_eq_sample_routing_identity_filters_on_a_ramp(ohs, nb):
+    """Routing check of the systolic EQ kernel (conveyor refills / drains at every chunk and group
+    boundary): identity bands (b0 = 1) must return the ramp exactly, for sizes around every boundary."""
+    eg = ohs.StereoParametricEQ.new(nb, 48000.0)
+    for i in range(nb):
+        eg.set_band_coeffs(i, [1.0, 0.0, 0.0, 0.0, 0.0], True)
+    for n in (127, 128, 129, 255, 256, 257, 300, 383, 384, 385, 400, 511, 512, 640, 1000, 2049):
+        l = np.arange(n, dtype=np.float32)
+        r = (100000.0 - np.arange(n)).astype(np.float32)
+        el, er = l.copy(), r.copy()
+        eg.process_block(l, r)
+        assert np.array_equal(l, el) and np.array_equal(r, er), (nb, n, np.nonzero(l != el)[0][:8])
