@@ -19,11 +19,13 @@ Operands: %[s1] %[s2] %[o] %[c] (in/out), %[n0..n7] (out: next group's inputs, l
 (An LDS-fed variant -- 7 VALU + 2 DS per step -- was measured at 60.8 cycles per step against 43.5 for
 this one: a lone wave pays ~16 cycles per DS instruction.  Rejected.)
 """
+import os
 import sys
 
 R = ["v102", "v104", "v106"]
 RP = ["v[102:103]", "v[104:105]", "v[106:107]"]
 STEPS = 128
+ORDER = os.environ.get("EQ_ORDER", "O A T Y C D N M P").split()   # 39.7 cycles per step; "O T NOP Y A C D N M P" 43.6 (tools/ubench_eq_order.hip)
 
 
 def gen(shr_nonzero: bool):
@@ -76,23 +78,32 @@ def gen(shr_nonzero: bool):
     for k in range(STEPS):
         i = k + 1
         boundary = i < STEPS and i % 16 == 0
-        e(O)
-        e(T)
         if i < STEPS:
-            e("s_nop 0")            # O wrote v100: second wait state before Y reads it through DPP
-            Y(i)
-            if boundary:
-                refill(i)           # the conveyor was drained 8 instructions ago (below)
-            e(A)
-            if boundary:
-                e("s_nop 3")        # refill -> C(i): DPP read after VALU write (A + 4 wait states)
-            C(i); D(i)
-            e(N)
-            M(i); P(i)
+            # per-step issue order (tokens O T A N belong to step k, Y C D M P to step k+1); constraints:
+            # Y needs 2 instructions after O (DPP read of v100), C after Y, D after C, M/P after D, N after A and T
+            for tok in ORDER:
+                if tok == "O": e(O)
+                elif tok == "T": e(T)
+                elif tok == "A": e(A)
+                elif tok == "N": e(N)
+                elif tok == "NOP": e("s_nop 0")
+                elif tok == "Y":
+                    Y(i)
+                    if boundary:
+                        refill(i)       # the conveyor was drained several instructions ago (below)
+                elif tok == "C":
+                    if boundary:
+                        e("s_nop 3")    # refill -> C(i): DPP read needs wait states after the VALU write
+                    C(i)
+                elif tok == "D": D(i)
+                elif tok == "M": M(i)
+                elif tok == "P": P(i)
             if (i + 1) < STEPS and (i + 1) % 16 == 0:
                 drain(i + 1)        # c_(i+1) = R[(i+1)%3] was completed by C(i) four instructions ago and is
                                     # refilled four instructions from now: clear of both ends
         else:
+            e(O)
+            e(T)
             e(A)
             e(N)
     cfinal = R[STEPS % 3]
