@@ -1283,9 +1283,12 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
     // The EQ is a serial recurrence (latency-bound, ~128 waves at 256 streams) and leaves most of the
     // chip idle, so the convolution of time chunk i runs on a second stream underneath the EQ of
     // chunk i+1.  Chunks touch disjoint frame ranges; state (EQ s1/s2, overlaps) chains per stream.
+    // Uneven chunks: only the LAST chunk's convolution is not hidden under an EQ launch, so it is short.
     const int nch = (b->overlap && n_blocks >= 64) ? 4 : 1;
+    static const double kCut[5] = {0.0, 0.34, 0.66, 0.92, 1.0};
     for (int i = 0; i < nch; ++i) {
-        const size_t blk0 = (size_t)i * n_blocks / nch, blk1 = (size_t)(i + 1) * n_blocks / nch;
+        const size_t blk0 = nch == 1 ? 0 : (size_t)(kCut[i] * (double)n_blocks);
+        const size_t blk1 = nch == 1 ? n_blocks : (i == nch - 1 ? n_blocks : (size_t)(kCut[i + 1] * (double)n_blocks));
         const size_t off = blk0 * BS;
         const int nb_i = (int)(blk1 - blk0);
         rc = span_begin(st, 0); if (rc) return rc;
