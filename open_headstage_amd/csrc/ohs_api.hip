@@ -45,6 +45,8 @@ int fail(int status, const std::string &msg)
 struct DeviceCtx {
     int device = -1;
     float2 *d_tw = nullptr;
+    int *d_pairs = nullptr;     // k_conv_tp_mac: leaders of the spectrum position pairs {b, mirror(b)}
+    int n_pairs = 0;
 };
 std::mutex g_ctx_mu;
 std::vector<DeviceCtx *> g_ctx;
@@ -82,6 +84,16 @@ int get_ctx(int device, DeviceCtx **out)
         hipFree(c->d_tw);
         delete c;
         return fail(OHS_ERR_HIP, "hipMemcpy(twiddles) failed");
+    }
+    {
+        int pairs[NF];
+        c->n_pairs = conv_tp_build_pairs(pairs);
+        if (hipMalloc(&c->d_pairs, NF * sizeof(int)) != hipSuccess ||
+            hipMemcpy(c->d_pairs, pairs, c->n_pairs * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(c->d_tw);
+            delete c;
+            return fail(OHS_ERR_HIP, "pair table upload failed");
+        }
     }
     g_ctx.push_back(c);
     *out = c;
@@ -326,6 +338,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 a.n_streams = (int)c.S; a.seg_blocks = seg; a.n_mac = seg; a.Ppad = Ppad;
                 a.CD = c.d_cdm; a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt + (unsigned long long)done;
                 a.W = c.d_W; a.W1 = c.d_W1; a.tails = c.d_tails; a.tails_out = c.d_tails_alt;
+                a.pairs = ctx->d_pairs; a.n_pairs = ctx->n_pairs;
                 a.tw = ctx->d_tw; a.gain = gain;
                 hipError_t e = launch_conv_tp_forward(a, st);
                 if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
