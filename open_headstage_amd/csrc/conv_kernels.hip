@@ -577,6 +577,10 @@ __device__ __forceinline__ int mirror_position(int b)
 // twice the accumulators: 256 VGPRs / 1 wave per SIMD, or spills at 128 -- 0.69 ms and 1.46 ms against
 // 0.25 ms for this form on config 4.)
 constexpr int kTB = 8;
+#ifndef OHS_MAC_PI
+#define OHS_MAC_PI 8
+#endif
+constexpr int kPI = OHS_MAC_PI;     // partitions per register window (Ppad is a multiple of 16, so 8 or 16)
 __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
@@ -591,23 +595,23 @@ __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 #pragma unroll
     for (int t = 0; t < kTB; ++t) acc[t] = make_float2(0.f, 0.f);
 
-    for (int i0 = 0; i0 < A.Ppad; i0 += 8) {
-        // window of blocks u = t - i, t in [0,8), i in [i0, i0+8): w = (t - i) + i0 + 7 in [0, 15)
-        float2 zw[15], zm[15];
+    for (int i0 = 0; i0 < A.Ppad; i0 += kPI) {
+        // window of blocks u = t - i, t in [0,TB), i in [i0, i0+PI): w = (t - i) + i0 + PI - 1 in [0, TB+PI-1)
+        float2 zw[kTB + kPI - 1], zm[kTB + kPI - 1];
 #pragma unroll
-        for (int w = 0; w < 15; ++w) {
-            const unsigned long long u = base + (unsigned long long)(long long)(w - 7 - i0);
+        for (int w = 0; w < kTB + kPI - 1; ++w) {
+            const unsigned long long u = base + (unsigned long long)(long long)(w - (kPI - 1) - i0);
             const float2 *hs = hist + (size_t)(u & mask) * kFft;
             zw[w] = hs[b];
             zm[w] = hs[mb];
         }
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) {
+        for (int ii = 0; ii < kPI; ++ii) {
             const float2 c = A.CD[((size_t)(i0 + ii) * 2 + 0) * kFft + b];
             const float2 d = A.CD[((size_t)(i0 + ii) * 2 + 1) * kFft + b];
 #pragma unroll
             for (int t = 0; t < kTB; ++t) {
-                const float2 z = zw[t - ii + 7], m = zm[t - ii + 7];
+                const float2 z = zw[t - ii + kPI - 1], m = zm[t - ii + kPI - 1];
                 acc[t].x += z.x * c.x - z.y * c.y + m.x * d.x + m.y * d.y;
                 acc[t].y += z.x * c.y + z.y * c.x + m.x * d.y - m.y * d.x;
             }

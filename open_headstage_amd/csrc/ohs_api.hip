@@ -101,7 +101,7 @@ int get_ctx(int device, DeviceCtx **out)
 }
 
 // the MAC reads up to Ppad - 1 blocks back (zero C/D beyond the real partition count)
-int Ppad_for_ring(int Pmax) { return (Pmax + 7) / 8 * 8; }
+int Ppad_for_ring(int Pmax) { return (Pmax + 15) / 16 * 16; }
 
 int next_pow2(int v)
 {
@@ -309,7 +309,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             const long long seg_max = std::min<long long>(SEG, n_blocks);
             int rc = conv_grow_ring(c, (int)(seg_max + Ppad_for_ring(Pmax) - 1), st);
             if (rc) return rc;
-            const int Ppad = (Pmax + 7) / 8 * 8;
+            const int Ppad = Ppad_for_ring(Pmax);
             if (!c.cdm_valid || c.cdm_ppad != Ppad) {
                 HIP_TRY(hipStreamSynchronize(st));
                 if (c.d_cdm) hipFree(c.d_cdm);
