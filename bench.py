@@ -216,8 +216,10 @@ def main() -> int:
         conv_name = "k_conv_p1" if TAPS <= 512 else "k_conv_general"
         # per LAUNCH (a step issues several launches of each kernel when EQ and convolution overlap):
         # (average launch ms, algorithmic bytes per launch, total ms per step)
+        # <= 12 enabled bands -> the ring form of the EQ kernel (eq_kernels.hip), else the conveyor form
+        eq_name = "k_eq_ring" if int(np.count_nonzero(enabled)) <= 12 else "k_eq_pass"
         kernels = {
-            "k_eq_pass": (eq_ms / max(eq_launches, 1), eq_b * n_calls / max(eq_launches, 1), eq_ms / max(n_calls, 1)),
+            eq_name: (eq_ms / max(eq_launches, 1), eq_b * n_calls / max(eq_launches, 1), eq_ms / max(n_calls, 1)),
             conv_name: (conv_ms / max(conv_launches, 1), conv_b * n_calls / max(conv_launches, 1),
                         conv_ms / max(n_calls, 1)),
         }
@@ -259,7 +261,7 @@ def main() -> int:
                 "traffic": load_traffic(dom),
                 "algorithmic_bytes_per_launch": int(dom_bytes),
                 "avg_launch_ms": round(dom_ms, 4),
-                "launches_per_step": {"k_eq_pass": eq_launches // max(n_calls, 1),
+                "launches_per_step": {eq_name: eq_launches // max(n_calls, 1),
                                       conv_name: conv_launches // max(n_calls, 1)},
                 "kernels_ms_per_step": {k: round(v[2], 4) for k, v in kernels.items()},
             },

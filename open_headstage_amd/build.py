@@ -39,7 +39,7 @@ def _hipcc() -> str:
 
 def _deps(src: str) -> list[str]:
     deps = [os.path.join(CSRC, src)]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "ohs_hip.h"))
     deps.append(os.path.abspath(__file__))
     return deps
