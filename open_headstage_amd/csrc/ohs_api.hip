@@ -1297,8 +1297,25 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
     // chip idle, so the convolution of time chunk i runs on a second stream underneath the EQ of
     // chunk i+1.  Chunks touch disjoint frame ranges; state (EQ s1/s2, overlaps) chains per stream.
     // Uneven chunks: only the LAST chunk's convolution is not hidden under an EQ launch, so it is short.
-    const int nch = (b->overlap && n_blocks >= 64) ? 4 : 1;
-    static const double kCut[5] = {0.0, 0.34, 0.66, 0.92, 1.0};
+    // OHS_OVERLAP_CUTS="0.3,0.6,0.9" overrides the interior cut points (tuning experiments).
+    static const std::vector<double> kCut = [] {
+        std::vector<double> c = {0.0, 0.34, 0.66, 0.92, 1.0};
+        if (const char *e = getenv("OHS_OVERLAP_CUTS")) {
+            std::vector<double> v = {0.0};
+            const char *p = e;
+            while (*p && v.size() < 16) {
+                char *end = nullptr;
+                const double x = strtod(p, &end);
+                if (end == p) break;
+                if (x > v.back() && x < 1.0) v.push_back(x);
+                p = (*end == ',') ? end + 1 : end;
+            }
+            v.push_back(1.0);
+            if (v.size() >= 3) c = v;
+        }
+        return c;
+    }();
+    const int nch = (b->overlap && n_blocks >= 64) ? (int)kCut.size() - 1 : 1;
     for (int i = 0; i < nch; ++i) {
         const size_t blk0 = nch == 1 ? 0 : (size_t)(kCut[i] * (double)n_blocks);
         const size_t blk1 = nch == 1 ? n_blocks : (i == nch - 1 ? n_blocks : (size_t)(kCut[i + 1] * (double)n_blocks));
