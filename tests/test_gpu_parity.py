@@ -413,9 +413,11 @@ def test_batch_small_block_counts_every_kernel_path(ohs, synth, oracle, taps, n_
     _batch_vs_oracle(ohs, synth, oracle, S=3, taps=taps, n_blocks=n_blocks, eq_on=False, calls=3)
 
 
-@pytest.mark.parametrize("nb", [1, 16, 17, 32])
+@pytest.mark.parametrize("nb", [1, 2, 4, 5, 8, 9, 11, 12, 13, 15, 16, 17, 28, 32])
 def test_eq_band_counts_bit_exact(ohs, synth, oracle, nb):
-    """16 bands = the full DPP row (no output shift), 17 / 32 = two passes, 1 = shift by 15."""
+    """<= 12 bands: ring kernel (12 = the last band's output lands in the I/O port bank); 13..16:
+    conveyor kernel (16 = the full DPP row, no output shift); 17 / 28 / 32 = two passes (16 + ring or
+    16 + conveyor)."""
     from open_headstage_amd import BandConfig, FilterType
     bands = [BandConfig(FilterType.Peak, 60.0 * (i + 1.5), 0.9 + 0.05 * i, (-1.0) ** i * (1.0 + 0.2 * i), True)
              for i in range(nb)]
@@ -507,7 +509,7 @@ def test_real_hrirs_cipic_subject_003(ohs, synth, oracle):
     assert_parity(y, f, "CIPIC batch vs f64")
 
 
-@pytest.mark.parametrize("nb", [1, 5, 10, 16])
+@pytest.mark.parametrize("nb", [1, 5, 10, 12, 13, 16])
 def test_eq_sample_routing_identity_filters_on_a_ramp(ohs, nb):
     """Routing check of the systolic EQ kernel (conveyor refills / drains at every chunk and group
     boundary): identity bands (b0 = 1) must return the ramp exactly, for sizes around every boundary."""
@@ -520,3 +522,29 @@ def test_eq_sample_routing_identity_filters_on_a_ramp(ohs, nb):
         el, er = l.copy(), r.copy()
         eg.process_block(l, r)
         assert np.array_equal(l, el) and np.array_equal(r, er), (nb, n, np.nonzero(l != el)[0][:8])
+
+
+def test_eq_ring_documented_edge_cases_signed_zero_and_non_finite_input(ohs, synth, oracle):
+    """the ring kernel's pass-on lanes run `1*x + 0` in the asm groups.  (a) A -0.0
+    sample may come out as +0.0: equal as numbers, every other sample bit-exact.  (b) A non-finite
+    input sample: the reference (and the oracle) is non-finite from that sample on; this kernel
+    may additionally lose up to 16 samples BEFORE it -- everything earlier is bit-exact."""
+    eg, eo = _mk_eqs(ohs, oracle, synth.eq_table())
+    n = 4096
+    x = synth.white_noise([12], n)[0]
+    x[:, 1000:1100] = -0.0
+    gl, gr = x[0].copy(), x[1].copy(); ol, orr = x[0].copy(), x[1].copy()
+    eg.process_block(gl, gr); eo.process_block(ol, orr)
+    assert np.array_equal(gl, ol) and np.array_equal(gr, orr)           # numeric equality (-0 == +0)
+    nz = ol != 0
+    assert np.array_equal(gl[nz].view(np.uint32), ol[nz].view(np.uint32))
+
+    eg, eo = _mk_eqs(ohs, oracle, synth.eq_table())
+    x = synth.white_noise([13], n)[0]
+    k = 2500
+    x[0, k] = np.nan
+    gl, gr = x[0].copy(), x[1].copy(); ol, orr = x[0].copy(), x[1].copy()
+    eg.process_block(gl, gr); eo.process_block(ol, orr)
+    assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32))      # the other channel is untouched
+    assert np.array_equal(gl[:k - 16].view(np.uint32), ol[:k - 16].view(np.uint32))
+    assert np.isnan(ol[k:]).all() and np.isnan(gl[k:]).all()
