@@ -1,0 +1,140 @@
+// conv_mac_kernels.hip -- long impulse responses: the spectral multiply-accumulate of the time-parallel
+// path.  Separate translation unit because it wants hipcc's SLP vectoriser (packed f32
+// MACs on pairs of accumulators), while the FFT kernels of conv_kernels.hip are built with
+// -fno-slp-vectorize: there the vectoriser pairs the real parts of two different complex values and
+// pays for it with ~30 % register moves (k_conv_p1: 168 -> 124 VGPRs, 0.97 -> 0.87 ms without it).
+#include "kernels.h"
+#include "wave_fft.hpp"
+
+namespace ohs {
+
+// position in the bin layout holding bin N-k of the bin held at position b
+__device__ __forceinline__ int mirror_position(int b)
+{
+    const int r = b >> 6, L = b & 63;
+    const int j = r & 3, q = r >> 2;
+    if (j) return (4 * (3 - q) + (4 - j)) * 64 + (63 - L);
+    if (L) return (4 * (3 - q)) * 64 + (64 - L);
+    return (4 * ((4 - q) & 3)) * 64;
+}
+
+// M: thread = one layout position; block = (quarter of the spectrum, 8-block time tile, stream).
+// (A variant with one thread per position PAIR {b, mirror(b)} halves the history reads but needs
+// twice the accumulators: 256 VGPRs / 1 wave per SIMD, or spills at 128 -- 0.69 ms and 1.46 ms against
+// 0.25 ms for this form on config 4.)
+constexpr int kTB = 8;
+#ifndef OHS_MAC_PI
+#define OHS_MAC_PI 8
+#endif
+constexpr int kPI = OHS_MAC_PI;     // partitions per register window (Ppad is a multiple of 16, so 8 or 16)
+__global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * kTB;
+    const size_t s = blockIdx.z;
+    const int mb = mirror_position(b);
+    const float2 *hist = A.hist + s * (size_t)A.cap * kFft;
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+    const unsigned long long base = A.cnt + (unsigned long long)t0;
+
+    float2 acc[kTB];
+#pragma unroll
+    for (int t = 0; t < kTB; ++t) acc[t] = make_float2(0.f, 0.f);
+
+    for (int i0 = 0; i0 < A.Ppad; i0 += kPI) {
+        // window of blocks u = t - i, t in [0,TB), i in [i0, i0+PI): w = (t - i) + i0 + PI - 1 in [0, TB+PI-1)
+        float2 zw[kTB + kPI - 1], zm[kTB + kPI - 1];
+#pragma unroll
+        for (int w = 0; w < kTB + kPI - 1; ++w) {
+            const unsigned long long u = base + (unsigned long long)(long long)(w - (kPI - 1) - i0);
+            const float2 *hs = hist + (size_t)(u & mask) * kFft;
+            zw[w] = hs[b];
+            zm[w] = hs[mb];
+        }
+#pragma unroll
+        for (int ii = 0; ii < kPI; ++ii) {
+            const float2 c = A.CD[((size_t)(i0 + ii) * 2 + 0) * kFft + b];
+            const float2 d = A.CD[((size_t)(i0 + ii) * 2 + 1) * kFft + b];
+#pragma unroll
+            for (int t = 0; t < kTB; ++t) {
+                const float2 z = zw[t - ii + kPI - 1], m = zm[t - ii + kPI - 1];
+                acc[t].x += z.x * c.x - z.y * c.y + m.x * d.x + m.y * d.y;
+                acc[t].y += z.x * c.y + z.y * c.x + m.x * d.y - m.y * d.x;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kTB; ++t)
+        if (t0 + t < A.n_mac) A.W[(s * (size_t)A.n_mac + (size_t)(t0 + t)) * kFft + b] = acc[t];
+}
+
+// The segment's LAST block additionally needs its L-speaker part W1 = sum_i X_l A_i, with
+// X_l = (Z + conj(Zm))/2 and A_i = H_lsl + j H_lsr = C_i + D_i, so that the four per-path overlaps of
+// the state at rest can be rebuilt (W2 = W - W1).  One block per stream: its own tiny kernel, so the
+// main MAC loop carries no per-iteration test for it (that test cost the main kernel 55 %).
+__global__ __launch_bounds__(256) void k_conv_tp_w1(const ConvTpArgs A)
+{
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (pi >= A.n_pairs) return;
+    const int b = A.pairs[pi];
+    const int mb = mirror_position(b);
+    const size_t s = blockIdx.y;
+    const float2 *hist = A.hist + s * (size_t)A.cap * kFft;
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+    const unsigned long long last = A.cnt + (unsigned long long)(A.n_mac - 1);
+    float2 acc1b = make_float2(0.f, 0.f), acc1m = make_float2(0.f, 0.f);
+    for (int i0 = 0; i0 < A.Ppad; i0 += 8) {       // Ppad is a multiple of 8: 48 loads in flight per step
+        float2 zz[8], mm[8], cbv[8], dbv[8], cmv[8], dmv[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            const float2 *hs = hist + (size_t)((last - (unsigned long long)i) & mask) * kFft;
+            zz[ii] = hs[b]; mm[ii] = hs[mb];
+            cbv[ii] = A.CD[((size_t)i * 2 + 0) * kFft + b]; dbv[ii] = A.CD[((size_t)i * 2 + 1) * kFft + b];
+            cmv[ii] = A.CD[((size_t)i * 2 + 0) * kFft + mb]; dmv[ii] = A.CD[((size_t)i * 2 + 1) * kFft + mb];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+        const float2 z = zz[ii], m = mm[ii], cb = cbv[ii], db = dbv[ii], cm = cmv[ii], dm = dmv[ii];
+        const float2 xlb = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+        const float2 ab = make_float2(cb.x + db.x, cb.y + db.y);
+        acc1b.x += xlb.x * ab.x - xlb.y * ab.y;
+        acc1b.y += xlb.x * ab.y + xlb.y * ab.x;
+        const float2 xlm = make_float2(0.5f * (m.x + z.x), 0.5f * (m.y - z.y));
+        const float2 am = make_float2(cm.x + dm.x, cm.y + dm.y);
+        acc1m.x += xlm.x * am.x - xlm.y * am.y;
+        acc1m.y += xlm.x * am.y + xlm.y * am.x;
+        }
+    }
+    A.W1[s * (size_t)kFft + b] = acc1b;
+    if (b != mb) A.W1[s * (size_t)kFft + mb] = acc1m;
+}
+
+hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
+{
+    if (a.n_mac <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_conv_tp_mac, dim3(kFft / 256, (a.n_mac + kTB - 1) / kTB, a.n_streams), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_conv_tp_w1, dim3((a.n_pairs + 255) / 256, a.n_streams), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// host helper: the leaders of the 514 position pairs {b, mirror(b)}, ordered so that consecutive
+// threads touch consecutive addresses as far as possible (ascending b)
+int conv_tp_build_pairs(int *out)
+{
+    int n = 0;
+    for (int b = 0; b < kFft; ++b) {
+        const int r = b >> 6, L = b & 63;
+        const int j = r & 3, q = r >> 2;
+        int mb;
+        if (j) mb = (4 * (3 - q) + (4 - j)) * 64 + (63 - L);
+        else if (L) mb = (4 * (3 - q)) * 64 + (64 - L);
+        else mb = (4 * ((4 - q) & 3)) * 64;
+        if (b <= mb) out[n++] = b;
+    }
+    return n;
+}
+
+}  // namespace ohs
