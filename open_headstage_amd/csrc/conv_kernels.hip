@@ -468,6 +468,8 @@ __global__ __launch_bounds__(256) void k_conv_p1_fixup(const ConvP1Args A)
     out_r[idx] += t.y * A.gain;
 }
 
+int conv_p1_waves_per_cu() { return kP1Waves; }
+
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
 {
     const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);

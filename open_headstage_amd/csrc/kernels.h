@@ -64,6 +64,7 @@ struct ConvP1Args {
     float gain;
 };
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
+int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)
 // CD[0][..] = (A - jB)/2, CD[1][..] = (A + jB)/2 from four single-partition spectra
 hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
                            float2 *cd, hipStream_t st);

@@ -47,6 +47,7 @@ struct DeviceCtx {
     float2 *d_tw = nullptr;
     int *d_pairs = nullptr;     // k_conv_tp_mac: leaders of the spectrum position pairs {b, mirror(b)}
     int n_pairs = 0;
+    int num_cus = 256;
 };
 std::mutex g_ctx_mu;
 std::vector<DeviceCtx *> g_ctx;
@@ -67,6 +68,11 @@ int get_ctx(int device, DeviceCtx **out)
     DeviceCtx *c = new (std::nothrow) DeviceCtx();
     if (!c) return fail(OHS_ERR_ALLOC, "out of host memory");
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            c->num_cus = cus;
+    }
     // tw[e] = exp(-2 pi i e / 1024), computed in f64 and rounded to f32 (as rustfft does)
     std::vector<float2> tw(NF);
     for (int k = 0; k < NF; ++k) {
@@ -250,8 +256,15 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("build_cd: ") + hipGetErrorString(e));
             c.cd_valid = true;
         }
-        // enough waves to fill 256 CUs x 8 resident waves a couple of times over
-        long long K = (6144 + (long long)c.S - 1) / (long long)c.S;   // 256 CUs x 12 waves x 2 rounds
+        // block ranges per stream: waves for exactly two full rounds of (CUs x resident waves per CU) --
+        // measured on config 3 without EQ: 1.7 rounds 0.847 ms, 2.0 rounds 0.794 ms, 2.5 rounds 0.892 ms
+        static const long long target_override = [] {
+            const char *e = getenv("OHS_P1_TARGET_WAVES");      // tuning experiments
+            return e ? atoll(e) : 0LL;
+        }();
+        const long long target_waves =
+            target_override > 0 ? target_override : 2LL * ctx->num_cus * conv_p1_waves_per_cu();
+        long long K = (target_waves + (long long)c.S - 1) / (long long)c.S;
         if (K > n_blocks - 1) K = n_blocks - 1;                        // the last block has its own kernel
         if (K < 1) K = 1;
         if ((size_t)K > c.chunk_tails_cap) {
