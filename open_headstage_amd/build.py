@@ -22,7 +22,8 @@ ARCH = "gfx950"
 # (source, extra flags)
 UNITS = [
     ("conv_kernels.hip", ["-fno-slp-vectorize"]),     # FFT kernels: see conv_mac_kernels.hip
-    ("conv_mac_kernels.hip", [f"-DOHS_MAC_PI={os.environ.get('OHS_MAC_PI', '8')}"]),
+    ("conv_mac_kernels.hip", [f"-DOHS_MAC_TB={os.environ.get('OHS_MAC_TB', '16')}",
+                              f"-DOHS_MAC_PI={os.environ.get('OHS_MAC_PI', '16')}"]),
     ("eq_kernels.hip", ["-ffp-contract=off"]),
     ("ohs_api.hip", []),
     ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver

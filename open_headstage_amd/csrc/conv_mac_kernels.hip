@@ -6,7 +6,24 @@
 #include "kernels.h"
 #include "wave_fft.hpp"
 
+#include <cstdlib>
+
 namespace ohs {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// acc += z * c + conj(m) * d on (re, im) register pairs: four v_pk_fma_f32, every swizzle and sign an
+// operand modifier (op_sel picks the half of a source for the low result, op_sel_hi for the high one).
+//   re += z.re c.re - z.im c.im + m.re d.re + m.im d.im ;  im += z.re c.im + z.im c.re + m.re d.im - m.im d.re
+// hipcc's own code for the same expression is 2.6 VALU instructions per FMA pair (separate multiplies
+// and adds plus register moves for the SLP pairing); this is 1.
+__device__ __forceinline__ void cmac_z_c_conjm_d(v2f &acc, v2f z, v2f c, v2f m, v2f d)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(z), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(z), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(m), "v"(d));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(acc) : "v"(m), "v"(d));
+}
 
 // position in the bin layout holding bin N-k of the bin held at position b
 __device__ __forceinline__ int mirror_position(int b)
@@ -18,54 +35,76 @@ __device__ __forceinline__ int mirror_position(int b)
     return (4 * ((4 - q) & 3)) * 64;
 }
 
-// M: thread = one layout position; block = (quarter of the spectrum, 8-block time tile, stream).
-// (A variant with one thread per position PAIR {b, mirror(b)} halves the history reads but needs
-// twice the accumulators: 256 VGPRs / 1 wave per SIMD, or spills at 128 -- 0.69 ms and 1.46 ms against
-// 0.25 ms for this form on config 4.)
-constexpr int kTB = 8;
+// M: thread = one layout position; workgroup = (quarter of the spectrum, TB-block time tile, stream).
+// Register tile: TB output blocks x PI partitions per window = TB*PI complex MAC pairs from
+// 2(TB+PI-1) history loads + 2 PI spectrum loads.  The kernel is bound by L2 -> L1 traffic (every load
+// is an L2 hit once the XCD mapping below is in place, L1 is far too small), so bigger tiles win until
+// registers run out -- config 4, whole convolution step:
+//   compiler-scheduled MAC, (TB,PI) = (8,8): 0.372 ms | explicit v_pk_fma_f32 (8,8): 0.334 | (8,16): 0.313
+//   (16,8): 0.286 | (16,16): 0.277 (137 VGPRs) | (32,8): 0.265 | (32,16): 0.256 (254 VGPRs)
+// (16,16) is the default: short segments (many streams) waste less of a tile than with TB = 32.
+// (A variant with one thread per position PAIR {b, mirror(b)} halves the history reads; with the
+// compiler-scheduled MAC it needed 256 VGPRs and ran at 0.69 ms.)
+#ifndef OHS_MAC_TB
+#define OHS_MAC_TB 16
+#endif
+constexpr int kTB = OHS_MAC_TB;     // output blocks per register tile
 #ifndef OHS_MAC_PI
-#define OHS_MAC_PI 8
+#define OHS_MAC_PI 16
 #endif
 constexpr int kPI = OHS_MAC_PI;     // partitions per register window (Ppad is a multiple of 16, so 8 or 16)
 __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const int t0 = blockIdx.y * kTB;
-    const size_t s = blockIdx.z;
+    // XCD-aware mapping.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own
+    // 4 MiB L2; all workgroups of one stream re-read that stream's history ring (P + n_mac spectra,
+    // 2.3 MiB on config 4), so a stream's workgroups are given ids that are congruent mod 8: its ring
+    // is then fetched into ONE L2 instead of eight.
+    const unsigned tiles = (unsigned)(A.mac_tiles < 0 ? -A.mac_tiles : A.mac_tiles);
+    const unsigned wps = (kFft / 256) * tiles;                  // workgroups per stream
+    size_t s;
+    unsigned widx;
+    if (A.mac_tiles > 0) {
+        const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        s = (size_t)(slot / wps) * 8 + xcd;
+        widx = slot % wps;
+    } else {                    // plain stream-major order (OHS_MAC_NO_XCD=1, for comparison)
+        s = blockIdx.x / wps;
+        widx = blockIdx.x % wps;
+    }
+    if (s >= (size_t)A.n_streams) return;
+    const int b = (int)(widx & (kFft / 256 - 1)) * 256 + threadIdx.x;
+    const int t0 = (int)(widx / (kFft / 256)) * kTB;
     const int mb = mirror_position(b);
     const float2 *hist = A.hist + s * (size_t)A.cap * kFft;
     const unsigned long long mask = (unsigned long long)(A.cap - 1);
     const unsigned long long base = A.cnt + (unsigned long long)t0;
 
-    float2 acc[kTB];
+    v2f acc[kTB];
 #pragma unroll
-    for (int t = 0; t < kTB; ++t) acc[t] = make_float2(0.f, 0.f);
+    for (int t = 0; t < kTB; ++t) acc[t] = (v2f){0.f, 0.f};
 
     for (int i0 = 0; i0 < A.Ppad; i0 += kPI) {
         // window of blocks u = t - i, t in [0,TB), i in [i0, i0+PI): w = (t - i) + i0 + PI - 1 in [0, TB+PI-1)
-        float2 zw[kTB + kPI - 1], zm[kTB + kPI - 1];
+        v2f zw[kTB + kPI - 1], zm[kTB + kPI - 1];
 #pragma unroll
         for (int w = 0; w < kTB + kPI - 1; ++w) {
             const unsigned long long u = base + (unsigned long long)(long long)(w - (kPI - 1) - i0);
-            const float2 *hs = hist + (size_t)(u & mask) * kFft;
+            const v2f *hs = reinterpret_cast<const v2f *>(hist + (size_t)(u & mask) * kFft);
             zw[w] = hs[b];
             zm[w] = hs[mb];
         }
 #pragma unroll
         for (int ii = 0; ii < kPI; ++ii) {
-            const float2 c = A.CD[((size_t)(i0 + ii) * 2 + 0) * kFft + b];
-            const float2 d = A.CD[((size_t)(i0 + ii) * 2 + 1) * kFft + b];
+            const v2f c = reinterpret_cast<const v2f *>(A.CD)[((size_t)(i0 + ii) * 2 + 0) * kFft + b];
+            const v2f d = reinterpret_cast<const v2f *>(A.CD)[((size_t)(i0 + ii) * 2 + 1) * kFft + b];
 #pragma unroll
-            for (int t = 0; t < kTB; ++t) {
-                const float2 z = zw[t - ii + kPI - 1], m = zm[t - ii + kPI - 1];
-                acc[t].x += z.x * c.x - z.y * c.y + m.x * d.x + m.y * d.y;
-                acc[t].y += z.x * c.y + z.y * c.x + m.x * d.y - m.y * d.x;
-            }
+            for (int t = 0; t < kTB; ++t) cmac_z_c_conjm_d(acc[t], zw[t - ii + kPI - 1], c, zm[t - ii + kPI - 1], d);
         }
     }
 #pragma unroll
     for (int t = 0; t < kTB; ++t)
-        if (t0 + t < A.n_mac) A.W[(s * (size_t)A.n_mac + (size_t)(t0 + t)) * kFft + b] = acc[t];
+        if (t0 + t < A.n_mac)
+            reinterpret_cast<v2f *>(A.W)[(s * (size_t)A.n_mac + (size_t)(t0 + t)) * kFft + b] = acc[t];
 }
 
 // The segment's LAST block additionally needs its L-speaker part W1 = sum_i X_l A_i, with
@@ -113,7 +152,13 @@ __global__ __launch_bounds__(256) void k_conv_tp_w1(const ConvTpArgs A)
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
 {
     if (a.n_mac <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_conv_tp_mac, dim3(kFft / 256, (a.n_mac + kTB - 1) / kTB, a.n_streams), dim3(256), 0, st, a);
+    ConvTpArgs m = a;
+    m.mac_tiles = (a.n_mac + kTB - 1) / kTB;
+    const unsigned wps = (unsigned)(kFft / 256) * (unsigned)m.mac_tiles;
+    const unsigned groups = ((unsigned)a.n_streams + 7u) / 8u;
+    const bool xcd_map = getenv("OHS_MAC_NO_XCD") == nullptr;       // tuning experiments
+    if (!xcd_map) m.mac_tiles = -m.mac_tiles;
+    hipLaunchKernelGGL(k_conv_tp_mac, dim3(groups * 8u * wps), dim3(256), 0, st, m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_conv_tp_w1, dim3((a.n_pairs + 255) / 256, a.n_streams), dim3(256), 0, st, a);

@@ -88,6 +88,7 @@ struct ConvTpArgs {
     unsigned long long cnt;     // absolute index of the segment's first block
     const int *pairs;           // leaders b of the 514 position pairs {b, mirror(b)} (device)
     int n_pairs;
+    int mac_tiles;              // set by launch_conv_tp_mac: 8-block time tiles per stream
     float2 *W;                  // [stream][n_mac][1024] scratch
     float2 *W1;                 // [stream][1024]: L-speaker part (lsl + j lsr) of the LAST block's spectrum
     const float2 *tails;        // state in (sum of the two packed tails feeds block 0)
