@@ -45,22 +45,52 @@ def run_batch(name, S, taps, frames, eq_on, steps=5, warmup=2):
                       "conv_model_GBps": round(cb / (conv_ms / n * 1e-3) / 1e9, 1)}), flush=True)
 
 
-def run_engine_c2(calls=200):
-    """C2: one stream, 1024-frame host blocks through the blocking engine API (PCIe + launches)."""
+def _per_call(fn, items):
+    ts = []
+    for it in items:
+        t0 = time.perf_counter()
+        fn(*it)
+        ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e6
+    return {"median": round(float(np.median(ts)), 1), "mean": round(float(ts.mean()), 1),
+            "p99": round(float(np.percentile(ts, 99)), 1), "max": round(float(ts.max()), 1)}
+
+
+def run_engine_c2(calls=400, n=1024):
+    """C2: one stream, 1024-frame host blocks through the blocking C ABI (host buffers in, host buffers
+    out), per-call latency in microseconds: the convolution engine alone, the EQ alone, and the whole
+    lib.rs:1169-1207 chain (coefficient refresh excluded)."""
     e = ohs.ConvolutionEngine.new()
     irs = synth.hrir_set(512)
     for p in range(4):
         e.set_ir(p, irs[p])
-    x = synth.white_noise([0], 1024 * calls)[0]
-    ol = np.empty(1024, np.float32); orr = np.empty(1024, np.float32)
-    for c in range(10):
-        e.process_block(x[0, c * 1024:(c + 1) * 1024], x[1, c * 1024:(c + 1) * 1024], ol, orr)
-    t0 = time.perf_counter()
-    for c in range(calls):
-        e.process_block(x[0, c * 1024:(c + 1) * 1024], x[1, c * 1024:(c + 1) * 1024], ol, orr)
-    dt = (time.perf_counter() - t0) / calls
-    print(json.dumps({"config": "c2_engine_1024_blocking", "us_per_call": round(dt * 1e6, 1),
-                      "x_realtime": round(1024 / dt / 48000.0, 0)}), flush=True)
+    bands = synth.eq_table()
+    eq = ohs.StereoParametricEQ.new(len(bands), synth.FS)
+    for i, b in enumerate(bands):
+        eq.update_band_coeffs(i, synth.FS, b)
+    x = synth.white_noise([0], n * (calls + 20))[0]
+    ol = np.empty(n, np.float32); orr = np.empty(n, np.float32)
+
+    def blocks():
+        return [(x[0, c * n:(c + 1) * n].copy(), x[1, c * n:(c + 1) * n].copy()) for c in range(calls + 20)]
+
+    bl = blocks()
+    for l, r in bl[:20]:
+        e.process_block(l, r, ol, orr)
+    st = _per_call(lambda l, r: e.process_block(l, r, ol, orr), bl[20:])
+    print(json.dumps({"config": f"c2_engine_{n}_blocking", "us_per_call": st["median"], "latency_us": st,
+                      "x_realtime": round(n / (st["median"] * 1e-6) / 48000.0, 0)}), flush=True)
+    bl = blocks()
+    for l, r in bl[:20]:
+        eq.process_block(l, r)
+    st = _per_call(lambda l, r: eq.process_block(l, r), bl[20:])
+    print(json.dumps({"config": f"c2_eq_only_{n}_blocking", "us_per_call": st["median"], "latency_us": st}), flush=True)
+    bl = blocks()
+    for l, r in bl[:20]:
+        ohs.process_chain(e, eq, l, r, eq_enable=True, output_gain=0.9)
+    st = _per_call(lambda l, r: ohs.process_chain(e, eq, l, r, eq_enable=True, output_gain=0.9), bl[20:])
+    print(json.dumps({"config": f"c2_chain_eq_conv_gain_{n}_blocking", "us_per_call": st["median"], "latency_us": st,
+                      "x_realtime": round(n / (st["median"] * 1e-6) / 48000.0, 0)}), flush=True)
 
 
 if __name__ == "__main__":
