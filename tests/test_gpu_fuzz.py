@@ -1,0 +1,149 @@
+"""Randomised operation sequences: the HIP path (C ABI) against the CPU oracle, call by call.
+
+The fixed-case parity tests pin each kernel path; these sequences mix them the way a host would --
+ragged host blocks, impulse responses replaced in mid-stream (per path, different lengths), EQ bands
+retuned / toggled / reset between calls, engine clones -- so that every hand-over of state between the
+single-launch engine call, the general kernel, the one-partition fast path, the time-parallel long-IR
+path and the two EQ kernels gets exercised.  Bars as in test_gpu_parity.py: EQ bit-exact, everything that
+passes through an FFT <= 1e-6 RMS (absolute and relative) against the oracle.
+"""
+import numpy as np
+import pytest
+
+from tests.util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ohs():
+    import open_headstage_amd
+    return open_headstage_amd
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from open_headstage_amd import synth
+    return synth
+
+
+def _random_ir(rng, taps):
+    """Decaying noise burst after a short delay, L1 norm 0.45 (two paths per ear keep |y| <= 0.9 |x|)."""
+    if taps == 0:
+        return np.zeros(0, np.float32)
+    h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / max(taps / 5.0, 1.0))
+    h[min(int(rng.integers(0, 40)), taps - 1)] += 2.0
+    return (0.45 * h / np.abs(h).sum()).astype(np.float32)
+
+
+def _random_band(ohs, rng):
+    from open_headstage_amd import BandConfig, FilterType
+    return BandConfig(FilterType(int(rng.integers(0, 8))), float(np.exp(rng.uniform(np.log(30.0), np.log(18000.0)))),
+                      float(rng.uniform(0.3, 3.0)), float(rng.uniform(-6.0, 6.0)), bool(rng.random() < 0.8))
+
+
+def _sync_band(qg, qo, i):
+    c, en = qg.get_band_coeffs(i)          # the oracle is fed the SAME coefficient bits
+    qo.set_band_coeffs(i, c, en)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    eg, eo = ohs.ConvolutionEngine.new(), oracle.ConvolutionEngine()
+    nb = int(rng.choice([3, 10, 12, 14, 20]))       # ring kernel, conveyor kernel, two passes
+    qg, qo = ohs.StereoParametricEQ.new(nb, synth.FS), oracle.StereoParametricEQ(nb, synth.FS)
+    for i in range(nb):
+        qg.update_band_coeffs(i, synth.FS, _random_band(ohs, rng))
+        _sync_band(qg, qo, i)
+    for p in range(4):
+        h = _random_ir(rng, int(rng.choice([64, 512, 700])))
+        eg.set_ir(p, h); eo.set_ir(p, h)
+    sizes = [1, 7, 64, 511, 512, 513, 1024, 1024, 1024, 1500, 2048, 3000, 4096, 9000]
+    stream = synth.white_noise([200 + seed], 120000)[0]
+    pos = 0
+    got, ref = [], []
+    for step in range(45):
+        op = rng.random()
+        if op < 0.62:                   # the lib.rs:1169-1207 chain on one host block
+            n = int(rng.choice(sizes))
+            l, r = stream[0, pos:pos + n].copy(), stream[1, pos:pos + n].copy()
+            pos += n
+            ol, orr = l.copy(), r.copy()
+            eq_on = bool(rng.random() < 0.7)
+            gain = float(np.float32(rng.uniform(0.2, 1.0)))
+            ohs.process_chain(eg, qg, l, r, eq_enable=eq_on, output_gain=gain)
+            oracle.chain_process(eo, qo, ol, orr, eq_enable=eq_on, gain=gain)
+            got.append(np.stack([l, r])); ref.append(np.stack([ol, orr]))
+            assert np.abs(got[-1] - ref[-1]).max() < 2e-5, (seed, step, n)
+        elif op < 0.70:                 # EQ alone: bit-exact
+            n = int(rng.choice(sizes))
+            l, r = stream[0, pos:pos + n].copy(), stream[1, pos:pos + n].copy()
+            pos += n
+            ol, orr = l.copy(), r.copy()
+            qg.process_block(l, r); qo.process_block(ol, orr)
+            assert np.array_equal(l.view(np.uint32), ol.view(np.uint32)), (seed, step, n)
+            assert np.array_equal(r.view(np.uint32), orr.view(np.uint32)), (seed, step, n)
+        elif op < 0.80:                 # one path gets a new impulse response (set_ir resets that path only)
+            p = int(rng.integers(0, 4))
+            h = _random_ir(rng, int(rng.choice([0, 1, 100, 512, 513, 1500, 2048])))
+            eg.set_ir(p, h); eo.set_ir(p, h)
+        elif op < 0.90:                 # retune / toggle a band (state is kept: parametric_eq.rs:112)
+            i = int(rng.integers(0, nb))
+            qg.update_band_coeffs(i, synth.FS, _random_band(ohs, rng))
+            _sync_band(qg, qo, i)
+        elif op < 0.95:
+            qg.reset_all_bands_state(); qo.reset_all_bands_state()
+        else:                           # continue on deep copies
+            eg, eo = eg.clone(), eo.clone()
+    if got:
+        assert_parity(np.concatenate(got, 1), np.concatenate(ref, 1), f"fuzz chain seed {seed}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_batch(ohs, synth, oracle, seed):
+    import torch
+    rng = np.random.default_rng(2000 + seed)
+    S = int(rng.integers(1, 6))
+    bands = synth.eq_table()
+    bp = ohs.BatchProcessor(S, num_bands=len(bands))
+    eos = [oracle.ConvolutionEngine() for _ in range(S)]
+    qos = [oracle.StereoParametricEQ(len(bands), synth.FS) for _ in range(S)]
+    for i, b in enumerate(bands):
+        bp.update_band_coeffs(i, synth.FS, b)
+        c = ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db)
+        for q in qos:
+            q.set_band_coeffs(i, c, b.enabled)
+    long_ir = bool(seed % 2)            # odd seeds: partitions > 1 (general + time-parallel kernels)
+    lengths = [300, 512, 2000, 5000] if long_ir else [64, 300, 512]
+    for p in range(4):
+        h = _random_ir(rng, int(rng.choice(lengths)))
+        bp.set_ir(p, h)
+        for e in eos:
+            e.set_ir(p, h)
+    x = synth.white_noise(range(300 + 10 * seed, 300 + 10 * seed + S), 512 * 400)
+    pos = 0
+    got, ref = [], []
+    for call in range(9):
+        if call and rng.random() < 0.35:    # mid-stream: one path replaced -> per-path gating in the general kernel
+            p = int(rng.integers(0, 4))
+            h = _random_ir(rng, int(rng.choice(lengths + [0])))
+            bp.set_ir(p, h)
+            for e in eos:
+                e.set_ir(p, h)
+        eq_on = bool(rng.random() < 0.6)
+        gain = float(np.float32(rng.uniform(0.3, 1.0)))
+        bp.set_eq_enabled(eq_on); bp.set_gain(gain)
+        nblk = int(rng.choice([1, 2, 3, 5, 9, 17, 40, 70]))
+        n = nblk * 512
+        xt = torch.from_numpy(np.ascontiguousarray(x[:, :, pos:pos + n])).cuda()
+        y = bp.process(xt).cpu().numpy()
+        o = np.empty_like(y)
+        for s in range(S):
+            l, r = x[s, 0, pos:pos + n].copy(), x[s, 1, pos:pos + n].copy()
+            oracle.chain_process(eos[s], qos[s], l, r, eq_enable=eq_on, gain=gain)
+            o[s, 0], o[s, 1] = l, r
+        pos += n
+        assert np.abs(y - o).max() < 2e-5, (seed, call, nblk)
+        got.append(y); ref.append(o)
+    assert_parity(np.concatenate(got, 2), np.concatenate(ref, 2), f"fuzz batch seed {seed}")
