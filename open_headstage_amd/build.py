@@ -27,6 +27,8 @@ UNITS = [
     ("eq_kernels.hip", ["-ffp-contract=off"]),
     ("ohs_api.hip", []),
     ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
+    ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
+    ("biquad_coeffs.cpp", ["-x", "hip"]),   # host-only C++ (RBJ coefficient formulas)
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-value", "-Wno-unused-result"]

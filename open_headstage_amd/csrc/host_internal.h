@@ -1,0 +1,13 @@
+// host_internal.h -- host-side helpers shared between the translation units of libohs_hip.so (not part
+// of the public header).
+#pragma once
+
+extern "C" void ohs_internal_set_error(const char *msg);     // ohs_api.hip: feeds ohs_last_error()
+
+namespace ohs_host {
+
+// biquad 0.4.2 Coefficients::<f32>::from_params restated; out = {b0, b1, b2, a1, a2} / a0.
+// Returns an OHS_* status (OHS_ERR_OUTSIDE_NYQUIST, OHS_ERR_NEGATIVE_Q, OHS_ERR_INVALID_ARG).
+int rbj(int type, float fs, float fc, float q, float gain_db, float out[5]);
+
+}  // namespace ohs_host
