@@ -13,7 +13,22 @@
 #include "kernels.h"
 #include "wave_fft.hpp"
 
+#include <atomic>
+
 namespace ohs {
+
+// > 64 KiB of dynamic LDS needs an opt-in function attribute, per device.
+static hipError_t allow_large_lds(const void *fn, size_t bytes, std::atomic<unsigned long long> &done_mask)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done_mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // ---------------------------------------------------------------------------------
 // IR partition spectra (set_ir, convolution.rs:120-132)
@@ -93,6 +108,72 @@ struct EngineIO {
     }
 };
 
+// ---- the three per-block pieces of convolve_path_partitioned, shared by the sequential general body and
+// the one-wave-per-block engine call ----
+
+// (1) inputs of block t -> packed spectrum Z = FFT(x_l + j x_r)  (convolution.rs:245-255)
+template <class IO>
+__device__ __forceinline__ void block_forward(const IO &io, int t, float2 (&v)[16], float2 *lds, const float2 *tab,
+                                              int lane)
+{
+#pragma unroll
+    for (int a = 0; a < 8; ++a) v[a] = io.load((size_t)t * kBlock + 64 * a + lane);
+#pragma unroll
+    for (int a = 8; a < 16; ++a) v[a] = make_float2(0.0f, 0.0f);   // zero pad (:248-254)
+    wave_fft_fwd(v, lds, tab, lane);
+}
+
+// (2) history[history_index] = spectrum (:258); one packed ring per stream
+__device__ __forceinline__ void block_store_history(const ConvGeneralArgs &A, float2 *hist, int t,
+                                                    const float2 (&v)[16], int lane)
+{
+    float2 *hs = hist + ((A.cnt + (unsigned long long)t) & (unsigned long long)(A.cap - 1)) * kFft;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hs[r * 64 + lane] = v[r];
+}
+
+// (3) partitions, newest block with partition 0 (:261-273): acc1 = lsl + j lsr, acc2 = rsl + j rsr spectra
+__device__ __forceinline__ void block_mac(const ConvGeneralArgs &A, const float2 *hist, int t, int maxP,
+                                          const float2 (&v)[16], float2 (&acc1)[16], float2 (&acc2)[16], int lane)
+{
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = make_float2(0.f, 0.f); acc2[r] = make_float2(0.f, 0.f); }
+    for (int i = 0; i < maxP; ++i) {
+        // path p sees block (t - i) only if that block was processed after p's last set_ir
+        const bool g0 = i < A.P[0] && (long long)i <= A.since[0] + t;
+        const bool g1 = i < A.P[1] && (long long)i <= A.since[1] + t;
+        const bool g2 = i < A.P[2] && (long long)i <= A.since[2] + t;
+        const bool g3 = i < A.P[3] && (long long)i <= A.since[3] + t;
+        if (!(g0 || g1 || g2 || g3)) continue;
+
+        float2 zi[16], zm[16];
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zi[r] = v[r];
+        } else {
+            const float2 *hs = hist + ((A.cnt + (unsigned long long)t - (unsigned long long)i) & mask) * kFft;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zi[r] = hs[r * 64 + lane];
+        }
+        wave_mirror(zi, zm, lane);
+        const float2 *h0 = A.H[0] + (size_t)i * kFft;
+        const float2 *h1 = A.H[1] + (size_t)i * kFft;
+        const float2 *h2 = A.H[2] + (size_t)i * kFft;
+        const float2 *h3 = A.H[3] + (size_t)i * kFft;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // X_l = (Z + conj(Zm))/2 ; X_r = -j (Z - conj(Zm))/2
+            const float2 xl = make_float2(0.5f * (zi[r].x + zm[r].x), 0.5f * (zi[r].y - zm[r].y));
+            const float2 xr = make_float2(0.5f * (zi[r].y + zm[r].y), -0.5f * (zi[r].x - zm[r].x));
+            if (g0) { const float2 y = cmul(xl, h0[r * 64 + lane]); acc1[r].x += y.x; acc1[r].y += y.y; }
+            if (g1) { const float2 y = cmul(xl, h1[r * 64 + lane]); acc1[r].x -= y.y; acc1[r].y += y.x; }
+            if (g2) { const float2 y = cmul(xr, h2[r * 64 + lane]); acc2[r].x += y.x; acc2[r].y += y.y; }
+            if (g3) { const float2 y = cmul(xr, h3[r * 64 + lane]); acc2[r].x -= y.y; acc2[r].y += y.x; }
+        }
+    }
+}
+
 template <class IO>
 __device__ __forceinline__ void conv_general_body(const ConvGeneralArgs &A, const IO &io, float2 *tab, float2 *lds,
                                                   int lane, size_t s)
@@ -110,66 +191,14 @@ __device__ __forceinline__ void conv_general_body(const ConvGeneralArgs &A, cons
     int maxP = A.P[0];
 #pragma unroll
     for (int p = 1; p < 4; ++p) maxP = A.P[p] > maxP ? A.P[p] : maxP;
-    const unsigned long long mask = (unsigned long long)(A.cap - 1);
     const float scale = 1.0f / (float)kFft;   // convolution.rs:280
 
     for (int t = 0; t < A.n_blocks; ++t) {
         float2 v[16];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-            v[a] = io.load(idx);
-        }
-#pragma unroll
-        for (int a = 8; a < 16; ++a) v[a] = make_float2(0.0f, 0.0f);   // zero pad (:248-254)
-        wave_fft_fwd(v, lds, tab, lane);
-
-        // history[history_index] = spectrum (:258); one packed ring per stream
-        {
-            float2 *hs = hist + ((A.cnt + (unsigned long long)t) & mask) * kFft;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hs[r * 64 + lane] = v[r];
-        }
-
+        block_forward(io, t, v, lds, tab, lane);
+        block_store_history(A, hist, t, v, lane);
         float2 acc1[16], acc2[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc1[r] = make_float2(0.f, 0.f); acc2[r] = make_float2(0.f, 0.f); }
-
-        // partitions, newest block with partition 0 (:261-273)
-        for (int i = 0; i < maxP; ++i) {
-            // path p sees block (t - i) only if that block was processed after p's last set_ir
-            const bool g0 = i < A.P[0] && (long long)i <= A.since[0] + t;
-            const bool g1 = i < A.P[1] && (long long)i <= A.since[1] + t;
-            const bool g2 = i < A.P[2] && (long long)i <= A.since[2] + t;
-            const bool g3 = i < A.P[3] && (long long)i <= A.since[3] + t;
-            if (!(g0 || g1 || g2 || g3)) continue;
-
-            float2 zi[16], zm[16];
-            if (i == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zi[r] = v[r];
-            } else {
-                const float2 *hs =
-                    hist + ((A.cnt + (unsigned long long)t - (unsigned long long)i) & mask) * kFft;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zi[r] = hs[r * 64 + lane];
-            }
-            wave_mirror(zi, zm, lane);
-            const float2 *h0 = A.H[0] + (size_t)i * kFft;
-            const float2 *h1 = A.H[1] + (size_t)i * kFft;
-            const float2 *h2 = A.H[2] + (size_t)i * kFft;
-            const float2 *h3 = A.H[3] + (size_t)i * kFft;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // X_l = (Z + conj(Zm))/2 ; X_r = -j (Z - conj(Zm))/2
-                const float2 xl = make_float2(0.5f * (zi[r].x + zm[r].x), 0.5f * (zi[r].y - zm[r].y));
-                const float2 xr = make_float2(0.5f * (zi[r].y + zm[r].y), -0.5f * (zi[r].x - zm[r].x));
-                if (g0) { const float2 y = cmul(xl, h0[r * 64 + lane]); acc1[r].x += y.x; acc1[r].y += y.y; }
-                if (g1) { const float2 y = cmul(xl, h1[r * 64 + lane]); acc1[r].x -= y.y; acc1[r].y += y.x; }
-                if (g2) { const float2 y = cmul(xr, h2[r * 64 + lane]); acc2[r].x += y.x; acc2[r].y += y.y; }
-                if (g3) { const float2 y = cmul(xr, h3[r * 64 + lane]); acc2[r].x -= y.y; acc2[r].y += y.x; }
-            }
-        }
+        block_mac(A, hist, t, maxP, v, acc1, acc2, lane);
 
         wave_fft_inv(acc1, lds, tab, lane);   // re = lsl, im = lsr   (:276)
         wave_fft_inv(acc2, lds, tab, lane);   // re = rsl, im = rsr
@@ -207,17 +236,19 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
     conv_general_body(A, io, tab, lds, lane, blockIdx.x);
 }
 
-// One launch = one ConvolutionEngine::process_block call for a single stream (f2).
-__global__ __launch_bounds__(64) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E)
+// One launch = one ConvolutionEngine::process_block call for a single stream (f2).  One WAVE PER BLOCK:
+// the k <= 8 internal blocks of a call only couple through the history ring (P > 1) and the 512-sample
+// overlap tails, so they run side by side and exchange those through memory / LDS at two barriers --
+// the call's latency is one block's (forward FFT, MAC, two inverse FFTs), not k of them.
+__global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
-    float2 *lds = smem + kTabComplex;
-    const int lane = threadIdx.x;
-    fill_twiddle_tables(tab, A.tw, lane, 64);
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, blockDim.x);
     // 1. frames already waiting in the output FIFO: pop what this call takes, slide the rest down
-    if (E.out_len > 0 && E.emit) {
+    if (wave == 0 && E.out_len > 0 && E.emit) {
         const int take = E.out_len < E.n ? E.out_len : E.n;
         for (int i = lane; i < take; i += 64) {
             E.host_l[i] = E.out_fifo[i] * E.gain_pop;
@@ -230,25 +261,68 @@ __global__ __launch_bounds__(64) void k_engine_call(const ConvGeneralArgs A, con
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (i < E.out_len) { E.out_fifo[i - E.n] = l; E.out_fifo[E.out_cap + i - E.n] = r; }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // 2. every complete 512-block (convolution.rs:152-161)
+    __syncthreads();
+    // 2. every complete 512-block (convolution.rs:152-161), block t = wave
     EngineIO io;
     io.E = E;
-    if (A.n_blocks > 0) conv_general_body(A, io, tab, lds, lane, 0);
-    // 3. what is left of the input (< 512 frames) becomes the FIFO content for the next call
-    const int consumed = A.n_blocks * kBlock;
-    const int rem = E.in_len + E.n - consumed;
-    if (A.n_blocks == 0) {
-        for (int i = lane; i < E.n; i += 64) {
-            E.in_fifo[E.in_len + i] = E.src_l[i];
-            E.in_fifo[E.in_cap + E.in_len + i] = E.src_r[i];
+    const int t = wave;
+    const bool active = t < A.n_blocks;
+    float2 *hist = A.hist;
+    int maxP = A.P[0];
+#pragma unroll
+    for (int p = 1; p < 4; ++p) maxP = A.P[p] > maxP ? A.P[p] : maxP;
+    float2 v[16], acc1[16], acc2[16];
+    if (active) {
+        block_forward(io, t, v, lds, tab, lane);
+        block_store_history(A, hist, t, v, lane);
+    }
+    __threadfence_block();      // the ring slots written above are read by the other waves' partitions
+    __syncthreads();            // (also: every input frame has been read before step 3 rewrites the FIFO)
+    const float scale = 1.0f / (float)kFft;   // convolution.rs:280
+    if (active) {
+        block_mac(A, hist, t, maxP, v, acc1, acc2, lane);
+        wave_fft_inv(acc1, lds, tab, lane);   // re = lsl, im = lsr   (:276)
+        wave_fft_inv(acc2, lds, tab, lane);   // re = rsl, im = rsr
+        // this block's overlaps (upper halves) into its own slab, for the next block's wave
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            lds[a * 64 + lane] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
+            lds[(8 + a) * 64 + lane] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
         }
-    } else {
-        // in_len < 512 <= consumed: the remainder lies entirely in this call's new frames
-        for (int i = lane; i < rem; i += 64) {
-            E.in_fifo[i] = E.src_l[consumed - E.in_len + i];
-            E.in_fifo[E.in_cap + i] = E.src_r[consumed - E.in_len + i];
+    }
+    __syncthreads();
+    if (active) {
+        // overlap-add per path, then ear sums (:279-284, :228-231); gain on the popped frames only
+        const float2 *prev = t ? smem + kTabComplex + (wave - 1) * kWaveLdsComplex : A.tails;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const float2 t1 = prev[a * 64 + lane], t2 = prev[(8 + a) * 64 + lane];
+            const float lsl = acc1[a].x * scale + t1.x, lsr = acc1[a].y * scale + t1.y;
+            const float rsl = acc2[a].x * scale + t2.x, rsr = acc2[a].y * scale + t2.y;
+            io.store((size_t)t * kBlock + 64 * a + lane, lsl + rsl, lsr + rsr);
+        }
+    }
+    __syncthreads();            // tails_out may alias tails: block 0 has read the old state by now
+    if (active && t == A.n_blocks - 1) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) A.tails_out[a * 64 + lane] = lds[a * 64 + lane];
+    }
+    // 3. what is left of the input (< 512 frames) becomes the FIFO content for the next call
+    if (wave == n_waves - 1) {
+        const int consumed = A.n_blocks * kBlock;
+        const int rem = E.in_len + E.n - consumed;
+        if (A.n_blocks == 0) {
+            for (int i = lane; i < E.n; i += 64) {
+                E.in_fifo[E.in_len + i] = E.src_l[i];
+                E.in_fifo[E.in_cap + E.in_len + i] = E.src_r[i];
+            }
+        } else {
+            // in_len < 512 <= consumed: the remainder lies entirely in this call's new frames
+            for (int i = lane; i < rem; i += 64) {
+                E.in_fifo[i] = E.src_l[consumed - E.in_len + i];
+                E.in_fifo[E.in_cap + i] = E.src_r[consumed - E.in_len + i];
+            }
         }
     }
 }
@@ -262,8 +336,14 @@ hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStrea
 
 hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st)
 {
-    const size_t shmem = (kTabComplex + kWaveLdsComplex) * sizeof(float2);
-    hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(64), shmem, st, a, e);
+    if (a.n_blocks < 0 || a.n_blocks > 8) return hipErrorInvalidValue;
+    const int waves = a.n_blocks > 0 ? a.n_blocks : 1;
+    const size_t shmem = (kTabComplex + (size_t)waves * kWaveLdsComplex) * sizeof(float2);   // <= 85 KiB
+    static std::atomic<unsigned long long> lds_ok{0};
+    const hipError_t e2 = allow_large_lds(reinterpret_cast<const void *>(k_engine_call),
+                                          (kTabComplex + 8 * kWaveLdsComplex) * sizeof(float2), lds_ok);
+    if (e2 != hipSuccess) return e2;
+    hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(64 * waves), shmem, st, a, e);
     return hipGetLastError();
 }
 
@@ -477,13 +557,9 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
     if (a.n_blocks > 1) {       // blocks [0, n_blocks - 1): `chunks` independent waves per stream
         const long long waves = (long long)a.n_streams * a.chunks;
         const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
-        static bool attr_done = false;      // > 64 KiB of dynamic LDS needs the opt-in attribute
-        if (!attr_done) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_p1),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_main);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        static std::atomic<unsigned long long> lds_ok{0};
+        e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1), shmem_main, lds_ok);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_conv_p1, dim3((unsigned)((waves + kP1Waves - 1) / kP1Waves)), dim3(64 * kP1Waves),
                            shmem_main, st, a);
         e = hipGetLastError();

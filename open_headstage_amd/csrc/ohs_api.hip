@@ -589,6 +589,12 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
     hipStream_t st = e->st;
     int rc = engine_pinned_reserve(e, n);
     if (rc) return rc;
+    {
+        int maxP = 1;
+        for (int p = 0; p < 4; ++p) maxP = std::max(maxP, e->conv.P[p]);
+        rc = conv_grow_ring(e->conv, maxP + 7, st);      // normally a no-op: ohs_engine_set_ir has done it
+        if (rc) return rc;
+    }
     std::memcpy(e->h_in, in_l, n * sizeof(float));
     std::memcpy(e->h_in + e->hcap, in_r, n * sizeof(float));
     const float *src_l = e->dm_in, *src_r = e->dm_in + e->hcap;
@@ -843,7 +849,13 @@ int ohs_engine_set_ir(ohs_engine *e, int path, const float *ir, size_t len)
 {
     if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
-    return conv_set_ir(e->conv, e->ctx, path, ir, len, e->st);
+    int rc = conv_set_ir(e->conv, e->ctx, path, ir, len, e->st);
+    if (rc) return rc;
+    // k_engine_call runs the (up to 8) blocks of a call side by side: the ring must hold the P - 1
+    // older spectra the first of them reads AND the 8 new ones -- grown here, not on the audio thread
+    int maxP = 1;
+    for (int p = 0; p < 4; ++p) maxP = std::max(maxP, e->conv.P[p]);
+    return conv_grow_ring(e->conv, maxP + 7, e->st);
 }
 
 int ohs_engine_process_block(ohs_engine *e, const float *in_l, const float *in_r, float *out_l,

@@ -46,14 +46,19 @@ def run_batch(name, S, taps, frames, eq_on, steps=5, warmup=2):
 
 
 def _per_call(fn, items):
+    import gc
+    gc.collect()
+    gc.disable()        # a full collection with torch loaded takes ~40 ms and would land on one call
     ts = []
     for it in items:
         t0 = time.perf_counter()
         fn(*it)
         ts.append(time.perf_counter() - t0)
+    gc.enable()
     ts = np.array(ts) * 1e6
     return {"median": round(float(np.median(ts)), 1), "mean": round(float(ts.mean()), 1),
-            "p99": round(float(np.percentile(ts, 99)), 1), "max": round(float(ts.max()), 1)}
+            "p99": round(float(np.percentile(ts, 99)), 1), "max": round(float(ts.max()), 1),
+            "argmax": int(ts.argmax())}
 
 
 def run_engine_c2(calls=400, n=1024):
