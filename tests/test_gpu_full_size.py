@@ -88,3 +88,45 @@ def test_config4_full_size_impulse_responses():
         exp[0, pos_r[s]:pos_r[s] + taps] += -0.5 * irs[2].astype(np.float64)[: frames - pos_r[s]]
         exp[1, pos_r[s]:pos_r[s] + taps] += -0.5 * irs[3].astype(np.float64)[: frames - pos_r[s]]
         assert_parity(y[s], exp, f"config 4 impulse stream {s}")
+
+
+def test_config5_per_node_stream_count_on_one_gpu():
+    """BASELINE config 5 shards 2048 streams over 8 GPUs; here all 2048 sit on one device (4096 EQ chains =
+    one wave per SIMD, 4 block ranges per stream in the convolution): streams 0, 1023 and 2047 against the
+    oracle, every other stream against the stream it repeats, across two calls."""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    from oracle import ohs_oracle as orc
+
+    S, n_blocks, taps = 2048, 24, 512
+    frames = n_blocks * 512
+    irs = synth.hrir_set(taps)
+    bands = synth.eq_table()
+    bp = ohs.BatchProcessor(S, num_bands=len(bands))
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i, b in enumerate(bands):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(True)
+    bp.set_gain(0.7)
+    dev = torch.device("cuda:0")
+    base = synth.white_noise_torch(40, 3, 2 * frames, dev)            # three distinct streams
+    x = base[torch.arange(S, device=dev) % 3].contiguous()           # stream s = base[s % 3]
+    ys = [bp.process(x[:, :, c * frames:(c + 1) * frames].contiguous()) for c in range(2)]
+    y = torch.cat(ys, dim=2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    for s in range(3, S):
+        assert torch.equal(y[s], y[s % 3]), f"stream {s} differs from stream {s % 3}"
+    for s in (0, 1023, 2047):
+        eng = orc.ConvolutionEngine()
+        for p in range(4):
+            eng.set_ir(p, irs[p])
+        eq = orc.StereoParametricEQ(len(bands), synth.FS)
+        for i, b in enumerate(bands):
+            eq.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+        xs = base[s % 3].cpu().numpy()
+        l, r = xs[0].copy(), xs[1].copy()
+        orc.chain_process(eng, eq, l, r, eq_enable=True, gain=0.7)
+        assert_parity(y[s].cpu().numpy(), np.stack([l, r]), f"config 5 stream {s}")
