@@ -154,8 +154,9 @@ struct Reader {
         if (!ok(root, 16) || std::memcmp(&f[root], "FHIB", 4) != 0) return;
         uint64_t q = root + 5 + off_size + boff;
         // rows of direct blocks: row 0 and 1 have start_block size, then doubling up to max_direct
+        if (start_block == 0 || start_block > max_direct) return;       // corrupt heap header
         uint64_t max_direct_rows = 2;
-        for (uint64_t s = start_block; s < max_direct; s <<= 1) ++max_direct_rows;
+        for (uint64_t s = start_block; s < max_direct && max_direct_rows < 48; s <<= 1) ++max_direct_rows;
         for (uint64_t r = 0; r < cur_rows && r < max_direct_rows; ++r) {
             const uint64_t bsize = r < 2 ? start_block : start_block << (r - 1);
             for (uint64_t k = 0; k < width; ++k) {
@@ -265,6 +266,7 @@ struct Reader {
                     q += nl + 4 * ncd;
                     if (ver == 1 && (ncd & 1)) q += 4;
                     filters.push_back(id);
+                    if (filters.size() > 32) return fail("filter pipeline too long");   // the chunk filter mask has 32 bits
                 }
             } else if (m.type == 0x0C) {     // attribute: keep fixed-length string values
                 const int ver = f[p];
