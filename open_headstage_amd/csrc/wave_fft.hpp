@@ -30,7 +30,7 @@ constexpr int kBlock = 512;
 constexpr int kFft = 1024;
 constexpr int kWaveLdsComplex = 16 * 68;   // per-wave LDS slab, in float2 units (8704 B)
 
-// twiddle tables kept in LDS per workgroup (float2 units); 17 KiB so that three 4-wave workgroups
+// twiddle tables kept in LDS per workgroup (float2 units); 17 KiB, small enough that three 4-wave workgroups
 // (3 x (17 + 4 x 8.5) KiB) fit the 160 KiB of a CU
 constexpr int kTabA = 0;              // [16][64]  w1024^(m p)            lane m,  reg p   (forward)
 constexpr int kTabD = 16 * 64;        // [16][64]  w1024^((4b+c) p)       lane L1, reg b   (inverse, conj)
@@ -125,7 +125,7 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
     t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
-// The 26 KiB of per-workgroup twiddle tables are expanded ONCE per device on the host
+// The 17 KiB of per-workgroup twiddle tables are expanded ONCE per device on the host
 // (expand_twiddle_tables, from exp(-2 pi i e / 1024) computed in f64 and rounded to f32, as rustfft
 // does); a kernel only copies them into LDS with 16-byte loads.
 __device__ __forceinline__ void fill_twiddle_tables(float2 *tab, const float2 *__restrict__ gtab,
