@@ -1240,11 +1240,15 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
         rc = span_end(st); if (rc) return rc;
         hipStream_t cst = st;
         if (nch > 1) {
-            hipEvent_t ev;
-            rc = get_event(&ev); if (rc) return rc;
-            HIP_TRY(hipEventRecord(ev, st));
-            HIP_TRY(hipStreamWaitEvent(b->st2, ev, 0));
-            b->ev_inflight.push_back(ev);
+            if (b->profiling) {     // the span's end event marks the same point: one record less on the EQ stream
+                HIP_TRY(hipStreamWaitEvent(b->st2, b->spans.back().b, 0));
+            } else {
+                hipEvent_t ev;
+                rc = get_event(&ev); if (rc) return rc;
+                HIP_TRY(hipEventRecord(ev, st));
+                HIP_TRY(hipStreamWaitEvent(b->st2, ev, 0));
+                b->ev_inflight.push_back(ev);
+            }
             cst = b->st2;
         }
         rc = span_begin(cst, 1); if (rc) return rc;

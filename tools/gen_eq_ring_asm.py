@@ -38,7 +38,10 @@ def ror(n):
     return "quad_perm:[0,1,2,3]" if n == 0 else f"row_ror:{n}"
 
 
-def gen():
+def gen(first_step=0, loads=True):
+    """first_step: 0 = whole group, 16 = chunks 1..7 only (the launch's first group, whose chunk 0 needs the
+    gated form); loads: prefetch the next group's inputs inside the block (interior groups) or not (the
+    caller has issued bounds-checked loads itself)."""
     out = []
     e = out.append
 
@@ -62,20 +65,20 @@ def gen():
         e(f"v_mov_b32_dpp {X}, %[x{nxt // 16}] {ror(12 - 4 * b)} row_mask:0xf bank_mask:0x8")
 
     e(".p2align 5")
-    for q in range(0 if "load" in KNOCK else 8):
+    for q in range(8 if loads and "load" not in KNOCK else 0):
         e(f"global_load_dword %[n{q}], %[lp], off" + (f" offset:{64 * q}" if q else ""))
     e(f"v_mov_b32 {X}, %[o]")
     e("v_mov_b32 v112, %[s1]")
     e("v_mov_b32 v113, %[s2]")
     e("s_nop 1")
-    port(0)
+    port(first_step)
     e("s_nop 0")                # INJ -> M: a DPP read needs 2 wait states after the VALU write of its source
     e("s_nop 0")
     e(P)
     e(M)
     e("s_nop 0")                # P -> O likewise
     e("s_nop 0")
-    for k in range(STEPS):
+    for k in range(first_step, STEPS):
         last = k == STEPS - 1
         boundary = (k + 1) % 4 == 0 and not last
         ported = False
@@ -105,9 +108,11 @@ if __name__ == "__main__":
     path = sys.argv[1] if len(sys.argv) > 1 else "open_headstage_amd/csrc/eq_ring_asm.inc"
     name = sys.argv[2] if len(sys.argv) > 2 else "EQ_RING_BODY"
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_eq_ring_asm.py -- do not edit.  128-step EQ ring group body (see eq_kernels.hip).\n")
-        lines = gen()
-        f.write(f"#define {name} \\\n")
-        f.write(" \\\n".join('    "' + l + '\\n"' for l in lines))
-        f.write("\n")
+        f.write("// GENERATED by tools/gen_eq_ring_asm.py -- do not edit.  128-step EQ ring group bodies (see eq_kernels.hip).\n")
+        for macro, kw in ((name, {}), (name + "_NOLOAD", {"loads": False}),
+                          (name + "_HEAD", {"first_step": 16, "loads": False})):
+            lines = gen(**kw)
+            f.write(f"#define {macro} \\\n")
+            f.write(" \\\n".join('    "' + l + '\\n"' for l in lines))
+            f.write("\n\n")
     print("wrote", path)
