@@ -7,12 +7,17 @@ single-launch engine call, the general kernel, the one-partition fast path, the 
 path and the two EQ kernels gets exercised.  Bars as in test_gpu_parity.py: EQ bit-exact, everything that
 passes through an FFT <= 1e-6 RMS (absolute and relative) against the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
 from tests.util import assert_parity
 
 pytestmark = pytest.mark.gpu
+
+# OHS_FUZZ_SEEDS=200 python -m pytest tests/test_gpu_fuzz.py -m gpu   for a longer soak
+_EXTRA = int(os.environ.get("OHS_FUZZ_SEEDS", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +52,7 @@ def _sync_band(qg, qo, i):
     qo.set_band_coeffs(i, c, en)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, _EXTRA)))
 def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     eg, eo = ohs.ConvolutionEngine.new(), oracle.ConvolutionEngine()
@@ -100,7 +105,7 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
         assert_parity(np.concatenate(got, 1), np.concatenate(ref, 1), f"fuzz chain seed {seed}")
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(max(4, _EXTRA)))
 def test_fuzz_batch(ohs, synth, oracle, seed):
     import torch
     rng = np.random.default_rng(2000 + seed)
