@@ -65,7 +65,7 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
         h = _random_ir(rng, int(rng.choice([64, 512, 700])))
         eg.set_ir(p, h); eo.set_ir(p, h)
     sizes = [1, 7, 64, 511, 512, 513, 1024, 1024, 1024, 1500, 2048, 3000, 4096, 9000]
-    stream = synth.white_noise([200 + seed], 120000)[0]
+    stream = synth.white_noise([200 + seed], 45 * 9000)[0]        # 45 steps of <= 9000 frames
     pos = 0
     got, ref = [], []
     for step in range(45):
@@ -126,7 +126,7 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
         bp.set_ir(p, h)
         for e in eos:
             e.set_ir(p, h)
-    x = synth.white_noise(range(300 + 10 * seed, 300 + 10 * seed + S), 512 * 400)
+    x = synth.white_noise(range(300 + 10 * seed, 300 + 10 * seed + S), 512 * 70 * 9)     # 9 calls of <= 70 blocks
     pos = 0
     got, ref = [], []
     for call in range(9):
