@@ -174,3 +174,18 @@ def test_world_size_2_gloo_sharded_run_matches_single_process(tmp_path, oracle):
         l, r = x[sid, 0].copy(), x[sid, 1].copy()
         oracle.chain_process(eng, eq, l, r, eq_enable=True, gain=1.0)
         assert np.array_equal(got[sid, 0], l) and np.array_equal(got[sid, 1], r), sid
+
+
+def test_header_is_plain_c_and_the_c_host_links(tmp_path):
+    """include/ohs_hip.h must be consumable by a C compiler (the Rust side binds a C ABI), and
+    examples/host_chain.c must link against the built library (no GPU needed for either)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    libdir = os.path.join(root, "open_headstage_amd")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), "-o",
+                    str(tmp_path / "host_chain"), os.path.join(root, "examples", "host_chain.c"),
+                    "-L" + libdir, "-lohs_hip", "-lm", "-Wl,-rpath," + libdir], check=True)
