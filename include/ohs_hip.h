@@ -109,7 +109,10 @@ int  ohs_eq_update_band(ohs_eq *eq, size_t band, float fs, int filter_type, floa
 /* Same, but the host supplies biquad-crate coefficients so the bits are its own. */
 int  ohs_eq_set_band_coeffs(ohs_eq *eq, size_t band, const float coeffs[5], int enabled);
 int  ohs_eq_get_band_coeffs(const ohs_eq *eq, size_t band, float coeffs[5], int *enabled);
-/* process_block(&mut [f32], &mut [f32]) in place  parametric_eq.rs:166-179. */
+/* process_block(&mut [f32], &mut [f32]) in place  parametric_eq.rs:166-179.  Same products and sums
+ * in the same order, each rounded separately: bit-identical to the reference's DF2T recurrence for
+ * finite samples, except that a -0.0 may come out as +0.0; a non-finite INPUT sample makes the output
+ * non-finite from up to 16 samples before it (the reference: from that sample on).  DESIGN.md 4.4. */
 int  ohs_eq_process_block(ohs_eq *eq, float *left, float *right, size_t n);
 /* reset_all_bands_state  parametric_eq.rs:181-188 (also Plugin::reset, lib.rs:1152-1154). */
 int  ohs_eq_reset(ohs_eq *eq);
