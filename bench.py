@@ -265,6 +265,12 @@ def main() -> int:
                 "launches_per_step": {eq_name: eq_launches // max(n_calls, 1),
                                       conv_name: conv_launches // max(n_calls, 1)},
                 "kernels_ms_per_step": {k: round(v[2], 4) for k, v in kernels.items()},
+                # the dominant kernel is a serial recurrence, not a streaming kernel: what bounds it is one
+                # wave's instruction issue, reported here next to the HBM figure
+                "issue_bound": {
+                    "cycles_per_sample_floor": 26.7,        # 6.5 VALU per sample x 4.1 cycles per instruction
+                    "ns_per_sample": round(eq_ms / max(n_calls, 1) * 1e6 / frames, 3),
+                } if dom == eq_name else None,
             },
             "finite": ok,
         }
