@@ -201,6 +201,15 @@ int  ohs_batch_reset(ohs_batch *b);
  * d_in may equal d_out. Strides are in floats. */
 int  ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
                        size_t stream_stride, size_t channel_stride, void *hip_stream);
+/* The same, but `hip_stream` is NOT made to wait for the last time chunk's convolution (it runs on an
+ * internal stream underneath the EQ): d_out is complete on `hip_stream` only after ohs_batch_join (a
+ * stream-side wait, asynchronous) or ohs_batch_sync.  Back-to-back deferred calls with the same buffers
+ * pipeline: the next call's EQ starts while the previous call's last convolution finishes; every other
+ * use of the handle joins by itself first.  Results are identical to ohs_batch_process. */
+int  ohs_batch_process_deferred(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                                size_t stream_stride, size_t channel_stride, void *hip_stream);
+int  ohs_batch_join(ohs_batch *b, void *hip_stream);
+/* waits (host side) for everything queued on `hip_stream` and for a pending deferred call */
 int  ohs_batch_sync(ohs_batch *b, void *hip_stream);
 /* Per-kernel timing for the roofline report: when enabled, every ohs_batch_process call brackets
  * its kernels with hipEvents on the caller's stream.  ohs_batch_profile_read waits for them,

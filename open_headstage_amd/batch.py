@@ -53,13 +53,21 @@ class BatchProcessor:
 
     # -- processing --------------------------------------------------------------
     def process_ptr(self, d_in: int, d_out: int, n_blocks: int, stream_stride: int,
-                    channel_stride: int, hip_stream: int = 0) -> None:
-        check(lib().ohs_batch_process(self._h, C.c_void_p(d_in), C.c_void_p(d_out), int(n_blocks),
-                                      int(stream_stride), int(channel_stride),
-                                      C.c_void_p(hip_stream) if hip_stream else None))
+                    channel_stride: int, hip_stream: int = 0, deferred: bool = False) -> None:
+        fn = lib().ohs_batch_process_deferred if deferred else lib().ohs_batch_process
+        check(fn(self._h, C.c_void_p(d_in), C.c_void_p(d_out), int(n_blocks), int(stream_stride),
+                 int(channel_stride), C.c_void_p(hip_stream) if hip_stream else None))
 
-    def process(self, x, out=None, hip_stream: int | None = None):
-        """x, out: torch.float32 CUDA tensors [n_streams, 2, frames], frames % 512 == 0."""
+    def join(self, hip_stream: int | None = None) -> None:
+        """Make `hip_stream` (default: torch's current stream) wait for a pending deferred call."""
+        if hip_stream is None:
+            import torch
+            hip_stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib().ohs_batch_join(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def process(self, x, out=None, hip_stream: int | None = None, deferred: bool = False):
+        """x, out: torch.float32 CUDA tensors [n_streams, 2, frames], frames % 512 == 0.
+        deferred=True: `out` is complete on the stream only after join() / sync() (ohs_batch_process_deferred)."""
         import torch
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()):
             raise TypeError("x must be a contiguous float32 CUDA tensor [streams, 2, frames]")
@@ -75,7 +83,7 @@ class BatchProcessor:
         if hip_stream is None:
             hip_stream = torch.cuda.current_stream(x.device).cuda_stream
         self.process_ptr(x.data_ptr(), out.data_ptr(), frames // BLOCK_SIZE, 2 * frames, frames,
-                         hip_stream)
+                         hip_stream, deferred)
         return out
 
     def sync(self, hip_stream: int = 0) -> None:

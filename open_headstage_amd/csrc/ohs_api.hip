@@ -534,6 +534,12 @@ struct ohs_batch {
     uint64_t prof_calls = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<hipEvent_t> ev_inflight;   // ordering events of the current / previous calls
+    // ohs_batch_process_deferred: the convolutions of the previous call may still be running on st2
+    std::vector<hipEvent_t> chunk_done;    // one persistent event per time chunk, re-recorded on st2 by every such call
+    int chunk_done_n = 0;                  // chunks of the pending call
+    bool join_pending = false;
+    const float *pend_out = nullptr;       // geometry of the pending call: per-chunk waits only if the next one matches
+    size_t pend_blocks = 0, pend_ss = 0, pend_cs = 0;
 };
 
 namespace {
@@ -1089,6 +1095,7 @@ void ohs_batch_destroy(ohs_batch *b)
     for (auto &sp : b->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t e : b->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : b->ev_inflight) hipEventDestroy(e);
+    for (hipEvent_t e : b->chunk_done) hipEventDestroy(e);
     if (b->st2) hipStreamDestroy(b->st2);
     if (b->st) hipStreamDestroy(b->st);
     delete b;
@@ -1154,8 +1161,8 @@ int ohs_batch_reset(ohs_batch *b)
     return OHS_OK;
 }
 
-int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
-                      size_t stream_stride, size_t channel_stride, void *hip_stream)
+static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                              size_t stream_stride, size_t channel_stride, void *hip_stream, bool deferred)
 {
     if (!b || !d_in || !d_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
     if (n_blocks == 0) return OHS_OK;
@@ -1200,6 +1207,19 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
 
     const long long ss = (long long)stream_stride, cs = (long long)channel_stride;
     int rc;
+    // A deferred call may have left convolutions running on st2.  If this call repeats its geometry and
+    // overlaps again, EQ chunk c only has to wait for THAT call's convolution of chunk c (same frames of
+    // d_out); anything else joins completely first.
+    const bool will_overlap = eq_active && b->overlap && n_blocks >= 64;
+    bool chunk_waits = false;
+    if (b->join_pending) {
+        chunk_waits = will_overlap && b->pend_out == d_out && b->pend_blocks == n_blocks &&
+                      b->pend_ss == stream_stride && b->pend_cs == channel_stride;
+        if (!chunk_waits) {
+            HIP_TRY(hipStreamWaitEvent(st, b->chunk_done[(size_t)b->chunk_done_n - 1], 0));
+            b->join_pending = false;
+        }
+    }
     if (!eq_active) {     // lib.rs:1179 eq_enable false (or every band disabled: identity)
         rc = span_begin(st, 1); if (rc) return rc;
         rc = conv_launch(b->conv, b->ctx, d_in, ss, cs, d_out, ss, cs, (int)n_blocks, b->gain, st);
@@ -1234,6 +1254,7 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
         const size_t blk1 = nch == 1 ? n_blocks : (i == nch - 1 ? n_blocks : (size_t)(kCut[i + 1] * (double)n_blocks));
         const size_t off = blk0 * BS;
         const int nb_i = (int)(blk1 - blk0);
+        if (chunk_waits) HIP_TRY(hipStreamWaitEvent(st, b->chunk_done[(size_t)i], 0));
         rc = span_begin(st, 0); if (rc) return rc;
         rc = eq_launch(b->eq, d_in + off, d_out + off, ss, cs, (long long)nb_i * BS, st);
         if (rc) return rc;
@@ -1255,14 +1276,49 @@ int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_bl
         rc = conv_launch(b->conv, b->ctx, d_out + off, ss, cs, d_out + off, ss, cs, nb_i, b->gain, cst);
         if (rc) return rc;
         rc = span_end(cst); if (rc) return rc;
+        if (nch > 1 && deferred) {
+            while (b->chunk_done.size() <= (size_t)i) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                b->chunk_done.push_back(ev);
+            }
+            HIP_TRY(hipEventRecord(b->chunk_done[(size_t)i], b->st2));
+        }
     }
-    if (nch > 1) {      // join: the caller's stream continues only after the last convolution
+    b->join_pending = false;
+    if (nch > 1 && deferred) {      // the caller joins later (ohs_batch_join / ohs_batch_sync / the next call)
+        b->join_pending = true;
+        b->chunk_done_n = nch;
+        b->pend_out = d_out; b->pend_blocks = n_blocks; b->pend_ss = stream_stride; b->pend_cs = channel_stride;
+    } else if (nch > 1) {           // join: the caller's stream continues only after the last convolution
         hipEvent_t ev;
         rc = get_event(&ev); if (rc) return rc;
         HIP_TRY(hipEventRecord(ev, b->st2));
         HIP_TRY(hipStreamWaitEvent(st, ev, 0));
         b->ev_inflight.push_back(ev);
     }
+    return OHS_OK;
+}
+
+int ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                      size_t stream_stride, size_t channel_stride, void *hip_stream)
+{
+    return batch_process_impl(b, d_in, d_out, n_blocks, stream_stride, channel_stride, hip_stream, false);
+}
+
+int ohs_batch_process_deferred(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                               size_t stream_stride, size_t channel_stride, void *hip_stream)
+{
+    return batch_process_impl(b, d_in, d_out, n_blocks, stream_stride, channel_stride, hip_stream, true);
+}
+
+int ohs_batch_join(ohs_batch *b, void *hip_stream)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    if (!b->join_pending) return OHS_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, b->chunk_done[(size_t)b->chunk_done_n - 1], 0));
+    b->join_pending = false;
     return OHS_OK;
 }
 
@@ -1302,6 +1358,10 @@ int ohs_batch_sync(ohs_batch *b, void *hip_stream)
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    if (b->join_pending) {
+        HIP_TRY(hipStreamSynchronize(b->st2));
+        b->join_pending = false;
+    }
     return OHS_OK;
 }
 

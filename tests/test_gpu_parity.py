@@ -548,3 +548,69 @@ def test_eq_ring_documented_edge_cases_signed_zero_and_non_finite_input(ohs, syn
     assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32))      # the other channel is untouched
     assert np.array_equal(gl[:k - 16].view(np.uint32), ol[:k - 16].view(np.uint32))
     assert np.isnan(ol[k:]).all() and np.isnan(gl[k:]).all()
+
+
+def test_batch_deferred_join_is_bit_identical_and_mixes_with_everything(ohs, synth, oracle):
+    """ohs_batch_process_deferred pipelines back-to-back calls (the next call's EQ starts while the last
+    convolution chunk of the previous one finishes).  Same bits as ohs_batch_process, whatever follows a
+    deferred call: the same geometry again, another buffer, a short call, a call without EQ, set_ir."""
+    import torch
+    S, taps, n_blocks = 6, 512, 96
+    frames = n_blocks * 512
+    irs = synth.hrir_set(taps)
+    bands = synth.eq_table()
+
+    def make():
+        bp = ohs.BatchProcessor(S, num_bands=len(bands))
+        for p in range(4):
+            bp.set_ir(p, irs[p])
+        for i, b in enumerate(bands):
+            bp.update_band_coeffs(i, synth.FS, b)
+        bp.set_eq_enabled(True)
+        return bp
+
+    x = torch.from_numpy(synth.white_noise(range(500, 500 + S), frames * 6)).cuda()
+    seg = [x[:, :, k * frames:(k + 1) * frames].contiguous() for k in range(6)]
+    short = seg[4][:, :, :20 * 512].contiguous()
+
+    def run(bp, deferred):
+        outs = []
+        y = torch.empty_like(seg[0])
+        for k in range(3):                       # same buffers, back to back: the pipelined case
+            bp.process(seg[k], out=y, deferred=deferred)
+            if deferred:
+                bp.join()                        # consume on the stream before the buffer is reused
+            outs.append(y.clone())
+        ys = [torch.empty_like(seg[0]) for _ in range(2)]
+        bp.process(seg[3], out=ys[0], deferred=deferred)       # deferred, then another output buffer
+        bp.process(seg[3], out=ys[1], deferred=deferred)
+        bp.process(short, out=None if not deferred else None, deferred=deferred)    # a short (non-overlapped) call
+        bp.set_eq_enabled(False)
+        y5 = bp.process(seg[5], deferred=deferred)             # no EQ: convolution on the caller's stream
+        bp.set_eq_enabled(True)
+        if deferred:
+            bp.join()
+        torch.cuda.synchronize()
+        outs += [ys[0].clone(), ys[1].clone(), y5.clone()]
+        irs2 = synth.hrir_set(300)
+        bp.set_ir(2, irs2[2])                                   # synchronises by itself
+        ylast = bp.process(seg[0], deferred=deferred)
+        if deferred:
+            bp.sync()                                           # host-side wait, includes the pending call
+        torch.cuda.synchronize()
+        outs.append(ylast.clone())
+        return outs
+
+    a = run(make(), False)
+    b = run(make(), True)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), f"deferred differs from strict at output {i}"
+
+    # the pure pipeline (no join between calls, same buffers) against the oracle for the last call
+    bp = make()
+    y = torch.empty_like(seg[0])
+    for k in range(3):
+        bp.process(seg[k], out=y, deferred=True)
+    bp.join()
+    torch.cuda.synchronize()
+    assert torch.equal(y, a[2])
