@@ -109,7 +109,7 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
 def test_fuzz_batch(ohs, synth, oracle, seed):
     import torch
     rng = np.random.default_rng(2000 + seed)
-    S = int(rng.integers(1, 6))
+    S = int(rng.integers(1, 6)) if seed % 5 else int(rng.integers(6, 24))
     bands = synth.eq_table()
     bp = ohs.BatchProcessor(S, num_bands=len(bands))
     eos = [oracle.ConvolutionEngine() for _ in range(S)]
@@ -120,7 +120,7 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
         for q in qos:
             q.set_band_coeffs(i, c, b.enabled)
     long_ir = bool(seed % 2)            # odd seeds: partitions > 1 (general + time-parallel kernels)
-    lengths = [300, 512, 2000, 5000] if long_ir else [64, 300, 512]
+    lengths = [300, 512, 2000, 5000, 9000] if long_ir else [64, 300, 512]
     for p in range(4):
         h = _random_ir(rng, int(rng.choice(lengths)))
         bp.set_ir(p, h)
@@ -142,13 +142,32 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
         nblk = int(rng.choice([1, 2, 3, 5, 9, 17, 40, 70]))
         n = nblk * 512
         xt = torch.from_numpy(np.ascontiguousarray(x[:, :, pos:pos + n])).cuda()
-        y = bp.process(xt).cpu().numpy()
+        mode = int(rng.integers(0, 4))
+        if mode == 0:                       # out of place, strict
+            y = bp.process(xt).cpu().numpy()
+        elif mode == 1:                     # in place
+            y = bp.process(xt, out=xt).cpu().numpy()
+        elif mode == 2:                     # deferred join (ohs_batch_process_deferred / ohs_batch_join)
+            yt = bp.process(xt, deferred=True)
+            bp.join()
+            y = yt.cpu().numpy()
+        else:                               # padded strides through the pointer interface
+            pad_c, pad_s = int(rng.integers(0, 3)) * 64, int(rng.integers(0, 3)) * 128
+            cs_ = n + pad_c
+            ss_ = 2 * cs_ + pad_s
+            buf = torch.full((S * ss_,), float("nan"), device="cuda")
+            view = torch.as_strided(buf, (S, 2, n), (ss_, cs_, 1))
+            view.copy_(xt)
+            obuf = torch.zeros_like(buf)
+            bp.process_ptr(buf.data_ptr(), obuf.data_ptr(), nblk, ss_, cs_,
+                           torch.cuda.current_stream().cuda_stream)
+            y = torch.as_strided(obuf, (S, 2, n), (ss_, cs_, 1)).cpu().numpy()
         o = np.empty_like(y)
         for s in range(S):
             l, r = x[s, 0, pos:pos + n].copy(), x[s, 1, pos:pos + n].copy()
             oracle.chain_process(eos[s], qos[s], l, r, eq_enable=eq_on, gain=gain)
             o[s, 0], o[s, 1] = l, r
         pos += n
-        assert np.abs(y - o).max() < 2e-5, (seed, call, nblk)
+        assert np.abs(y - o).max() < 2e-5, (seed, call, nblk, mode, eq_on, S, [int(v) for v in np.argwhere(np.abs(y - o) > 2e-5)[:6].ravel()])
         got.append(y); ref.append(o)
     assert_parity(np.concatenate(got, 2), np.concatenate(ref, 2), f"fuzz batch seed {seed}")

@@ -614,3 +614,39 @@ def test_batch_deferred_join_is_bit_identical_and_mixes_with_everything(ohs, syn
     bp.join()
     torch.cuda.synchronize()
     assert torch.equal(y, a[2])
+
+
+def test_batch_eq_in_place_with_a_partial_last_wave(ohs, synth, oracle):
+    """EQ + convolution in place (d_in == d_out) when the chain count is not a multiple of 4: the idle rows of
+    the last EQ wave must shadow a row of their OWN wave (lock-step).  Shadowing a chain of another wave --
+    here stream 0, handled by a wave on another CU -- read samples that wave had already overwritten as soon
+    as the two drifted apart under the overlapped convolution (found by tests/test_gpu_fuzz.py)."""
+    import torch
+    S = 255                                   # 510 chains: the last wave has two idle rows
+    bands = synth.eq_table()
+    irs = synth.hrir_set(512)
+    n = 512 * 128
+    x0 = synth.white_noise([900], n)[0]
+    eo = oracle.ConvolutionEngine()
+    for p in range(4):
+        eo.set_ir(p, irs[p])
+    qo = oracle.StereoParametricEQ(len(bands), synth.FS)
+    for i, b in enumerate(bands):
+        qo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+    l, r = x0[0].copy(), x0[1].copy()
+    oracle.chain_process(eo, qo, l, r, eq_enable=True, gain=1.0)
+    ref0 = np.stack([l, r])
+    bp = ohs.BatchProcessor(S, num_bands=len(bands))
+    for i, b in enumerate(bands):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(True)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    base = synth.white_noise_torch(901, 3, n, torch.device("cuda:0"))
+    for rep in range(3):
+        bp.reset()
+        xt = base[torch.arange(S, device="cuda") % 3].contiguous()
+        xt[0] = torch.from_numpy(x0).cuda()
+        y = bp.process(xt, out=xt)
+        assert_parity(y[0].cpu().numpy(), ref0, f"in-place chain, stream 0, repetition {rep}")
+        assert torch.equal(y[4], y[7]) and torch.equal(y[5], y[254])       # 4 = 7 = 1 mod 3, 5 = 254 = 2 mod 3
