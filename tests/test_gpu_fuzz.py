@@ -121,25 +121,44 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
             q.set_band_coeffs(i, c, b.enabled)
     long_ir = bool(seed % 2)            # odd seeds: partitions > 1 (general + time-parallel kernels)
     lengths = [300, 512, 2000, 5000, 9000] if long_ir else [64, 300, 512]
+    cur_irs = [None] * 4
     for p in range(4):
         h = _random_ir(rng, int(rng.choice(lengths)))
+        cur_irs[p] = h
         bp.set_ir(p, h)
         for e in eos:
             e.set_ir(p, h)
-    x = synth.white_noise(range(300 + 10 * seed, 300 + 10 * seed + S), 512 * 70 * 9)     # 9 calls of <= 70 blocks
+    x = synth.white_noise(range(300 + 10 * seed, 300 + 10 * seed + S), 512 * 130 * 9)    # 9 calls of <= 130 blocks
     pos = 0
     got, ref = [], []
     for call in range(9):
         if call and rng.random() < 0.35:    # mid-stream: one path replaced -> per-path gating in the general kernel
             p = int(rng.integers(0, 4))
             h = _random_ir(rng, int(rng.choice(lengths + [0])))
+            cur_irs[p] = h
             bp.set_ir(p, h)
             for e in eos:
                 e.set_ir(p, h)
+        if call and rng.random() < 0.15:    # retune one band for every stream (state kept)
+            i = int(rng.integers(0, len(bands)))
+            nb_ = _random_band(ohs, rng)
+            bp.update_band_coeffs(i, synth.FS, nb_)
+            c = ohs.biquad_coefficients(nb_.filter_type, synth.FS, nb_.center_freq, nb_.q, nb_.gain_db)
+            for q in qos:
+                q.set_band_coeffs(i, c, nb_.enabled)
+        if call and rng.random() < 0.1:     # zero all DSP state, keep IRs and EQ table
+            bp.reset()
+            for q in qos:
+                q.reset_all_bands_state()
+            irs_now = cur_irs
+            eos = [oracle.ConvolutionEngine() for _ in range(S)]
+            for e in eos:
+                for p in range(4):
+                    e.set_ir(p, irs_now[p])
         eq_on = bool(rng.random() < 0.6)
         gain = float(np.float32(rng.uniform(0.3, 1.0)))
         bp.set_eq_enabled(eq_on); bp.set_gain(gain)
-        nblk = int(rng.choice([1, 2, 3, 5, 9, 17, 40, 70]))
+        nblk = int(rng.choice([1, 2, 3, 5, 9, 17, 40, 64, 70, 130]))
         n = nblk * 512
         xt = torch.from_numpy(np.ascontiguousarray(x[:, :, pos:pos + n])).cuda()
         mode = int(rng.integers(0, 4))
