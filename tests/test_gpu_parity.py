@@ -650,3 +650,53 @@ def test_batch_eq_in_place_with_a_partial_last_wave(ohs, synth, oracle):
         y = bp.process(xt, out=xt)
         assert_parity(y[0].cpu().numpy(), ref0, f"in-place chain, stream 0, repetition {rep}")
         assert torch.equal(y[4], y[7]) and torch.equal(y[5], y[254])       # 4 = 7 = 1 mod 3, 5 = 254 = 2 mod 3
+
+
+def test_handles_on_concurrent_host_threads(ohs, synth, oracle):
+    """One handle = one thread at a time, but different handles run on different host threads at once
+    (ctypes releases the GIL inside the library): four engine + EQ pairs, each driven by its own thread."""
+    import threading
+    irs = synth.hrir_set(512)
+    bands = synth.eq_table()
+    n_threads, calls, n = 4, 60, 1024
+    results = [None] * n_threads
+    errors = []
+
+    def worker(tid):
+        try:
+            eg = ohs.ConvolutionEngine.new()
+            for p in range(4):
+                eg.set_ir(p, irs[p])
+            qg = ohs.StereoParametricEQ.new(len(bands), synth.FS)
+            for i, b in enumerate(bands):
+                qg.update_band_coeffs(i, synth.FS, b)
+            x = synth.white_noise([700 + tid], calls * n)[0]
+            out = np.empty_like(x)
+            for c in range(calls):
+                l, r = x[0, c * n:(c + 1) * n].copy(), x[1, c * n:(c + 1) * n].copy()
+                ohs.process_chain(eg, qg, l, r, eq_enable=True, output_gain=0.9)
+                out[0, c * n:(c + 1) * n], out[1, c * n:(c + 1) * n] = l, r
+            results[tid] = out
+        except Exception as e:       # noqa: BLE001 -- reported below
+            errors.append((tid, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for tid in range(n_threads):
+        eo = oracle.ConvolutionEngine()
+        for p in range(4):
+            eo.set_ir(p, irs[p])
+        qo = oracle.StereoParametricEQ(len(bands), synth.FS)
+        for i, b in enumerate(bands):
+            qo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+        x = synth.white_noise([700 + tid], calls * n)[0]
+        ref = np.empty_like(x)
+        for c in range(calls):
+            l, r = x[0, c * n:(c + 1) * n].copy(), x[1, c * n:(c + 1) * n].copy()
+            oracle.chain_process(eo, qo, l, r, eq_enable=True, gain=0.9)
+            ref[0, c * n:(c + 1) * n], ref[1, c * n:(c + 1) * n] = l, r
+        assert_parity(results[tid], ref, f"thread {tid}")
