@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 # OHS_FUZZ_SEEDS=200 python -m pytest tests/test_gpu_fuzz.py -m gpu   for a longer soak
 _EXTRA = int(os.environ.get("OHS_FUZZ_SEEDS", "0"))
+_FIRST = int(os.environ.get("OHS_FUZZ_FIRST", "0"))      # with OHS_FUZZ_SEEDS: skip seeds below this one
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +53,7 @@ def _sync_band(qg, qo, i):
     qo.set_band_coeffs(i, c, en)
 
 
-@pytest.mark.parametrize("seed", range(max(6, _EXTRA)))
+@pytest.mark.parametrize("seed", range(_FIRST if _EXTRA else 0, max(6, _EXTRA)))
 def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     eg, eo = ohs.ConvolutionEngine.new(), oracle.ConvolutionEngine()
@@ -105,7 +106,7 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
         assert_parity(np.concatenate(got, 1), np.concatenate(ref, 1), f"fuzz chain seed {seed}")
 
 
-@pytest.mark.parametrize("seed", range(max(4, _EXTRA)))
+@pytest.mark.parametrize("seed", range(_FIRST if _EXTRA else 0, max(4, _EXTRA)))
 def test_fuzz_batch(ohs, synth, oracle, seed):
     import torch
     rng = np.random.default_rng(2000 + seed)
