@@ -18,6 +18,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built library (it is git-ignored): build it in-tree once, if hipcc is here.
+    (hipcc cross-compiles without a GPU; on the GPU box the prebuilt .so travels with the snapshot.)"""
+    from open_headstage_amd import build as _build
+    if not os.path.exists(_build.LIB):
+        try:
+            _build.build()
+        except Exception as e:      # noqa: BLE001 -- the tests that need the library will say so themselves
+            print(f"conftest: could not build {_build.LIB}: {e}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import ohs_oracle
