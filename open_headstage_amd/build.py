@@ -5,9 +5,16 @@
 hipcc cross-compiles without a GPU.  eq_kernels.hip is compiled with
 -ffp-contract=off: the biquad recurrence must round every product and sum
 separately to be bit-exact with the reference's arithmetic.
+
+Staleness is decided by CONTENT (sha256 of each unit's source, every header / .inc it may include, its
+flags and this file), recorded in libohs_hip.stamp next to the library -- not by mtimes, which a
+snapshot copy to the GPU box does not keep.  `is_current()` lets the test session refuse a library
+that does not match the sources it is about to test.
 """
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -17,19 +24,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libohs_hip.so")
+STAMP = os.path.join(HERE, "libohs_hip.stamp")
 ARCH = "gfx950"
 
-# (source, extra flags)
-UNITS = [
-    ("conv_kernels.hip", ["-fno-slp-vectorize"]),     # FFT kernels: see conv_mac_kernels.hip
-    ("conv_mac_kernels.hip", [f"-DOHS_MAC_TB={os.environ.get('OHS_MAC_TB', '16')}",
-                              f"-DOHS_MAC_PI={os.environ.get('OHS_MAC_PI', '16')}"]),
-    ("eq_kernels.hip", ["-ffp-contract=off"]),
-    ("ohs_api.hip", []),
-    ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
-    ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
-    ("biquad_coeffs.cpp", ["-x", "hip"]),   # host-only C++ (RBJ coefficient formulas)
-]
+
+def _units():
+    # (source, extra flags)
+    return [
+        ("conv_kernels.hip", ["-fno-slp-vectorize"]),     # FFT kernels: see conv_mac_kernels.hip
+        ("conv_mac_kernels.hip", [f"-DOHS_MAC_TB={os.environ.get('OHS_MAC_TB', '16')}",
+                                  f"-DOHS_MAC_PI={os.environ.get('OHS_MAC_PI', '16')}"]),
+        ("eq_kernels.hip", ["-ffp-contract=off"]),
+        ("rt_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),   # persistent real-time adapter
+        ("ohs_api.hip", []),
+        ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
+        ("sofa_conditioning.cpp", ["-x", "hip"]),   # host-only C++ (libmysofa-style loudness / interpolation)
+        ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
+        ("biquad_coeffs.cpp", ["-x", "hip"]),   # host-only C++ (RBJ coefficient formulas)
+    ]
+
+
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -43,34 +57,73 @@ def _hipcc() -> str:
 
 def _deps(src: str) -> list[str]:
     deps = [os.path.join(CSRC, src)]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
+    deps += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc")))
     deps.append(os.path.join(os.path.dirname(HERE), "include", "ohs_hip.h"))
     deps.append(os.path.abspath(__file__))
     return deps
 
 
+def _unit_hash(src: str, extra: list[str]) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(COMMON + extra).encode())
+    for d in _deps(src):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _current_hashes() -> dict:
+    return {src: _unit_hash(src, extra) for src, extra in _units() if os.path.exists(os.path.join(CSRC, src))}
+
+
+def _read_stamp() -> dict:
+    try:
+        with open(STAMP) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def is_current() -> bool:
+    """True when libohs_hip.so exists and was built from exactly the sources in the tree."""
+    return os.path.exists(LIB) and _read_stamp() == _current_hashes()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    units = [(s, e) for s, e in _units() if os.path.exists(os.path.join(CSRC, s))]
+    want = _current_hashes()
+    have = _read_stamp()
+    if not force and os.path.exists(LIB) and have == want:
+        return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     objs = []
-    relink = force or not os.path.exists(LIB)
-    for src, extra in UNITS:
+    for src, extra in units:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        stale = force or not os.path.exists(obj) or any(
-            os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
-        if stale:
+        if force or not os.path.exists(obj) or _read_obj_hash(obj) != want[src]:
             cmd = [hipcc, *COMMON, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
-            relink = True
-    if relink or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+            with open(obj + ".hash", "w") as f:
+                f.write(want[src])
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        json.dump(want, f, indent=1)
     return LIB
+
+
+def _read_obj_hash(obj: str) -> str:
+    try:
+        with open(obj + ".hash") as f:
+            return f.read().strip()
+    except Exception:
+        return ""
 
 
 if __name__ == "__main__":

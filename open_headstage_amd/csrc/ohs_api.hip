@@ -212,22 +212,29 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
+    // every failure path below frees what it allocated: a HIP_TRY inside the lambda returns from the
+    // lambda only, the buffers are released after it
     float2 *nH = nullptr;
-    HIP_TRY(hipMalloc(&nH, (size_t)P * NF * sizeof(float2)));
-    if (len == 0) {
-        HIP_TRY(hipMemsetAsync(nH, 0, NF * sizeof(float2), st));   // :114-118 mute
-    } else {
-        float *d_ir = nullptr;
-        HIP_TRY(hipMalloc(&d_ir, len * sizeof(float)));
-        hipError_t e = hipMemcpyAsync(d_ir, ir, len * sizeof(float), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = launch_ir_spectrum(d_ir, (int)len, P, nH, ctx->d_tw, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        hipFree(d_ir);
-        if (e != hipSuccess) { hipFree(nH); return fail(OHS_ERR_HIP, hipGetErrorString(e)); }
-    }
-    int rc = conv_grow_ring(c, P, st);
-    if (rc) { hipFree(nH); return rc; }
-    HIP_TRY(hipStreamSynchronize(st));
+    float *d_ir = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&nH, (size_t)P * NF * sizeof(float2)));
+        if (len == 0) {
+            HIP_TRY(hipMemsetAsync(nH, 0, NF * sizeof(float2), st));   // :114-118 mute
+        } else {
+            HIP_TRY(hipMalloc(&d_ir, len * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(d_ir, ir, len * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(launch_ir_spectrum(d_ir, (int)len, P, nH, ctx->d_tw, st));
+        }
+        int rc = conv_grow_ring(c, P, st);
+        if (rc) return rc;
+        // one wait: the spectrum kernel has read d_ir, and nothing queued earlier on `st` still reads the
+        // old d_H[path]
+        HIP_TRY(hipStreamSynchronize(st));
+        return OHS_OK;
+    };
+    const int rc0 = body();
+    if (d_ir) hipFree(d_ir);
+    if (rc0) { if (nH) hipFree(nH); return rc0; }
     hipFree(c.d_H[path]);
     c.d_H[path] = nH;
     c.P[path] = P;
@@ -250,6 +257,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
                 bool allow_fast = true)
 {
+    if (n_blocks <= 0) return OHS_OK;       // nothing to do (k_conv_p1_last would index block -1)
     const bool p1 = c.P[0] == 1 && c.P[1] == 1 && c.P[2] == 1 && c.P[3] == 1;
     if (p1 && allow_fast) {
         // every path has one partition: time-parallel single-FFT-pair kernel
@@ -1254,6 +1262,20 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
         const size_t blk1 = nch == 1 ? n_blocks : (i == nch - 1 ? n_blocks : (size_t)(kCut[i + 1] * (double)n_blocks));
         const size_t off = blk0 * BS;
         const int nb_i = (int)(blk1 - blk0);
+        if (nb_i <= 0) {
+            // two cut points truncated to the same block (OHS_OVERLAP_CUTS experiments): an empty chunk.
+            // Its "done" event is recorded all the same so that a later deferred call's per-chunk wait
+            // finds every event of this call on st2.
+            if (nch > 1 && deferred) {
+                while (b->chunk_done.size() <= (size_t)i) {
+                    hipEvent_t ev;
+                    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    b->chunk_done.push_back(ev);
+                }
+                HIP_TRY(hipEventRecord(b->chunk_done[(size_t)i], b->st2));
+            }
+            continue;
+        }
         if (chunk_waits) HIP_TRY(hipStreamWaitEvent(st, b->chunk_done[(size_t)i], 0));
         rc = span_begin(st, 0); if (rc) return rc;
         rc = eq_launch(b->eq, d_in + off, d_out + off, ss, cs, (long long)nb_i * BS, st);

@@ -20,6 +20,10 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <new>
+#include <set>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -38,11 +42,29 @@ struct Reader {
 
     bool fail(const std::string &m) { if (err.empty()) err = m; return false; }
     bool ok(uint64_t pos, uint64_t n) const { return pos <= f.size() && n <= f.size() - pos; }
+    // Every read of the (untrusted) file image goes through rd() / u8(): out of range reads return 0 and
+    // latch `oob`, which the callers turn into OHS_ERR_PARSE -- nothing indexes `f` unchecked.
+    mutable bool oob = false;
     uint64_t rd(uint64_t pos, int n) const
     {
+        if (n < 0 || n > 8 || !ok(pos, (uint64_t)n)) { oob = true; return 0; }
         uint64_t v = 0;
         for (int i = n - 1; i >= 0; --i) v = (v << 8) | f[pos + i];
         return v;
+    }
+    int u8(uint64_t pos) const
+    {
+        if (!ok(pos, 1)) { oob = true; return 0; }
+        return f[pos];
+    }
+    // limits against hostile files: B-tree nodes visited per dataset, and bytes a dataset may occupy
+    // (zlib cannot expand by more than ~1032:1, so anything beyond that is not backed by file content)
+    static constexpr size_t kMaxBtreeNodes = 1u << 16;
+    static constexpr int kMaxBtreeDepth = 16;
+    uint64_t max_dataset_bytes() const
+    {
+        const uint64_t lim = (uint64_t)f.size() * 1100ull + (1ull << 20);
+        return lim < (1ull << 31) ? lim : (1ull << 31);
     }
 
     struct Msg { int type; uint64_t pos; uint32_t size; };
@@ -51,8 +73,8 @@ struct Reader {
     bool object_messages(uint64_t addr, std::vector<Msg> &out)
     {
         if (!ok(addr, 16) || std::memcmp(&f[addr], "OHDR", 4) != 0) return fail("not a version-2 object header");
-        if (f[addr + 4] != 2) return fail("object header version != 2");
-        const int flags = f[addr + 5];
+        if (u8(addr + 4) != 2) return fail("object header version != 2");
+        const int flags = u8(addr + 5);
         uint64_t p = addr + 6;
         if (flags & 0x20) p += 16;
         if (flags & 0x10) p += 4;
@@ -62,18 +84,20 @@ struct Reader {
         p += szb;
         struct Chunk { uint64_t pos, end; };
         std::vector<Chunk> chunks;
+        if (!ok(p, size0)) return fail("object header chunk out of range");
         chunks.push_back({p, p + size0});
         for (size_t ci = 0; ci < chunks.size() && ci < 64; ++ci) {
             uint64_t q = chunks[ci].pos;
             const uint64_t end = chunks[ci].end;
-            if (!ok(q, end - q)) return fail("object header chunk out of range");
+            if (end < q || !ok(q, end - q)) return fail("object header chunk out of range");
             const int hdr = 4 + ((flags & 4) ? 2 : 0);
             while (q + hdr <= end) {
-                const int type = f[q];
+                const int type = u8(q);
                 const uint32_t sz = (uint32_t)rd(q + 1, 2);
                 q += hdr;
                 if (q + sz > end) break;
                 if (type == 0x10) {   // continuation: offset, length -> "OCHK" ... checksum
+                    if (sz < (uint32_t)(off_size + len_size)) break;
                     const uint64_t coff = rd(q, off_size), clen = rd(q + off_size, len_size);
                     if (ok(coff, clen) && clen >= 8 && std::memcmp(&f[coff], "OCHK", 4) == 0)
                         chunks.push_back({coff + 4, coff + clen - 4});
@@ -90,6 +114,7 @@ struct Reader {
     bool parse_link(uint64_t p, uint64_t limit, std::string &name, uint64_t &addr, uint64_t &consumed)
     {
         const uint64_t p0 = p;
+        if (limit > f.size()) limit = f.size();
         if (p + 2 > limit || f[p] != 1) return false;
         const int flags = f[p + 1];
         p += 2;
@@ -111,6 +136,7 @@ struct Reader {
         } else if (ltype == 1) {       // soft link: length + string
             if (p + 2 > limit) return false;
             p += 2 + rd(p, 2);
+            if (p > limit) return false;
             addr = ~0ull;
         } else return false;
         consumed = p - p0;
@@ -120,10 +146,11 @@ struct Reader {
     // walk the direct blocks of a fractal heap and parse the link messages stored back to back
     void heap_links(uint64_t heap_addr, std::map<std::string, uint64_t> &links)
     {
-        if (!ok(heap_addr, 64) || std::memcmp(&f[heap_addr], "FRHP", 4) != 0) return;
+        if (!ok(heap_addr, 5 + 4 + 1 + 4 + 12 * 8 + 2 + 2 * 8 + 2 + 2 + 8 + 2) ||
+            std::memcmp(&f[heap_addr], "FRHP", 4) != 0) return;
         uint64_t p = heap_addr + 5;
         p += 2 + 2;                        // heap id length, io filter length
-        const int hflags = f[p]; p += 1;
+        const int hflags = u8(p); p += 1;
         p += 4;                            // max size of managed objects
         p += len_size + off_size;          // next huge id, huge btree
         p += len_size + off_size;          // free space, free space manager
@@ -136,11 +163,12 @@ struct Reader {
         p += 2;                            // starting rows in root indirect block
         const uint64_t root = rd(p, off_size); p += off_size;
         const uint64_t cur_rows = rd(p, 2);
+        if (max_heap_bits > 64) return;   // corrupt heap header
         const int boff = (int)((max_heap_bits + 7) / 8);
         const bool cksum = (hflags & 2) != 0;
 
         auto scan_direct = [&](uint64_t baddr, uint64_t bsize) {
-            if (!ok(baddr, bsize) || std::memcmp(&f[baddr], "FHDB", 4) != 0) return;
+            if (bsize < 16 || !ok(baddr, bsize) || std::memcmp(&f[baddr], "FHDB", 4) != 0) return;
             uint64_t q = baddr + 5 + off_size + boff + (cksum ? 4 : 0);
             const uint64_t end = baddr + bsize;
             while (q + 4 < end && f[q] == 1) {
@@ -159,7 +187,7 @@ struct Reader {
         for (uint64_t s = start_block; s < max_direct && max_direct_rows < 48; s <<= 1) ++max_direct_rows;
         for (uint64_t r = 0; r < cur_rows && r < max_direct_rows; ++r) {
             const uint64_t bsize = r < 2 ? start_block : start_block << (r - 1);
-            for (uint64_t k = 0; k < width; ++k) {
+            for (uint64_t k = 0; k < width && k < 4096; ++k) {
                 if (!ok(q, off_size)) return;
                 const uint64_t a = rd(q, off_size);
                 q += off_size;
@@ -178,7 +206,8 @@ struct Reader {
                 if (parse_link(m.pos, m.pos + m.size, name, a, used) && a != ~0ull) links[name] = a;
             } else if (m.type == 0x02) {   // link info -> fractal heap
                 uint64_t p = m.pos + 2;
-                if (f[m.pos + 1] & 1) p += 8;
+                if (u8(m.pos + 1) & 1) p += 8;
+                if (p + (uint64_t)off_size > m.pos + m.size) continue;
                 const uint64_t heap = rd(p, off_size);
                 if (heap != ~0ull) heap_links(heap, links);
             }
@@ -204,6 +233,7 @@ struct Reader {
 
     bool parse_type(uint64_t p, TypeInfo &t)
     {
+        if (!ok(p, 8)) { oob = true; return false; }
         t.cls = f[p] & 0x0f;
         t.big_endian = (f[p + 1] & 1) != 0;
         t.is_signed = (f[p + 1] & 8) != 0;
@@ -233,30 +263,43 @@ struct Reader {
         uint64_t compact_pos = 0;
         for (const Msg &m : msgs) {
             const uint64_t p = m.pos;
+            const uint64_t mend = m.pos + m.size;        // every cursor below stays inside [p, mend)
+            if (!ok(p, m.size)) return fail("message out of range");
             if (m.type == 0x01) {
+                if (m.size < 4) return fail("truncated dataspace message");
                 const int ver = f[p], rank = f[p + 1];
                 uint64_t q = p + (ver == 1 ? 8 : 4);
+                if (rank > 8 || q + (uint64_t)rank * len_size > mend) return fail("bad dataspace message");
                 ds.dims.clear();
                 for (int i = 0; i < rank; ++i) { ds.dims.push_back(rd(q, len_size)); q += len_size; }
             } else if (m.type == 0x03) {
+                if (m.size < 8) return fail("truncated datatype message");
                 parse_type(p, ty);
             } else if (m.type == 0x08) {
+                if (m.size < 4) return fail("truncated data layout message");
                 const int ver = f[p];
                 if (ver != 3) return fail("unsupported data layout message version " + std::to_string(ver));
                 layout_class = f[p + 1];
-                if (layout_class == 0) { data_size = rd(p + 2, 2); compact_pos = p + 4; }
-                else if (layout_class == 1) { data_addr = rd(p + 2, off_size); data_size = rd(p + 2 + off_size, len_size); }
-                else if (layout_class == 2) {
+                if (layout_class == 0) {
+                    data_size = rd(p + 2, 2); compact_pos = p + 4;
+                    if (compact_pos + data_size > mend) return fail("compact data exceeds its message");
+                } else if (layout_class == 1) {
+                    if (p + 2 + (uint64_t)off_size + len_size > mend) return fail("truncated data layout message");
+                    data_addr = rd(p + 2, off_size); data_size = rd(p + 2 + off_size, len_size);
+                } else if (layout_class == 2) {
                     const int nd = f[p + 2];
+                    if (nd > 9 || p + 3 + (uint64_t)off_size + 4ull * nd > mend) return fail("bad chunked layout message");
                     btree = rd(p + 3, off_size);
                     uint64_t q = p + 3 + off_size;
                     chunk_dims.clear();
                     for (int i = 0; i < nd; ++i) { chunk_dims.push_back(rd(q, 4)); q += 4; }
                 }
             } else if (m.type == 0x0B) {
+                if (m.size < 2) return fail("truncated filter pipeline message");
                 const int ver = f[p], nf = f[p + 1];
                 uint64_t q = p + (ver == 1 ? 8 : 2);
                 for (int i = 0; i < nf; ++i) {
+                    if (q + 8 > mend) return fail("filter pipeline exceeds its message");
                     const int id = (int)rd(q, 2); q += 2;
                     uint64_t nl = 0;
                     if (ver == 1 || id >= 256) { nl = rd(q, 2); q += 2; }
@@ -265,36 +308,44 @@ struct Reader {
                     if (ver == 1) nl = (nl + 7) & ~7ull;
                     q += nl + 4 * ncd;
                     if (ver == 1 && (ncd & 1)) q += 4;
+                    if (q > mend) return fail("filter pipeline exceeds its message");
                     filters.push_back(id);
                     if (filters.size() > 32) return fail("filter pipeline too long");   // the chunk filter mask has 32 bits
                 }
             } else if (m.type == 0x0C) {     // attribute: keep fixed-length string values
+                if (m.size < 9) continue;
                 const int ver = f[p];
                 const uint64_t nsz = rd(p + 2, 2), tsz = rd(p + 4, 2), ssz = rd(p + 6, 2);
                 uint64_t q = p + 8 + (ver == 3 ? 1 : 0);
                 auto pad = [&](uint64_t v) { return ver == 1 ? (v + 7) & ~7ull : v; };
-                if (q + pad(nsz) + pad(tsz) + pad(ssz) > p + m.size) continue;
+                if (q + pad(nsz) + pad(tsz) + pad(ssz) > mend || tsz < 8) continue;
                 std::string an((const char *)&f[q], (size_t)nsz);
                 while (!an.empty() && an.back() == '\0') an.pop_back();
                 const uint64_t tq = q + pad(nsz);
-                TypeInfo at; parse_type(tq, at);
+                TypeInfo at;
+                if (!parse_type(tq, at)) continue;
                 const uint64_t dq = tq + pad(tsz) + pad(ssz);
-                if (at.cls == 3 && dq + at.size <= p + m.size) {
+                if (at.cls == 3 && dq + at.size <= mend) {
                     std::string v((const char *)&f[dq], at.size);
                     while (!v.empty() && (v.back() == '\0' || v.back() == ' ')) v.pop_back();
                     ds.str_attrs[an] = v;
                 }
             }
         }
+        if (oob) return fail("truncated or corrupt object header message");
         if (ty.cls != 0 && ty.cls != 1) return fail("unsupported datatype class");
         if (ty.size != 1 && ty.size != 2 && ty.size != 4 && ty.size != 8) return fail("unsupported element size");
         uint64_t count = 1;
-        for (uint64_t d : ds.dims) count *= d;
-        if (count > (1ull << 31)) return fail("dataset too large");
+        for (uint64_t d : ds.dims) {
+            if (d != 0 && count > (1ull << 31) / d) return fail("dataset too large");
+            count *= d;
+        }
+        if (count * ty.size > max_dataset_bytes()) return fail("dataset larger than the file can back");
         std::vector<uint8_t> raw(count * ty.size, 0);
         if (layout_class == 0) {
             if (data_size > raw.size()) data_size = raw.size();
-            std::memcpy(raw.data(), &f[compact_pos], data_size);
+            if (!ok(compact_pos, data_size)) return fail("compact data out of range");
+            if (data_size) std::memcpy(raw.data(), &f[compact_pos], data_size);
         } else if (layout_class == 1) {
             if (data_addr != ~0ull) {
                 if (!ok(data_addr, raw.size())) return fail("contiguous data out of range");
@@ -304,14 +355,26 @@ struct Reader {
             const size_t rank = ds.dims.size();
             if (chunk_dims.size() != rank + 1) return fail("chunk dimensionality mismatch");
             uint64_t chunk_elems = 1;
-            for (size_t i = 0; i < rank; ++i) chunk_elems *= chunk_dims[i];
+            for (size_t i = 0; i < rank; ++i) {
+                if (chunk_dims[i] == 0) return fail("zero chunk dimension");
+                if (chunk_elems > (1ull << 31) / chunk_dims[i]) return fail("chunk too large");
+                chunk_elems *= chunk_dims[i];
+            }
             const size_t chunk_bytes = chunk_elems * ty.size;
-            // iterative walk of the version-1 B-tree (node type 1)
-            std::vector<uint64_t> stack;
-            if (btree != ~0ull) stack.push_back(btree);
+            if (chunk_bytes > max_dataset_bytes()) return fail("chunk larger than the file can back");
+            // iterative walk of the version-1 B-tree (node type 1); a node may be visited once, the tree
+            // may not be deeper than kMaxBtreeDepth and may not hold more than kMaxBtreeNodes nodes
+            struct Item { uint64_t node; int depth; };
+            std::vector<Item> stack;
+            std::set<uint64_t> seen;
+            if (btree != ~0ull) stack.push_back({btree, 0});
             while (!stack.empty()) {
-                const uint64_t node = stack.back();
+                const uint64_t node = stack.back().node;
+                const int depth = stack.back().depth;
                 stack.pop_back();
+                if (depth > kMaxBtreeDepth) return fail("chunk B-tree too deep");
+                if (seen.size() >= kMaxBtreeNodes) return fail("chunk B-tree has too many nodes");
+                if (!seen.insert(node).second) return fail("chunk B-tree revisits a node (cycle)");
                 if (!ok(node, 24) || std::memcmp(&f[node], "TREE", 4) != 0 || f[node + 4] != 1)
                     return fail("bad chunk B-tree node");
                 const int level = f[node + 5];
@@ -325,15 +388,17 @@ struct Reader {
                     for (size_t i = 0; i < rank; ++i) coff[i] = rd(q + 8 + 8 * i, 8);
                     const uint64_t child = rd(q + key_size, off_size);
                     q += key_size + off_size;
-                    if (level > 0) { stack.push_back(child); continue; }
+                    if (level > 0) { stack.push_back({child, depth + 1}); continue; }
+                    if (csize > max_dataset_bytes()) return fail("chunk out of range");
                     if (!ok(child, csize)) return fail("chunk out of range");
                     std::vector<uint8_t> buf(&f[child], &f[child] + csize), tmp;
                     for (int fi = (int)filters.size() - 1; fi >= 0; --fi) {
-                        if (fmask & (1u << fi)) continue;
+                        if (fi < 32 && (fmask & (1u << fi))) continue;
                         if (filters[fi] == 1) {              // deflate
                             if (!inflate_buf(buf.data(), buf.size(), tmp, chunk_bytes)) return false;
                             buf.swap(tmp);
                         } else if (filters[fi] == 2) {       // shuffle
+                            if (fi >= 32) return fail("filter pipeline too long");
                             const size_t n = buf.size() / ty.size;
                             tmp.resize(buf.size());
                             for (size_t i = 0; i < n; ++i)
@@ -421,11 +486,9 @@ int ohs_sofa_cartesian_to_spherical(const float xyz[3], float az_el_r[3])
     return OHS_OK;
 }
 
-int ohs_sofa_open(const char *path, ohs_sofa **out)
+static int sofa_open_impl(const char *path, ohs_sofa **out)
 {
     using namespace ohs_sofa_detail;
-    if (!path || !out) return sfail(OHS_ERR_INVALID_ARG, "NULL argument");
-    *out = nullptr;
     FILE *fp = std::fopen(path, "rb");
     if (!fp) return sfail(OHS_ERR_IO, std::string("cannot open ") + path);   // SofaError::FileOpen (loader.rs:92-99)
     Reader rd;
@@ -444,6 +507,7 @@ int ohs_sofa_open(const char *path, ohs_sofa **out)
     rd.len_size = rd.f[10];
     if (rd.off_size != 8 || rd.len_size != 8) return sfail(OHS_ERR_PARSE, "only 8-byte HDF5 offsets/lengths supported");
     const uint64_t root = rd.rd(12 + 3 * 8, 8);
+    if (rd.oob) return sfail(OHS_ERR_PARSE, "truncated superblock");
     std::map<std::string, uint64_t> links;
     if (!rd.root_links(root, links)) return sfail(OHS_ERR_PARSE, "root group: " + rd.err);
     auto get = [&](const char *name, Dataset &ds) -> bool {
@@ -456,9 +520,12 @@ int ohs_sofa_open(const char *path, ohs_sofa **out)
         return sfail(OHS_ERR_PARSE, rd.err);
     if (ir.dims.size() != 3 || sp.dims.size() != 2 || sp.dims[1] != 3 || sr.values.empty())
         return sfail(OHS_ERR_PARSE, "unexpected SOFA dataset shapes (need Data.IR [M][R][N], SourcePosition [M][3])");
-    ohs_sofa *s = new ohs_sofa();
+    if (sp.dims[0] != ir.dims[0] && sp.dims[0] != 1) return sfail(OHS_ERR_PARSE, "SourcePosition rows != M");
+    if (ir.values.size() != ir.dims[0] * ir.dims[1] * ir.dims[2] || sp.values.size() != sp.dims[0] * 3)
+        return sfail(OHS_ERR_PARSE, "dataset size does not match its dimensions");
+    std::unique_ptr<ohs_sofa> hold(new ohs_sofa());
+    ohs_sofa *s = hold.get();
     s->M = (size_t)ir.dims[0]; s->R = (size_t)ir.dims[1]; s->N = (size_t)ir.dims[2];
-    if (sp.dims[0] != ir.dims[0] && sp.dims[0] != 1) { delete s; return sfail(OHS_ERR_PARSE, "SourcePosition rows != M"); }
     s->fs = (float)sr.values[0];
     s->ir.resize(ir.values.size());
     for (size_t i = 0; i < ir.values.size(); ++i) s->ir[i] = (float)ir.values[i];
@@ -487,14 +554,34 @@ int ohs_sofa_open(const char *path, ohs_sofa **out)
     }
     s->delay.assign(s->M * s->R, 0.f);
     if (links.count("Data.Delay")) {
+        // [1][R] (one delay per receiver for every measurement) or [M][R]; any other shape is ignored
+        // (delays stay 0) rather than indexed -- a dims[0] that is neither 1 nor M would read past the end
         Dataset d;
-        if (rd.read_dataset(links["Data.Delay"], d) && d.dims.size() == 2 && d.dims[1] == s->R)
+        if (rd.read_dataset(links["Data.Delay"], d) && d.dims.size() == 2 && d.dims[1] == s->R &&
+            (d.dims[0] == 1 || d.dims[0] == s->M) && d.values.size() == d.dims[0] * s->R)
             for (size_t m = 0; m < s->M; ++m)
                 for (size_t r = 0; r < s->R; ++r)
                     s->delay[m * s->R + r] = (float)d.values[(d.dims[0] == 1 ? 0 : m) * s->R + r];
     }
-    *out = s;
+    *out = hold.release();
     return OHS_OK;
+}
+
+// nothing may unwind across the C ABI: allocation failures and anything else thrown while parsing an
+// untrusted file become status codes
+int ohs_sofa_open(const char *path, ohs_sofa **out)
+{
+    if (!path || !out) return sfail(OHS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    try {
+        return sofa_open_impl(path, out);
+    } catch (const std::bad_alloc &) {
+        return sfail(OHS_ERR_ALLOC, "out of memory while reading the SOFA file");
+    } catch (const std::exception &e) {
+        return sfail(OHS_ERR_PARSE, std::string("malformed SOFA file: ") + e.what());
+    } catch (...) {
+        return sfail(OHS_ERR_PARSE, "malformed SOFA file");
+    }
 }
 
 void ohs_sofa_close(ohs_sofa *s) { delete s; }

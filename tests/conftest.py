@@ -19,14 +19,16 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no built library (it is git-ignored): build it in-tree once, if hipcc is here.
-    (hipcc cross-compiles without a GPU; on the GPU box the prebuilt .so travels with the snapshot.)"""
+    """The library is git-ignored and ships prebuilt to the GPU box, so a stale binary could be tested
+    silently against newer sources.  Always run the (content-hash incremental) build; if it cannot run or
+    fails, the session ends loudly unless the existing library is provably built from this tree."""
     from open_headstage_amd import build as _build
-    if not os.path.exists(_build.LIB):
-        try:
-            _build.build()
-        except Exception as e:      # noqa: BLE001 -- the tests that need the library will say so themselves
-            print(f"conftest: could not build {_build.LIB}: {e}", file=sys.stderr)
+    try:
+        _build.build()
+    except Exception as e:      # noqa: BLE001
+        if not _build.is_current():
+            pytest.exit(f"conftest: libohs_hip.so is missing or stale and could not be rebuilt: {e}", returncode=3)
+        print(f"conftest: build step failed ({e}); the existing library matches the sources", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")

@@ -3,6 +3,8 @@
 //       -Iopen_headstage_amd/csrc -o /tmp/ohs_fuzz tools/fuzz_host_parsers.cpp \\
 //       open_headstage_amd/csrc/sofa_reader.cpp open_headstage_amd/csrc/autoeq_parser.cpp -lz
 //   /tmp/ohs_fuzz <some.sofa> [iterations]
+// Round 2: bounds-checked reads, B-tree visit limits, size caps and try/catch at the ABI after the advisor's
+// Data.Delay [2][R] over-read; `--open` mode runs single regression files (tests/test_cpu_parsers_asan.py).
 // Round 1: found one shift-by-corrupt-count (fixed, with a guard on corrupt heap headers); then 6 000 mutated
 // copies of the CIPIC subject-003 file and 20 000 mutated CSV texts without a report.
 #include "ohs_hip.h"
@@ -18,9 +20,31 @@ static thread_local std::string g_err;
 extern "C" void ohs_internal_set_error(const char *m) { g_err = m ? m : ""; }
 extern "C" const char *ohs_last_error(void) { return g_err.c_str(); }
 
+// open one file and touch every accessor (what a host does with a file it was handed)
+static int exercise(const char *path)
+{
+    ohs_sofa *s = nullptr;
+    const int rc = ohs_sofa_open(path, &s);
+    if (rc != OHS_OK) return rc;
+    size_t M = 0, R = 0, N = 0; float fs = 0;
+    ohs_sofa_info(s, &M, &R, &N, &fs);
+    std::vector<float> l(N + 1), r(N + 1); float dl, dr; size_t idx;
+    ohs_sofa_nearest(s, 30.f, 0.f, 1.f, &idx);
+    ohs_sofa_get_hrtf_irs(s, -30.f, 10.f, 1.f, l.data(), r.data(), N, &dl, &dr);
+    float p3[3]; if (M) ohs_sofa_position(s, M - 1, p3);
+    ohs_sofa_close(s);
+    return OHS_OK;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc < 2) { printf("usage: %s <file.sofa> [iterations | --open]\n", argv[0]); return 2; }
     const char *src = argv[1];
+    if (argc > 2 && !strcmp(argv[2], "--open")) {      // regression inputs: one file, as it is
+        const int rc = exercise(src);
+        printf("open: status %d (%s)\n", rc, rc ? ohs_last_error() : "ok");
+        return 0;
+    }
     const int iters = argc > 2 ? atoi(argv[2]) : 300;
     std::vector<unsigned char> good = slurp(src);
     if (good.empty()) { printf("cannot read %s\n", src); return 2; }
@@ -42,19 +66,19 @@ int main(int argc, char **argv)
             const unsigned long long v = (rng() & 1) ? ~0ull : (1ull << (rng() % 63));
             memcpy(&m[o], &v, (rng() & 1) ? 8 : 4);
         }
+        if (it % 16 == 5) {                    // structure-aware: grow / zero a dimension or a count near a known tag
+            static const char *tags[] = {"TREE", "OHDR", "FRHP", "FHDB", "OCHK"};
+            const char *tag = tags[rng() % 5];
+            std::vector<size_t> hits;
+            for (size_t o = 0; o + 4 < std::min<size_t>(m.size(), 1u << 20); ++o)
+                if (!memcmp(&m[o], tag, 4)) hits.push_back(o);
+            if (!hits.empty()) {
+                const size_t o = hits[rng() % hits.size()] + 4 + rng() % 40;
+                if (o + 8 < m.size()) { const unsigned long long v = rng() & 3 ? rng() % 70000 : ~0ull; memcpy(&m[o], &v, 1 + rng() % 8); }
+            }
+        }
         FILE *f = fopen("/tmp/ohs_fuzz_mut.sofa", "wb"); fwrite(m.data(), 1, m.size(), f); fclose(f);
-        ohs_sofa *s = nullptr;
-        const int rc = ohs_sofa_open("/tmp/ohs_fuzz_mut.sofa", &s);
-        if (rc == OHS_OK) {
-            size_t M = 0, R = 0, N = 0; float fs = 0;
-            ohs_sofa_info(s, &M, &R, &N, &fs);
-            std::vector<float> l(N + 1), r(N + 1); float dl, dr; size_t idx;
-            ohs_sofa_nearest(s, 30.f, 0.f, 1.f, &idx);
-            ohs_sofa_get_hrtf_irs(s, -30.f, 10.f, 1.f, l.data(), r.data(), N, &dl, &dr);
-            float p3[3]; if (M) ohs_sofa_position(s, M - 1, p3);
-            ohs_sofa_close(s);
-            ++ok;
-        } else ++bad;
+        if (exercise("/tmp/ohs_fuzz_mut.sofa") == OHS_OK) ++ok; else ++bad;
     }
     printf("sofa: %d mutated files opened, %d rejected, no crash\n", ok, bad);
     // AutoEQ CSV
