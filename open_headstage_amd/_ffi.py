@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libohs_hip.so")
+# OHS_LIB: load an experiment variant built by `OHS_BUILD_TAG=... python -m open_headstage_amd.build`
+LIB_PATH = os.environ.get("OHS_LIB") or os.path.join(HERE, "libohs_hip.so")
 
 OHS_OK = 0
 OHS_ERR_INVALID_ARG = 1

@@ -22,9 +22,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libohs_hip.so")
-STAMP = os.path.join(HERE, "libohs_hip.stamp")
+# Experiment variants: OHS_BUILD_TAG=name OHS_EXTRA_DEFS="-DFOO=1 ..." builds libohs_hip_name.so beside the
+# product library (objects under build/name/); OHS_LIB=<path> makes _ffi.py load it.  Not used in production.
+TAG = os.environ.get("OHS_BUILD_TAG", "")
+EXTRA_DEFS = os.environ.get("OHS_EXTRA_DEFS", "").split()
+OBJ = os.path.join(HERE, "build", TAG) if TAG else os.path.join(HERE, "build")
+LIB = os.path.join(HERE, f"libohs_hip_{TAG}.so" if TAG else "libohs_hip.so")
+STAMP = os.path.join(HERE, f"libohs_hip_{TAG}.stamp" if TAG else "libohs_hip.stamp")
 ARCH = "gfx950"
 
 
@@ -65,7 +69,7 @@ def _deps(src: str) -> list[str]:
 
 def _unit_hash(src: str, extra: list[str]) -> str:
     h = hashlib.sha256()
-    h.update(" ".join(COMMON + extra).encode())
+    h.update(" ".join(COMMON + extra + EXTRA_DEFS).encode())
     for d in _deps(src):
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
@@ -103,7 +107,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or _read_obj_hash(obj) != want[src]:
-            cmd = [hipcc, *COMMON, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc, *COMMON, *extra, *EXTRA_DEFS, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

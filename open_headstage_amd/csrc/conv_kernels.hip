@@ -381,16 +381,39 @@ hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2,
     return hipGetLastError();
 }
 
-// main kernel: blocks [0, n_main) of every stream in merged form (n_main = n_blocks - 1).
-// 14 waves per workgroup, one workgroup per CU: 17 KiB twiddle tables + 16 KiB combined spectra
-// (C, D) shared in LDS + 14 x 8.5 KiB FFT slabs = 152 KiB of the CU's 160; 124 VGPRs (this file is built
-// with -fno-slp-vectorize, see conv_mac_kernels.hip) => up to 4 waves per SIMD.  Measured on config 3
-// without EQ: C, D in 64 VGPRs per lane, 2 waves per SIMD 1.07 ms; C, D in LDS, 12 waves 0.97 ms;
-// without the SLP vectoriser's register moves 0.88 ms; 14 waves 0.84 ms.
+// Launch structure (`out` is written exactly once, in place allowed):
+//   1. k_conv_p1_edges -- everything that needs a block's INPUT before the main kernel may overwrite it in place:
+//        wave (s, e), e = 1..K-1 : the overlap tail leaving block b0(e) - 1, i.e. entering chunk e  -> chunk_tails
+//        wave (s, 0)             : the launch's LAST block, in the reference's four-overlap form (two packed
+//                                  inverse transforms) so that the state at rest is the general kernel's format and
+//                                  a later per-path set_ir can zero exactly one path's overlap (convolution.rs:138);
+//                                  its incoming overlap is recomputed from block n_blocks - 2
+//   2. k_conv_p1       -- blocks [0, n_blocks - 1): K chunks per stream as independent waves, one forward + one
+//                         inverse transform per block, incoming overlap from chunk_tails (chunk 0: the saved state).
+// Round 1 added the chunk-boundary tails afterwards with a read-modify-write pass over `out` (k_conv_p1_fixup);
+// recomputing 1 block in ~34 instead costs less than that pass and its traffic.
 #ifndef OHS_P1_WAVES
 #define OHS_P1_WAVES 14
 #endif
 constexpr int kP1Waves = OHS_P1_WAVES;   // waves per workgroup = per CU (LDS: 33 KiB of tables + 8.5 KiB per wave)
+
+// W = Z C + conj(Zm) D for the 16 registers of a lane, written over the mirror values (cd: LDS, [2][16][64])
+__device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float2 (&w)[16], const float2 *cd, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float2 zz = z[r], m = w[r];
+        const float2 c = lds_ld(&cd[r * 64 + lane]), d = lds_ld(&cd[kFft + r * 64 + lane]);
+        w[r].x = zz.x * c.x - zz.y * c.y + m.x * d.x + m.y * d.y;
+        w[r].y = zz.x * c.y + zz.y * c.x + m.x * d.y - m.y * d.x;
+    }
+}
+
+__device__ __forceinline__ int p1_chunk_begin(int ck, int n_main, int chunks)
+{
+    return (int)((long long)ck * n_main / chunks);
+}
+
 __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -403,99 +426,137 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
         for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) dst[i] = src[i];
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave-uniform quantities are forced into SGPRs: stream, chunk, block range and the four audio base
+    // pointers then cost no VGPRs and the address arithmetic runs on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + 2 * kFft + wave * kWaveLdsComplex;
     const long long gw = (long long)blockIdx.x * kP1Waves + wave;
     if (gw >= (long long)A.n_streams * A.chunks) return;
-    const size_t s = (size_t)(gw / A.chunks);
+    const int s = (int)(gw / A.chunks);
     const int ck = (int)(gw % A.chunks);
     const int n_main = A.n_blocks - 1;
-    const int b0 = (int)((long long)ck * n_main / A.chunks);
-    const int b1 = (int)((long long)(ck + 1) * n_main / A.chunks);
+    const int b0 = p1_chunk_begin(ck, n_main, A.chunks);
+    const int b1 = p1_chunk_begin(ck + 1, n_main, A.chunks);
     if (b0 >= b1) return;
 
-    const float *in_l = A.in + s * A.in_stream_stride;
+    const float *in_l = A.in + (size_t)s * A.in_stream_stride;
     const float *in_r = in_l + A.in_ch_stride;
-    float *out_l = A.out + s * A.out_stream_stride;
+    float *out_l = A.out + (size_t)s * A.out_stream_stride;
     float *out_r = out_l + A.out_ch_stride;
-    const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
     const float scale = 1.0f / (float)kFft;
 
     float2 tail[8];
+    if (ck == 0) {
+        const float2 *tails = A.tails + (size_t)s * (2 * 8 * 64);
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        if (b0 == 0) {
+        for (int a = 0; a < 8; ++a) {
             const float2 t1 = tails[a * 64 + lane], t2 = tails[(8 + a) * 64 + lane];
             tail[a] = make_float2(t1.x + t2.x, t1.y + t2.y);
-        } else {
-            tail[a] = make_float2(0.0f, 0.0f);      // k_conv_p1_fixup adds the previous chunk's tail
         }
+    } else {
+        const float2 *ct = A.chunk_tails + ((size_t)s * A.chunks + ck) * (size_t)(8 * 64);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) tail[a] = ct[a * 64 + lane];
     }
     for (int t = b0; t < b1; ++t) {
+        const unsigned base = (unsigned)t * kBlock + lane;      // frames per call < 2^32 (host-checked)
         float2 v[16];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-            v[a] = make_float2(in_l[idx], in_r[idx]);
+            v[a] = make_float2(in_l[base + 64 * a], in_r[base + 64 * a]);
             v[a + 8] = make_float2(0.0f, 0.0f);
         }
-        wave_fft_fwd(v, lds, tab, lane);
         float2 w[16];
+#ifdef OHS_P1_BPERMUTE_MIRROR
+        wave_fft_fwd(v, lds, tab, lane);
         wave_mirror(v, w, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // W = Z C + conj(Zm) D, written over the mirror value
-            const float2 z = v[r], m = w[r];
-            const float2 c = cd[r * 64 + lane], d = cd[kFft + r * 64 + lane];
-            w[r].x = z.x * c.x - z.y * c.y + m.x * d.x + m.y * d.y;
-            w[r].y = z.x * c.y + z.y * c.x + m.x * d.y - m.y * d.x;
-        }
+#else
+        wave_fft_fwd_mirror(v, w, lds, tab, lane);
+#endif
+        p1_spectral_product(v, w, cd, lane);
         wave_fft_inv(w, lds, tab, lane);
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-            out_l[idx] = (w[a].x * scale + tail[a].x) * A.gain;
-            out_r[idx] = (w[a].y * scale + tail[a].y) * A.gain;
+            out_l[base + 64 * a] = (w[a].x * scale + tail[a].x) * A.gain;
+            out_r[base + 64 * a] = (w[a].y * scale + tail[a].y) * A.gain;
             tail[a] = make_float2(w[a + 8].x * scale, w[a + 8].y * scale);
         }
     }
-    // the tail leaving EVERY chunk is published: the next chunk's first block (fix-up kernel) or the
-    // launch's last block (k_conv_p1_last) adds it
-    float2 *ct = A.chunk_tails + (s * A.chunks + ck) * (size_t)(8 * 64);
-#pragma unroll
-    for (int a = 0; a < 8; ++a) ct[a * 64 + lane] = tail[a];
 }
 
-// last block of the launch, one wave per stream: four separate overlap tails, as the general kernel
-// keeps them (two packed inverse transforms)
-__global__ __launch_bounds__(256) void k_conv_p1_last(const ConvP1Args A)
+// pre-pass, 4 waves per workgroup: wave (s, e) as described above
+__global__ __launch_bounds__(256) void k_conv_p1_edges(const ConvP1Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
+    float2 *cd = smem + kTabComplex;
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(A.CD);
+        float4 *dst = reinterpret_cast<float4 *>(cd);
+        for (int i = threadIdx.x; i < kFft; i += 256) dst[i] = src[i];
+    }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
-    const long long s_ = (long long)blockIdx.x * 4 + wave;
-    if (s_ >= A.n_streams) return;
-    const size_t s = (size_t)s_;
-    const int t = A.n_blocks - 1;
-    const float *in_l = A.in + s * A.in_stream_stride;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2 *lds = smem + kTabComplex + 2 * kFft + wave * kWaveLdsComplex;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    if (gw >= (long long)A.n_streams * A.chunks) return;
+    const int s = (int)(gw / A.chunks);
+    const int e = (int)(gw % A.chunks);
+    const int n_main = A.n_blocks - 1;
+    const float *in_l = A.in + (size_t)s * A.in_stream_stride;
     const float *in_r = in_l + A.in_ch_stride;
-    float *out_l = A.out + s * A.out_stream_stride;
-    float *out_r = out_l + A.out_ch_stride;
-    const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
-    float2 *tails_out = A.tails_out + s * (size_t)(2 * 8 * 64);
     const float scale = 1.0f / (float)kFft;
+
+    // overlap tail leaving block t in merged form: (lsl + rsl) + j (lsr + rsr), time layout
+    auto merged_tail = [&](int t, float2 (&tl)[8]) {
+        const unsigned base = (unsigned)t * kBlock + lane;
+        float2 v[16], w[16];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            v[a] = make_float2(in_l[base + 64 * a], in_r[base + 64 * a]);
+            v[a + 8] = make_float2(0.0f, 0.0f);
+        }
+        wave_fft_fwd_mirror(v, w, lds, tab, lane);
+        p1_spectral_product(v, w, cd, lane);
+        wave_fft_inv(w, lds, tab, lane);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) tl[a] = make_float2(w[a + 8].x * scale, w[a + 8].y * scale);
+    };
+
+    if (e > 0) {
+        const int b0 = p1_chunk_begin(e, n_main, A.chunks);      // chunks <= n_main (host): b0 >= 1
+        float2 tl[8];
+        merged_tail(b0 - 1, tl);
+        float2 *ct = A.chunk_tails + ((size_t)s * A.chunks + e) * (size_t)(8 * 64);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) ct[a * 64 + lane] = tl[a];
+        return;
+    }
+    // e == 0: the last block of the launch
+    const int t = A.n_blocks - 1;
+    const float2 *tails = A.tails + (size_t)s * (2 * 8 * 64);
+    float2 *tails_out = A.tails_out + (size_t)s * (2 * 8 * 64);
+    float2 tin[8];
+    if (A.n_blocks == 1) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const float2 t1 = tails[a * 64 + lane], t2 = tails[(8 + a) * 64 + lane];
+            tin[a] = make_float2(t1.x + t2.x, t1.y + t2.y);
+        }
+    } else {
+        merged_tail(t - 1, tin);
+    }
+    float *out_l = A.out + (size_t)s * A.out_stream_stride;
+    float *out_r = out_l + A.out_ch_stride;
+    const unsigned base = (unsigned)t * kBlock + lane;
     float2 v[16], zm[16];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-        const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-        v[a] = make_float2(in_l[idx], in_r[idx]);
+        v[a] = make_float2(in_l[base + 64 * a], in_r[base + 64 * a]);
         v[a + 8] = make_float2(0.0f, 0.0f);
     }
-    wave_fft_fwd(v, lds, tab, lane);
-    wave_mirror(v, zm, lane);
+    wave_fft_fwd_mirror(v, zm, lds, tab, lane);
     float2 acc1[16], acc2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -510,69 +571,43 @@ __global__ __launch_bounds__(256) void k_conv_p1_last(const ConvP1Args A)
     }
     wave_fft_inv(acc1, lds, tab, lane);
     wave_fft_inv(acc2, lds, tab, lane);
-    // incoming overlap: the saved state for a one-block launch, else what the main kernel's last chunk left
-    const float2 *ct = A.chunk_tails + (s * A.chunks + (size_t)(A.chunks - 1)) * (size_t)(8 * 64);
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-        float2 tin;
-        if (A.n_blocks == 1) {
-            const float2 t1 = tails[a * 64 + lane], t2 = tails[(8 + a) * 64 + lane];
-            tin = make_float2(t1.x + t2.x, t1.y + t2.y);
-        } else {
-            tin = ct[a * 64 + lane];
-        }
-        const size_t idx = (size_t)t * kBlock + 64 * a + lane;
-        out_l[idx] = ((acc1[a].x * scale + tin.x) + acc2[a].x * scale) * A.gain;
-        out_r[idx] = ((acc1[a].y * scale + tin.y) + acc2[a].y * scale) * A.gain;
+        out_l[base + 64 * a] = ((acc1[a].x * scale + tin[a].x) + acc2[a].x * scale) * A.gain;
+        out_r[base + 64 * a] = ((acc1[a].y * scale + tin[a].y) + acc2[a].y * scale) * A.gain;
         tails_out[a * 64 + lane] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
         tails_out[(8 + a) * 64 + lane] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
     }
-}
-
-// out[first block of chunk ck] += gain * (tail leaving chunk ck-1), ck = 1..chunks-1
-__global__ __launch_bounds__(256) void k_conv_p1_fixup(const ConvP1Args A)
-{
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;   // over S * (K-1) * 512
-    const long long per_stream = (long long)(A.chunks - 1) * 512;
-    if (gid >= (long long)A.n_streams * per_stream) return;
-    const size_t s = (size_t)(gid / per_stream);
-    const int rem = (int)(gid % per_stream);
-    const int ck = 1 + rem / 512, i = rem % 512;
-    const int b0 = (int)((long long)ck * (A.n_blocks - 1) / A.chunks);
-    // chunks <= n_blocks - 1 (host-checked), so every chunk is non-empty and wrote its tail
-    const float2 t = A.chunk_tails[(s * A.chunks + (ck - 1)) * (size_t)512 + i];
-    float *out_l = A.out + s * A.out_stream_stride;
-    float *out_r = out_l + A.out_ch_stride;
-    const size_t idx = (size_t)b0 * kBlock + i;
-    out_l[idx] += t.x * A.gain;
-    out_r[idx] += t.y * A.gain;
 }
 
 int conv_p1_waves_per_cu() { return kP1Waves; }
 
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
 {
-    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
-    hipError_t e = hipSuccess;
-    if (a.n_blocks > 1) {       // blocks [0, n_blocks - 1): `chunks` independent waves per stream
+    if (a.n_blocks <= 0 || a.n_streams <= 0 || a.chunks < 1) return hipErrorInvalidValue;
+    if (a.n_blocks > 1 && a.chunks > a.n_blocks - 1) return hipErrorInvalidValue;
+    if ((unsigned long long)a.n_blocks * kBlock >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit frame offsets
+    {   // 1. boundary tails + last block
+        const size_t shmem = (kTabComplex + 2 * kFft + 4 * kWaveLdsComplex) * sizeof(float2);     // 67 KiB
+        static std::atomic<unsigned long long> lds_ok{0};
+        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1_edges), shmem, lds_ok);
+        if (e != hipSuccess) return e;
+        const long long waves = (long long)a.n_streams * a.chunks;
+        hipLaunchKernelGGL(k_conv_p1_edges, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (a.n_blocks > 1) {       // 2. blocks [0, n_blocks - 1): `chunks` independent waves per stream
         const long long waves = (long long)a.n_streams * a.chunks;
         const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
         static std::atomic<unsigned long long> lds_ok{0};
-        e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1), shmem_main, lds_ok);
+        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1), shmem_main, lds_ok);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_conv_p1, dim3((unsigned)((waves + kP1Waves - 1) / kP1Waves)), dim3(64 * kP1Waves),
                            shmem_main, st, a);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        if (a.chunks > 1) {
-            const long long n = (long long)a.n_streams * (a.chunks - 1) * 512;
-            hipLaunchKernelGGL(k_conv_p1_fixup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-        }
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_conv_p1_last, dim3((unsigned)((a.n_streams + 3) / 4)), dim3(256), shmem, st, a);
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------

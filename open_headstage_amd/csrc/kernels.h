@@ -46,7 +46,7 @@ hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e,
 
 // Fast path when every path has exactly one partition (taps <= 512): time-parallel over
 // `chunks` contiguous block ranges per stream, one forward + one inverse FFT per block, the
-// combined spectra C = (A - jB)/2, D = (A + jB)/2 (A = H0 + jH1, B = H2 + jH3) held in registers.
+// combined spectra C = (A - jB)/2, D = (A + jB)/2 (A = H0 + jH1, B = H2 + jH3) held in LDS.
 struct ConvP1Args {
     const float *in;
     float *out;
@@ -59,7 +59,7 @@ struct ConvP1Args {
     const float2 *H[4];         // single-partition spectra (used for the last block: split tails)
     const float2 *tails;        // [stream][2][8][64] state in, same format as the general kernel
     float2 *tails_out;          // state out (a different slab; the host swaps them after the launch)
-    float2 *chunk_tails;        // [stream][chunks][8][64] scratch: tail leaving each chunk
+    float2 *chunk_tails;        // [stream][chunks][8][64] scratch: overlap tail ENTERING chunk e (e >= 1), from k_conv_p1_edges
     const float2 *tw;
     float gain;
 };

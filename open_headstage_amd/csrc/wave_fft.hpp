@@ -62,6 +62,29 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS accessors of the FFT exchanges and table reads.  hipcc's load/store optimiser fuses two ds_read_b64
+// of one base register into a ds_read2_b64, which the LDS serves at HALF the bytes per clock of two separate
+// ds_read_b64 (MI355X: 2 x 32-lane groups per b64 read, 4 x 16 per half of a read2; measured by
+// tools/ubench_lds.py).  A volatile access is left alone by that pass; program order among them is what the
+// exchanges want anyway.
+#ifndef OHS_LDS_MERGE
+// (accessed as one 64-bit integer, not as a <2 x float> vector: with a vector type in play hipcc packs the
+// following complex arithmetic into v_pk_* instructions and pays for it in register moves)
+__device__ __forceinline__ float2 lds_ld(const float2 *p)
+{
+    const unsigned long long t = *(const volatile __attribute__((address_space(3))) unsigned long long *)p;
+    return make_float2(__uint_as_float((unsigned)t), __uint_as_float((unsigned)(t >> 32)));
+}
+__device__ __forceinline__ void lds_st(float2 *p, float2 v)
+{
+    *(volatile __attribute__((address_space(3))) unsigned long long *)p =
+        (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+}
+#else
+__device__ __forceinline__ float2 lds_ld(const float2 *p) { return *p; }
+__device__ __forceinline__ void lds_st(float2 *p, float2 v) { *p = v; }
+#endif
+
 // 4-point DFT in place: (a,b,c,d) = inputs 0..3 -> outputs 0..3
 template <bool INV>
 __device__ __forceinline__ void dft4(float2 &a, float2 &b, float2 &c, float2 &d)
@@ -157,30 +180,47 @@ __device__ __forceinline__ int t2_sigma(int q, int p_hi)
     return 16 * (p_hi & 1) + 8 * (p_hi >> 1) + (q & 7) + 32 * (q >> 3);
 }
 
-// time layout -> bin layout (unnormalised forward DFT)
-__device__ __forceinline__ void wave_fft_fwd(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
+// time layout -> bin layout (unnormalised forward DFT).
+// MIRROR: also return zm[reg] = Z[N - k(lane, reg)], the spectrum at the mirrored bin, which the packed
+// two-channel formulation needs next to Z[k].  It costs no cross-lane traffic: the last stage is a DFT4
+// over the T2 image, so a lane simply ALSO reads the four 4-point groups that produce its mirror bins --
+// those of lane 63 - L (k = 4L + j + 256 r, j != 0  ->  N - k = 4(63 - L) + (4 - j) + 256 (3 - r)) and, for
+// j == 0, of lane 64 - L -- and runs four more DFT4s: 16 ds_read_b64 + 64 adds instead of the 32
+// ds_bpermute_b32 of wave_mirror (5.7 LDS cycles each, tools/ubench_lds.py).
+template <bool MIRROR>
+__device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[16], float2 *lds, const float2 *tab,
+                                                  int lane)
 {
     dft16<false>(v);                                        // over a -> p
 #pragma unroll
-    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], tab[kTabA + p * 64 + lane]);
+    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], lds_ld(&tab[kTabA + p * 64 + lane]));
 #pragma unroll
-    for (int p = 0; p < 16; ++p) lds[68 * p + lane] = v[p];  // T1
+    for (int p = 0; p < 16; ++p) lds_st(&lds[68 * p + lane], v[p]);  // T1
     wave_lds_sync();
     const int pp = lane >> 2, c = lane & 3;
 #pragma unroll
-    for (int b = 0; b < 16; ++b) v[b] = lds[68 * pp + 4 * b + c];
+    for (int b = 0; b < 16; ++b) v[b] = lds_ld(&lds[68 * pp + 4 * b + c]);
     wave_lds_sync();
     dft16<false>(v);                                        // over b -> q
 #pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tab[kTabB + 4 * q + (lane & 3)]);
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], lds_ld(&tab[kTabB + 4 * q + (lane & 3)]));
     const int p_lo = pp & 3, p_hi = pp >> 2;
     const int wbase = 65 * (4 * p_lo + c) + 16 * (p_hi & 1) + 8 * (p_hi >> 1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) lds[wbase + (q & 7) + 32 * (q >> 3)] = v[q];  // T2
+    for (int q = 0; q < 16; ++q) lds_st(&lds[wbase + (q & 7) + 32 * (q >> 3)], v[q]);  // T2
     wave_lds_sync();
     const int rbase = t2_sigma(lane >> 2, lane & 3);
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) v[rr] = lds[65 * rr + rbase];   // rr = 4 p_lo + c
+    for (int rr = 0; rr < 16; ++rr) v[rr] = lds_ld(&lds[65 * rr + rbase]);   // rr = 4 p_lo + c
+    float2 m[16];
+    if constexpr (MIRROR) {
+        const int la = 63 - lane, lb = (64 - lane) & 63;
+        const int rbA = t2_sigma(la >> 2, la & 3), rbB = t2_sigma(lb >> 2, lb & 3);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) m[cc] = lds_ld(&lds[65 * cc + rbB]);                  // group j' = 0 of lane 64 - L
+#pragma unroll
+        for (int rr = 4; rr < 16; ++rr) m[rr] = lds_ld(&lds[65 * rr + rbA]);                 // groups j' = 1..3 of lane 63 - L
+    }
     wave_lds_sync();
     // DFT4 over c for each j = p_lo; result to reg 4 r + j
 #pragma unroll
@@ -192,6 +232,29 @@ __device__ __forceinline__ void wave_fft_fwd(float2 (&v)[16], float2 *lds, const
     t = v[6];  v[6] = v[9];   v[9] = t;
     t = v[7];  v[7] = v[13];  v[13] = t;
     t = v[11]; v[11] = v[14]; v[14] = t;
+    if constexpr (MIRROR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dft4<false>(m[4 * j], m[4 * j + 1], m[4 * j + 2], m[4 * j + 3]);   // m[4 j' + r']
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 1; j < 4; ++j) zm[4 * r + j] = m[4 * (4 - j) + (3 - r)];
+            // j == 0: lanes 1..63 take bin 256 (3 - r) of lane 64 - L; lane 0 (L = 0: N - 256 r) its own 256 ((4 - r) & 3)
+            const float2 g = m[3 - r], own = m[(4 - r) & 3];
+            zm[4 * r] = (lane == 0) ? own : g;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_fft_fwd(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
+{
+    float2 unused[16];
+    wave_fft_fwd_impl<false>(v, unused, lds, tab, lane);
+}
+__device__ __forceinline__ void wave_fft_fwd_mirror(float2 (&v)[16], float2 (&zm)[16], float2 *lds, const float2 *tab,
+                                                    int lane)
+{
+    wave_fft_fwd_impl<true>(v, zm, lds, tab, lane);
 }
 
 // bin layout -> time layout (unnormalised inverse DFT)
@@ -208,28 +271,28 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
-        const float2 w = tab[kTabC + 16 * c + (lane >> 2)];
+        const float2 w = lds_ld(&tab[kTabC + 16 * c + (lane >> 2)]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
     }
     const int rbase = t2_sigma(lane >> 2, lane & 3);
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) lds[65 * rr + rbase] = v[rr];     // T2'
+    for (int rr = 0; rr < 16; ++rr) lds_st(&lds[65 * rr + rbase], v[rr]);     // T2'
     wave_lds_sync();
     const int pp = lane >> 2, c = lane & 3;
     const int p_lo = pp & 3, p_hi = pp >> 2;
     const int wbase = 65 * (4 * p_lo + c) + 16 * (p_hi & 1) + 8 * (p_hi >> 1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = lds[wbase + (q & 7) + 32 * (q >> 3)];
+    for (int q = 0; q < 16; ++q) v[q] = lds_ld(&lds[wbase + (q & 7) + 32 * (q >> 3)]);
     wave_lds_sync();
     dft16<true>(v);                                         // over q -> b
 #pragma unroll
-    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], tab[kTabD + b * 64 + lane]);
+    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], lds_ld(&tab[kTabD + b * 64 + lane]));
 #pragma unroll
-    for (int b = 0; b < 16; ++b) lds[68 * pp + 4 * b + c] = v[b];    // T1'
+    for (int b = 0; b < 16; ++b) lds_st(&lds[68 * pp + 4 * b + c], v[b]);    // T1'
     wave_lds_sync();
 #pragma unroll
-    for (int p = 0; p < 16; ++p) v[p] = lds[68 * p + lane];
+    for (int p = 0; p < 16; ++p) v[p] = lds_ld(&lds[68 * p + lane]);
     wave_lds_sync();
     dft16<true>(v);                                         // over p -> a
 }
