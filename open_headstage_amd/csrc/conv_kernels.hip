@@ -393,9 +393,9 @@ hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2,
 // Round 1 added the chunk-boundary tails afterwards with a read-modify-write pass over `out` (k_conv_p1_fixup);
 // recomputing 1 block in ~34 instead costs less than that pass and its traffic.
 #ifndef OHS_P1_WAVES
-#define OHS_P1_WAVES 14
+#define OHS_P1_WAVES 15
 #endif
-constexpr int kP1Waves = OHS_P1_WAVES;   // waves per workgroup = per CU (LDS: 33 KiB of tables + 8.5 KiB per wave)
+constexpr int kP1Waves = OHS_P1_WAVES;   // waves per workgroup = per CU (LDS: 25 KiB of tables + 8.5 KiB per wave = 152.5 KiB)
 
 // W = Z C + conj(Zm) D for the 16 registers of a lane, written over the mirror values (cd: LDS, [2][16][64])
 __device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float2 (&w)[16], const float2 *cd, int lane)
@@ -458,12 +458,25 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #pragma unroll
         for (int a = 0; a < 8; ++a) tail[a] = ct[a * 64 + lane];
     }
+    // All waves of a workgroup leave the table barrier together and run the same program, so their LDS
+    // bursts and their arithmetic phases coincide; a start offset per wave spreads them over the block time.
+    for (int i = 0; i < wave * A.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    // The next block's 16 input dwords are requested BEFORE this block's 16 stores are issued: vector-memory
+    // operations retire in order, so loads issued after the stores (at the top of the next iteration) could not be
+    // consumed before every one of those stores had been acknowledged.  (Requesting them a whole inverse
+    // transform earlier would hide the HBM latency entirely, but needs 16 more VGPRs at the kernel's register
+    // peak: hipcc spilled 80 VGPRs at 4 waves per SIMD and still 24 at 3.)
+    float xl[8], xr[8];
+    // one address per channel and direction, advanced by a block per iteration; every access is base + immediate
+    const float *pl = in_l + (size_t)b0 * kBlock + lane, *pr = in_r + (size_t)b0 * kBlock + lane;
+    float *ql = out_l + (size_t)b0 * kBlock + lane, *qr = out_r + (size_t)b0 * kBlock + lane;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { xl[a] = pl[64 * a]; xr[a] = pr[64 * a]; }
     for (int t = b0; t < b1; ++t) {
-        const unsigned base = (unsigned)t * kBlock + lane;      // frames per call < 2^32 (host-checked)
         float2 v[16];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            v[a] = make_float2(in_l[base + 64 * a], in_r[base + 64 * a]);
+            v[a] = make_float2(xl[a], xr[a]);
             v[a + 8] = make_float2(0.0f, 0.0f);
         }
         float2 w[16];
@@ -474,35 +487,48 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
         wave_fft_fwd_mirror(v, w, lds, tab, lane);
 #endif
         p1_spectral_product(v, w, cd, lane);
+        // block t + 1 always exists (b1 <= n_blocks - 1), so the prefetch needs no guard
+        pl += kBlock; pr += kBlock;
+#ifdef OHS_P1_PREFETCH_EARLY
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { xl[a] = pl[64 * a]; xr[a] = pr[64 * a]; }
+        wave_fft_inv(w, lds, tab, lane);
+#else
         wave_fft_inv(w, lds, tab, lane);
 #pragma unroll
+        for (int a = 0; a < 8; ++a) { xl[a] = pl[64 * a]; xr[a] = pr[64 * a]; }
+#endif
+#pragma unroll
         for (int a = 0; a < 8; ++a) {
-            out_l[base + 64 * a] = (w[a].x * scale + tail[a].x) * A.gain;
-            out_r[base + 64 * a] = (w[a].y * scale + tail[a].y) * A.gain;
+            ql[64 * a] = (w[a].x * scale + tail[a].x) * A.gain;
+            qr[64 * a] = (w[a].y * scale + tail[a].y) * A.gain;
             tail[a] = make_float2(w[a + 8].x * scale, w[a + 8].y * scale);
         }
+        ql += kBlock; qr += kBlock;
     }
 }
 
-// pre-pass, 4 waves per workgroup: wave (s, e) as described above
-__global__ __launch_bounds__(256) void k_conv_p1_edges(const ConvP1Args A)
+// pre-pass: wave (s, e) as described above; same workgroup shape as the main kernel, so that the 25 KiB of
+// tables are fetched once per 15 waves and all waves of the pass are resident in two rounds
+__global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     float2 *cd = smem + kTabComplex;
-    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kP1Waves);
     {
         const float4 *src = reinterpret_cast<const float4 *>(A.CD);
         float4 *dst = reinterpret_cast<float4 *>(cd);
-        for (int i = threadIdx.x; i < kFft; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) dst[i] = src[i];
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + 2 * kFft + wave * kWaveLdsComplex;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const long long gw = (long long)blockIdx.x * kP1Waves + wave;
     if (gw >= (long long)A.n_streams * A.chunks) return;
-    const int s = (int)(gw / A.chunks);
-    const int e = (int)(gw % A.chunks);
+    // the heavy (last-block) jobs first: e == 0 for the first n_streams waves of the grid
+    const int s = gw < A.n_streams ? (int)gw : (int)((gw - A.n_streams) / (A.chunks - 1));
+    const int e = gw < A.n_streams ? 0 : 1 + (int)((gw - A.n_streams) % (A.chunks - 1));
     const int n_main = A.n_blocks - 1;
     const float *in_l = A.in + (size_t)s * A.in_stream_stride;
     const float *in_r = in_l + A.in_ch_stride;
@@ -587,19 +613,19 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
     if (a.n_blocks <= 0 || a.n_streams <= 0 || a.chunks < 1) return hipErrorInvalidValue;
     if (a.n_blocks > 1 && a.chunks > a.n_blocks - 1) return hipErrorInvalidValue;
     if ((unsigned long long)a.n_blocks * kBlock >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit frame offsets
+    const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
     {   // 1. boundary tails + last block
-        const size_t shmem = (kTabComplex + 2 * kFft + 4 * kWaveLdsComplex) * sizeof(float2);     // 67 KiB
         static std::atomic<unsigned long long> lds_ok{0};
-        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1_edges), shmem, lds_ok);
+        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1_edges), shmem_main, lds_ok);
         if (e != hipSuccess) return e;
         const long long waves = (long long)a.n_streams * a.chunks;
-        hipLaunchKernelGGL(k_conv_p1_edges, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
+        hipLaunchKernelGGL(k_conv_p1_edges, dim3((unsigned)((waves + kP1Waves - 1) / kP1Waves)), dim3(64 * kP1Waves),
+                           shmem_main, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     if (a.n_blocks > 1) {       // 2. blocks [0, n_blocks - 1): `chunks` independent waves per stream
         const long long waves = (long long)a.n_streams * a.chunks;
-        const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
         static std::atomic<unsigned long long> lds_ok{0};
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1), shmem_main, lds_ok);
         if (e != hipSuccess) return e;

@@ -62,6 +62,7 @@ struct ConvP1Args {
     float2 *chunk_tails;        // [stream][chunks][8][64] scratch: overlap tail ENTERING chunk e (e >= 1), from k_conv_p1_edges
     const float2 *tw;
     float gain;
+    int stagger;                // wave w of a workgroup starts its block loop w * stagger * 64 cycles late (0 = off)
 };
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
 int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)

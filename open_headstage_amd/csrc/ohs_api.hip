@@ -268,10 +268,9 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         }
         // block ranges per stream: waves for exactly two full rounds of (CUs x resident waves per CU) --
         // measured on config 3 without EQ: 1.7 rounds 0.847 ms, 2.0 rounds 0.794 ms, 2.5 rounds 0.892 ms
-        static const long long target_override = [] {
-            const char *e = getenv("OHS_P1_TARGET_WAVES");      // tuning experiments
-            return e ? atoll(e) : 0LL;
-        }();
+        // tuning experiments (read per call so that one process can sweep them: tools/tune_p1.py)
+        const char *env_tw = getenv("OHS_P1_TARGET_WAVES");
+        const long long target_override = env_tw ? atoll(env_tw) : 0LL;
         const long long target_waves =
             target_override > 0 ? target_override : 2LL * ctx->num_cus * conv_p1_waves_per_cu();
         long long K = (target_waves + (long long)c.S - 1) / (long long)c.S;
@@ -293,6 +292,8 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
         a.tails = c.d_tails; a.tails_out = c.d_tails_alt; a.chunk_tails = c.d_chunk_tails;
         a.tw = ctx->d_tw; a.gain = gain;
+        const char *env_sg = getenv("OHS_P1_STAGGER");          // tuning experiments
+        a.stagger = env_sg ? atoi(env_sg) : 0;
         hipError_t e = launch_conv_p1(a, st);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
         std::swap(c.d_tails, c.d_tails_alt);

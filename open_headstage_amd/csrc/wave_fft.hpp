@@ -16,11 +16,16 @@
 //   forward: DFT16(a->p) . w1024^(m p) . T1 . DFT16(b->q) . w64^(c q) . T2 . DFT4(c->r)
 //   inverse: the same graph run backwards with conjugated twiddles.
 //
-// LDS images (complex = 8 B units), both conflict-free for ds_read_b64/ds_write_b64
-// except a 2-way conflict on the inverse T2 write (tools/proto_wave_fft.py checks
-// the index plan and the bank census on the CPU):
+// LDS images (complex = 8 B units), conflict-free for ds_read_b64 (two 32-lane groups, 64 dword banks) and
+// ds_write_b64 (four 16-lane groups, 32 dword banks) except a 2-way conflict on the inverse T2 write
+// (tools/proto_wave_fft.py checks the index plan and the bank census on the CPU):
 //   T1: addr = 68 p + m                        (m = 4b + c)
 //   T2: addr = 65 (4 p_lo + c) + sigma(q, p_hi), sigma = 16(p_hi&1) + 8(p_hi>>1) + (q&7) + 32(q>>3)
+// Padded, not XOR-swizzled: every access of an exchange is then ONE base register + an immediate offset.  (An
+// unpadded 1024-entry XOR plan exists and is conflict-free everywhere, but needs a distinct address register
+// per access; hipcc keeps them all live across the block loop and k_conv_p1 spilled 81 VGPRs.)
+// The twiddle table w1024^(m p) is stored in the T1 layout as well, so the forward transform reads it by rows
+// (lane m, reg p) and the inverse by columns (lane (p, c), reg b), both conflict-free -- one table, not two.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,14 +35,15 @@ constexpr int kBlock = 512;
 constexpr int kFft = 1024;
 constexpr int kWaveLdsComplex = 16 * 68;   // per-wave LDS slab, in float2 units (8704 B)
 
-// twiddle tables kept in LDS per workgroup (float2 units); 17 KiB, small enough that three 4-wave workgroups
-// (3 x (17 + 4 x 8.5) KiB) fit the 160 KiB of a CU
-constexpr int kTabA = 0;              // [16][64]  w1024^(m p)            lane m,  reg p   (forward)
-constexpr int kTabD = 16 * 64;        // [16][64]  w1024^((4b+c) p)       lane L1, reg b   (inverse, conj)
-constexpr int kTabB = 32 * 64;        // [16][4]   w64^(c q)   index 4q + c: only 64 distinct values, the
-                                      //           lanes of a wave read 4 addresses (LDS broadcast)
-constexpr int kTabC = 32 * 64 + 64;   // [4][16]   w64^(c q)   index 16c + q (inverse, conj)
-constexpr int kTabComplex = 32 * 64 + 128;  // 2176 float2 = 17 KiB
+// twiddle tables kept in LDS per workgroup (float2 units), 9 KiB
+constexpr int kTabA = 0;              // [16][68]  w1024^(m p) at t1_index(p, m): rows for the forward transform,
+                                      //           columns (conjugated) for the inverse
+constexpr int kTabB = 16 * 68;        // [16][4]   w64^(c q)   index 4q + c: only 64 distinct values (LDS broadcast);
+                                      //           forward: lane c = lane & 3, reg q; inverse: lane q = lane >> 2, reg c
+constexpr int kTabComplex = 16 * 68 + 64;  // 1152 float2 = 9 KiB
+
+// T1 image / twiddle table position of element (p, m), m = 4b + c
+__host__ __device__ __forceinline__ constexpr int t1_index(int p, int m) { return 68 * p + m; }
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -163,22 +169,19 @@ __device__ __forceinline__ void fill_twiddle_tables(float2 *tab, const float2 *_
 // host side: expanded[kTabComplex] from tw[e] = exp(-2 pi i e / 1024)
 inline void expand_twiddle_tables(const float2 *tw, float2 *expanded)
 {
-    for (int i = 0; i < 16 * 64; ++i) {
-        const int r = i >> 6, l = i & 63;
-        expanded[kTabA + i] = tw[(l * r) & 1023];                            // w1024^(m p)
-        expanded[kTabD + i] = tw[((4 * r + (l & 3)) * (l >> 2)) & 1023];     // w1024^((4b+c) p)
-    }
+    for (int i = 0; i < kTabComplex; ++i) expanded[i] = tw[0];                                // padding
+    for (int p = 0; p < 16; ++p)
+        for (int m = 0; m < 64; ++m) expanded[kTabA + t1_index(p, m)] = tw[(m * p) & 1023];   // w1024^(m p)
     for (int q = 0; q < 16; ++q)
-        for (int c = 0; c < 4; ++c) {
-            expanded[kTabB + 4 * q + c] = tw[(16 * c * q) & 1023];           // w64^(c q)
-            expanded[kTabC + 16 * c + q] = tw[(16 * c * q) & 1023];
-        }
+        for (int c = 0; c < 4; ++c) expanded[kTabB + 4 * q + c] = tw[(16 * c * q) & 1023];    // w64^(c q)
 }
 
-__device__ __forceinline__ int t2_sigma(int q, int p_hi)
+__host__ __device__ __forceinline__ constexpr int t2_sigma(int q, int p_hi)
 {
     return 16 * (p_hi & 1) + 8 * (p_hi >> 1) + (q & 7) + 32 * (q >> 3);
 }
+// T2 image position of element (rr = 4 p_lo + c, q, p_hi)
+__host__ __device__ __forceinline__ constexpr int t2_index(int rr, int sigma) { return 65 * rr + sigma; }
 
 // time layout -> bin layout (unnormalised forward DFT).
 // MIRROR: also return zm[reg] = Z[N - k(lane, reg)], the spectrum at the mirrored bin, which the packed
@@ -193,33 +196,34 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
 {
     dft16<false>(v);                                        // over a -> p
 #pragma unroll
-    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], lds_ld(&tab[kTabA + p * 64 + lane]));
+    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], lds_ld(&tab[kTabA + t1_index(p, lane)]));
 #pragma unroll
-    for (int p = 0; p < 16; ++p) lds_st(&lds[68 * p + lane], v[p]);  // T1
+    for (int p = 0; p < 16; ++p) lds_st(&lds[t1_index(p, lane)], v[p]);  // T1
     wave_lds_sync();
     const int pp = lane >> 2, c = lane & 3;
+    const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
 #pragma unroll
-    for (int b = 0; b < 16; ++b) v[b] = lds_ld(&lds[68 * pp + 4 * b + c]);
+    for (int b = 0; b < 16; ++b) v[b] = lds_ld(&lds[t1r + 4 * b]);
     wave_lds_sync();
     dft16<false>(v);                                        // over b -> q
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], lds_ld(&tab[kTabB + 4 * q + (lane & 3)]));
     const int p_lo = pp & 3, p_hi = pp >> 2;
-    const int wbase = 65 * (4 * p_lo + c) + 16 * (p_hi & 1) + 8 * (p_hi >> 1);
+    const int rrw = 4 * p_lo + c;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) lds_st(&lds[wbase + (q & 7) + 32 * (q >> 3)], v[q]);  // T2
+    for (int q = 0; q < 16; ++q) lds_st(&lds[t2_index(rrw, t2_sigma(q, p_hi))], v[q]);  // T2
     wave_lds_sync();
     const int rbase = t2_sigma(lane >> 2, lane & 3);
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) v[rr] = lds_ld(&lds[65 * rr + rbase]);   // rr = 4 p_lo + c
+    for (int rr = 0; rr < 16; ++rr) v[rr] = lds_ld(&lds[t2_index(rr, rbase)]);   // rr = 4 p_lo + c
     float2 m[16];
     if constexpr (MIRROR) {
         const int la = 63 - lane, lb = (64 - lane) & 63;
         const int rbA = t2_sigma(la >> 2, la & 3), rbB = t2_sigma(lb >> 2, lb & 3);
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) m[cc] = lds_ld(&lds[65 * cc + rbB]);                  // group j' = 0 of lane 64 - L
+        for (int cc = 0; cc < 4; ++cc) m[cc] = lds_ld(&lds[t2_index(cc, rbB)]);               // group j' = 0 of lane 64 - L
 #pragma unroll
-        for (int rr = 4; rr < 16; ++rr) m[rr] = lds_ld(&lds[65 * rr + rbA]);                 // groups j' = 1..3 of lane 63 - L
+        for (int rr = 4; rr < 16; ++rr) m[rr] = lds_ld(&lds[t2_index(rr, rbA)]);              // groups j' = 1..3 of lane 63 - L
     }
     wave_lds_sync();
     // DFT4 over c for each j = p_lo; result to reg 4 r + j
@@ -271,28 +275,29 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
-        const float2 w = lds_ld(&tab[kTabC + 16 * c + (lane >> 2)]);
+        const float2 w = lds_ld(&tab[kTabB + 4 * (lane >> 2) + c]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
     }
     const int rbase = t2_sigma(lane >> 2, lane & 3);
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) lds_st(&lds[65 * rr + rbase], v[rr]);     // T2'
+    for (int rr = 0; rr < 16; ++rr) lds_st(&lds[t2_index(rr, rbase)], v[rr]);     // T2'
     wave_lds_sync();
     const int pp = lane >> 2, c = lane & 3;
     const int p_lo = pp & 3, p_hi = pp >> 2;
-    const int wbase = 65 * (4 * p_lo + c) + 16 * (p_hi & 1) + 8 * (p_hi >> 1);
+    const int rrw = 4 * p_lo + c;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = lds_ld(&lds[wbase + (q & 7) + 32 * (q >> 3)]);
+    for (int q = 0; q < 16; ++q) v[q] = lds_ld(&lds[t2_index(rrw, t2_sigma(q, p_hi))]);
     wave_lds_sync();
     dft16<true>(v);                                         // over q -> b
+    const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
 #pragma unroll
-    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], lds_ld(&tab[kTabD + b * 64 + lane]));
+    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], lds_ld(&tab[kTabA + t1r + 4 * b]));   // w1024^((4b+c) p), conj
 #pragma unroll
-    for (int b = 0; b < 16; ++b) lds_st(&lds[68 * pp + 4 * b + c], v[b]);    // T1'
+    for (int b = 0; b < 16; ++b) lds_st(&lds[t1r + 4 * b], v[b]);    // T1'
     wave_lds_sync();
 #pragma unroll
-    for (int p = 0; p < 16; ++p) v[p] = lds_ld(&lds[68 * p + lane]);
+    for (int p = 0; p < 16; ++p) v[p] = lds_ld(&lds[t1_index(p, lane)]);
     wave_lds_sync();
     dft16<true>(v);                                         // over p -> a
 }
