@@ -209,6 +209,14 @@ int  ohs_batch_process(ohs_batch *b, const float *d_in, float *d_out, size_t n_b
 int  ohs_batch_process_deferred(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
                                 size_t stream_stride, size_t channel_stride, void *hip_stream);
 int  ohs_batch_join(ohs_batch *b, void *hip_stream);
+/* The same processing with HOST buffers (same planar layout and strides, host pointers): the frames are cut
+ * into time chunks of `chunk_blocks` blocks (0 = library default, ~96 MiB per direction) and copy-in of
+ * chunk i + 1, the kernels of chunk i and copy-out of chunk i - 1 run concurrently on three internal
+ * streams.  Blocking: h_out is complete on return.  h_in may equal h_out.  Pinned (page-locked) host memory
+ * is needed for the copies to overlap at link speed; pageable memory works but serialises.  Results are
+ * bit-identical to the sequence of ohs_batch_process calls with the same chunk sizes on device buffers. */
+int  ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t n_blocks,
+                            size_t stream_stride, size_t channel_stride, size_t chunk_blocks);
 /* waits (host side) for everything queued on `hip_stream` and for a pending deferred call */
 int  ohs_batch_sync(ohs_batch *b, void *hip_stream);
 /* Per-kernel timing for the roofline report: when enabled, every ohs_batch_process call brackets
@@ -219,9 +227,12 @@ int  ohs_batch_sync(ohs_batch *b, void *hip_stream);
 int  ohs_batch_set_profiling(ohs_batch *b, int enable);
 int  ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls,
                             uint64_t *eq_launches, uint64_t *conv_launches);
-/* algorithmic HBM bytes one ohs_batch_process call of n_blocks moves (DESIGN.md byte model) */
+/* HBM bytes of one ohs_batch_process call of n_blocks by SURVEY.md 8d's per-block model (state persisted
+ * between 512-frame blocks: 25 112 B per stream-block at P = 1) -- the yardstick of the whole path */
 int  ohs_batch_algorithmic_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *bytes);
-/* the same, split per kernel: eq_bytes for the EQ kernel, conv_bytes for the convolution kernel */
+/* DESIGN bytes per kernel family: what the EQ / convolution kernels are built to move through HBM for such a
+ * call (P = 1: 16 B per frame + chunk-boundary tails + state; it writes no history and keeps overlaps in
+ * registers) -- the numerator of a kernel's own HBM fraction, next to rocprofv3's measured bytes */
 int  ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_bytes, uint64_t *conv_bytes);
 
 #ifdef __cplusplus

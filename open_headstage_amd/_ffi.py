@@ -85,6 +85,7 @@ PROTOTYPES = {
     "ohs_batch_process_deferred": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),
     "ohs_batch_join": (C.c_int, [vp, vp]),
     "ohs_batch_sync": (C.c_int, [vp, vp]),
+    "ohs_batch_process_host": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "ohs_batch_set_profiling": (C.c_int, [vp, C.c_int]),
     "ohs_batch_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),

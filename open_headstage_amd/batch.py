@@ -86,6 +86,30 @@ class BatchProcessor:
                          hip_stream, deferred)
         return out
 
+    def process_host(self, x, out=None, chunk_blocks: int = 0):
+        """x, out: HOST float32 tensors (torch, ideally pinned) or numpy arrays [n_streams, 2, frames]; blocking,
+        copy-in / kernels / copy-out pipelined over time chunks (ohs_batch_process_host)."""
+        is_np = isinstance(x, np.ndarray)
+        if out is None:
+            out = np.empty_like(x) if is_np else x.new_empty(x.shape).pin_memory()
+        S, ch, frames = x.shape
+        if S != self.n_streams or ch != 2 or frames % BLOCK_SIZE:
+            raise ValueError(f"expected [{self.n_streams}, 2, k*{BLOCK_SIZE}], got {tuple(x.shape)}")
+        if tuple(out.shape) != tuple(x.shape):
+            raise ValueError("out must match x")
+        if is_np:
+            if x.dtype != np.float32 or not x.flags.c_contiguous or out.dtype != np.float32 or not out.flags.c_contiguous:
+                raise TypeError("numpy buffers must be contiguous float32")
+            pi, po = x.ctypes.data, out.ctypes.data
+        else:
+            import torch
+            if x.is_cuda or out.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or not out.is_contiguous():
+                raise TypeError("x / out must be contiguous float32 HOST tensors")
+            pi, po = x.data_ptr(), out.data_ptr()
+        check(lib().ohs_batch_process_host(self._h, C.c_void_p(pi), C.c_void_p(po), frames // BLOCK_SIZE,
+                                           2 * frames, frames, int(chunk_blocks)))
+        return out
+
     def sync(self, hip_stream: int = 0) -> None:
         check(lib().ohs_batch_sync(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 

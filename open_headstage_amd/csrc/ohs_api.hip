@@ -549,6 +549,13 @@ struct ohs_batch {
     bool join_pending = false;
     const float *pend_out = nullptr;       // geometry of the pending call: per-chunk waits only if the next one matches
     size_t pend_blocks = 0, pend_ss = 0, pend_cs = 0;
+    // ohs_batch_process_host: three staging slots [S][2][slot_frames], copy-in / compute / copy-out streams
+    static constexpr int kHostSlots = 3;
+    float *d_slot[kHostSlots] = {nullptr, nullptr, nullptr};
+    size_t slot_frames = 0;
+    hipStream_t st_h2d = nullptr, st_comp = nullptr, st_d2h = nullptr;
+    hipEvent_t ev_h2d[kHostSlots] = {nullptr, nullptr, nullptr}, ev_comp[kHostSlots] = {nullptr, nullptr, nullptr},
+               ev_d2h[kHostSlots] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -1105,6 +1112,15 @@ void ohs_batch_destroy(ohs_batch *b)
     for (hipEvent_t e : b->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : b->ev_inflight) hipEventDestroy(e);
     for (hipEvent_t e : b->chunk_done) hipEventDestroy(e);
+    for (int k = 0; k < ohs_batch::kHostSlots; ++k) {
+        if (b->d_slot[k]) hipFree(b->d_slot[k]);
+        if (b->ev_h2d[k]) hipEventDestroy(b->ev_h2d[k]);
+        if (b->ev_comp[k]) hipEventDestroy(b->ev_comp[k]);
+        if (b->ev_d2h[k]) hipEventDestroy(b->ev_d2h[k]);
+    }
+    if (b->st_h2d) hipStreamDestroy(b->st_h2d);
+    if (b->st_comp) hipStreamDestroy(b->st_comp);
+    if (b->st_d2h) hipStreamDestroy(b->st_d2h);
     if (b->st2) hipStreamDestroy(b->st2);
     if (b->st) hipStreamDestroy(b->st);
     delete b;
@@ -1335,6 +1351,101 @@ int ohs_batch_process_deferred(ohs_batch *b, const float *d_in, float *d_out, si
     return batch_process_impl(b, d_in, d_out, n_blocks, stream_stride, channel_stride, hip_stream, true);
 }
 
+// Host-buffer batch call (north_star's offline mode fed from host memory).  The frames are cut into time
+// chunks; chunk i + 1 is copied in, chunk i processed and chunk i - 1 copied out at the same time, on three
+// streams over three device staging slots, so that both directions of the host link and the kernels
+// overlap (the 8 B/frame in + 8 B/frame out over PCIe, not the GPU work, is the bound: DESIGN.md section 5).
+// Each chunk is one ohs_batch_process call on its slot, in stream order, so per-stream state chains exactly
+// as in a sequence of device calls with the same chunk sizes.
+int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t n_blocks,
+                           size_t stream_stride, size_t channel_stride, size_t chunk_blocks)
+{
+    if (!b || !h_in || !h_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (n_blocks == 0) return OHS_OK;
+    if (n_blocks > (size_t)1 << 24) return fail(OHS_ERR_INVALID_ARG, "n_blocks too large");
+    const size_t frames = n_blocks * BS, S = b->conv.S;
+    if (channel_stride < frames || (S > 1 && stream_stride < 2 * frames && stream_stride < channel_stride + frames))
+        return fail(OHS_ERR_INVALID_ARG, "strides smaller than the processed region");
+    HIP_TRY(hipSetDevice(b->device));
+    if (chunk_blocks == 0) {
+        // default: ~96 MiB per chunk and direction (2.4 ms of link time at 40 GB/s), at least 64 blocks so that the
+        // EQ / convolution overlap inside ohs_batch_process stays on, at most the whole call
+        const size_t per_block = S * 2 * BS * sizeof(float);
+        chunk_blocks = std::max<size_t>(64, ((size_t)96 << 20) / per_block);
+    }
+    chunk_blocks = std::min(chunk_blocks, n_blocks);
+    const size_t cf = chunk_blocks * BS;
+    if (!b->st_h2d) {
+        HIP_TRY(hipStreamCreateWithFlags(&b->st_h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&b->st_comp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&b->st_d2h, hipStreamNonBlocking));
+        for (int k = 0; k < ohs_batch::kHostSlots; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_h2d[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_comp[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_d2h[k], hipEventDisableTiming));
+        }
+    }
+    if (cf > b->slot_frames) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (int k = 0; k < ohs_batch::kHostSlots; ++k) {
+            if (b->d_slot[k]) hipFree(b->d_slot[k]);
+            b->d_slot[k] = nullptr;
+        }
+        b->slot_frames = 0;
+        for (int k = 0; k < ohs_batch::kHostSlots; ++k) HIP_TRY(hipMalloc(&b->d_slot[k], S * 2 * cf * sizeof(float)));
+        b->slot_frames = cf;
+    }
+    // one 2-D copy per chunk when the host rows are equally spaced ([stream][channel] with stream_stride ==
+    // 2 * channel_stride, or a single stream); else one 2-D copy per stream
+    const bool regular = S == 1 || stream_stride == 2 * channel_stride;
+    auto copy = [&](bool to_device, float *dev, size_t off, size_t nf, hipStream_t st) -> int {
+        const size_t dpitch = b->slot_frames * sizeof(float), w = nf * sizeof(float);
+        if (regular) {
+            const size_t hpitch = channel_stride * sizeof(float);
+            if (to_device)
+                HIP_TRY(hipMemcpy2DAsync(dev, dpitch, h_in + off, hpitch, w, S * 2, hipMemcpyHostToDevice, st));
+            else
+                HIP_TRY(hipMemcpy2DAsync(h_out + off, hpitch, dev, dpitch, w, S * 2, hipMemcpyDeviceToHost, st));
+            return OHS_OK;
+        }
+        for (size_t s_ = 0; s_ < S; ++s_) {
+            const size_t hpitch = channel_stride * sizeof(float);
+            float *d = dev + s_ * 2 * b->slot_frames;
+            if (to_device)
+                HIP_TRY(hipMemcpy2DAsync(d, dpitch, h_in + s_ * stream_stride + off, hpitch, w, 2, hipMemcpyHostToDevice, st));
+            else
+                HIP_TRY(hipMemcpy2DAsync(h_out + s_ * stream_stride + off, hpitch, d, dpitch, w, 2, hipMemcpyDeviceToHost, st));
+        }
+        return OHS_OK;
+    };
+    const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
+    int rc = OHS_OK;
+    for (size_t i = 0; i < n_chunks && rc == OHS_OK; ++i) {
+        const int k = (int)(i % ohs_batch::kHostSlots);
+        const size_t blk0 = i * chunk_blocks, nb = std::min(chunk_blocks, n_blocks - blk0);
+        const size_t off = blk0 * BS, nf = nb * BS;
+        if (i >= (size_t)ohs_batch::kHostSlots) HIP_TRY(hipStreamWaitEvent(b->st_h2d, b->ev_d2h[k], 0));   // slot free again
+        rc = copy(true, b->d_slot[k], off, nf, b->st_h2d);
+        if (rc) break;
+        HIP_TRY(hipEventRecord(b->ev_h2d[k], b->st_h2d));
+        HIP_TRY(hipStreamWaitEvent(b->st_comp, b->ev_h2d[k], 0));
+        rc = batch_process_impl(b, b->d_slot[k], b->d_slot[k], nb, 2 * b->slot_frames, b->slot_frames, b->st_comp, false);
+        if (rc) break;
+        HIP_TRY(hipEventRecord(b->ev_comp[k], b->st_comp));
+        HIP_TRY(hipStreamWaitEvent(b->st_d2h, b->ev_comp[k], 0));
+        rc = copy(false, b->d_slot[k], off, nf, b->st_d2h);
+        if (rc) break;
+        HIP_TRY(hipEventRecord(b->ev_d2h[k], b->st_d2h));
+    }
+    // blocking call: the outputs are complete on return (also on a failure half-way: nothing may still be
+    // writing into the caller's buffers)
+    const hipError_t e1 = hipStreamSynchronize(b->st_h2d), e2 = hipStreamSynchronize(b->st_comp),
+                     e3 = hipStreamSynchronize(b->st_d2h);
+    if (rc) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(OHS_ERR_HIP, "host pipeline: stream sync failed");
+    return OHS_OK;
+}
+
 int ohs_batch_join(ohs_batch *b, void *hip_stream)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
@@ -1409,12 +1520,24 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
     if (!b || !eq_bytes || !conv_bytes) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
     int P = 1;
     for (int p = 0; p < 4; ++p) P = std::max(P, b->conv.P[p]);
-    // EQ kernel: audio in + out, state + coefficients.  Convolution kernel: audio in + out,
-    // history write + read, overlap read + write, HRIR spectra once per block-time.
+    const uint64_t S = b->conv.S, nbk = n_blocks;
+    // DESIGN bytes: what the kernels are built to move through HBM for one call of n_blocks (tables and ring
+    // re-reads that are served by L2 are not counted).  This is NOT the SURVEY 8d per-block model
+    // (ohs_batch_algorithmic_bytes): the P = 1 kernel keeps overlaps in registers and writes no history.
+    //   EQ:             audio in + out, state + coefficients
+    //   P = 1:          audio in + out; per stream the K chunk-boundary tails (written by the pre-pass, read by the
+    //                   main kernel, 4 KiB each) and the four-overlap state (8 KiB in + 8 KiB out)
+    //   P > 1 (time-parallel): audio in, ring write, ring read once, W write, W read, audio out
     const uint64_t eq_sb = 4096u + 4096u + 520u;
-    const uint64_t conv_sb = 4096u + 4096u + 2u * 4104u + 2u * (uint64_t)(P - 1) * 4104u + 2u * (2048u + 2048u);
-    *eq_bytes = b->eq_enable ? (uint64_t)n_blocks * b->conv.S * eq_sb : 0;
-    *conv_bytes = (uint64_t)n_blocks * ((uint64_t)b->conv.S * conv_sb + 4u * (uint64_t)P * 4104u);
+    *eq_bytes = b->eq_enable ? nbk * S * eq_sb : 0;
+    if (P == 1) {
+        uint64_t K = (2ull * (uint64_t)b->ctx->num_cus * (uint64_t)conv_p1_waves_per_cu() + S - 1) / S;
+        if (nbk < 2) K = 1; else if (K > nbk - 1) K = nbk - 1;
+        if (K < 1) K = 1;
+        *conv_bytes = nbk * S * 8192u + S * (K * 2u * 4096u + 2u * 8192u);
+    } else {
+        *conv_bytes = nbk * S * (4096u + 8192u + 8192u + 8192u + 8192u + 4096u);
+    }
     return OHS_OK;
 }
 

@@ -36,16 +36,37 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def build_native() -> str:
+    """The same source with -march=native, compiled ON THE MACHINE THAT RUNS IT (bench.py's cpu_baseline leg
+    on the GPU box: the north_star asks for the CPU path timed on that box's host cores).  The portable
+    -mavx2 library stays what the parity tests load; rounding is identical (-ffp-contract=off, no fast-math),
+    only the vectorisation differs."""
+    out = os.path.join(_HERE, "libohs_oracle_native.so")
+    src = os.path.join(_HERE, "ohs_oracle.c")
+    if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+        subprocess.run(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11",
+                        "-shared", "-o", out, src, "-lm"], check=True)
+    return out
+
+
+def use_library(path: str | None) -> None:
+    """Select the shared object lib() loads (None = the portable one); call before creating oracle objects."""
+    global _lib, _SO_OVERRIDE
+    _SO_OVERRIDE = path
+    _lib = None
+
+
 _lib = None
+_SO_OVERRIDE = None
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_SO):
+    if _SO_OVERRIDE is None and not os.path.exists(_SO):
         build()
-    L = C.CDLL(_SO)
+    L = C.CDLL(_SO_OVERRIDE or _SO)
     fp = C.POINTER(C.c_float)
     dp = C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int)

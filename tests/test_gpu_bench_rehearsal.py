@@ -1,0 +1,58 @@
+"""Rehearsal of the driver's multi-rank bench run on a ONE-GPU box: bench.py itself (not a helper) is launched
+with torch.distributed.run at world size 2, OHS_BENCH_DIST_BACKEND=gloo (table broadcast and barriers over
+gloo, both ranks on cuda:0), in weak and in strong (--total-streams) mode.  Checks the argument / environment /
+barrier plumbing, that the rank shards are disjoint and cover the job, and that every rank's outputs equal the
+single-rank run of the same stream ids bit for bit (streams share only read-only tables: SURVEY section 8e)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "2", "--warmup", "1", "--frames", "20480", "--no-cpu-baseline", "--no-extras"]
+
+
+def _run(tmp_path, tag, world, extra, port):
+    dump = str(tmp_path / tag)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OHS_BENCH_DIST_BACKEND="gloo", OHS_BENCH_DUMP=dump)
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *COMMON, *extra]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+               "--gpus", str(world), *COMMON, *extra]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints ONE JSON line
+    rec = json.loads(lines[0])
+    shards = {}
+    for r in range(world):
+        a = np.load(dump + f".rank{r}.npy")
+        shards[r] = (int(a[0]), int(a[1]), a[2:])
+    return rec, shards
+
+
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu_matches_single_rank(tmp_path, mode):
+    if mode == "weak":
+        two, one = ["--streams", "6"], ["--streams", "12"]
+    else:
+        two, one = ["--total-streams", "12"], ["--total-streams", "12"]
+    rec2, sh2 = _run(tmp_path, "w2" + mode, 2, two, 29541 if mode == "weak" else 29543)
+    rec1, sh1 = _run(tmp_path, "w1" + mode, 1, one, 0)
+    assert rec2["n_gpus"] == 2 and rec1["n_gpus"] == 1
+    assert rec2["scaling"] == mode and rec2["config"]["total_streams"] == 12
+    assert rec2["config"]["streams_per_gpu"] == 6 and rec2["finite"] and rec2["value"] > 0
+    assert rec2["steps"] == 2 and rec2["warmup"] == 1 and rec2["unit"] == "Msamples/s"
+    # disjoint, contiguous, covering
+    assert (sh2[0][0], sh2[0][1], sh2[1][0], sh2[1][1]) == (0, 6, 6, 12)
+    assert (sh1[0][0], sh1[0][1]) == (0, 12)
+    full = sh1[0][2].reshape(12, 2, 4096)
+    for r in (0, 1):
+        lo, hi, data = sh2[r]
+        assert np.array_equal(data.reshape(hi - lo, 2, 4096), full[lo:hi]), f"rank {r} differs from the single-rank run"

@@ -33,7 +33,7 @@ def main():
     f = load(fpath, "FETCH_SIZE")
     w = load(wpath, "WRITE_SIZE")
     out = {"_note": "per-launch averages; fetch corrected x2 for gfx950 (FETCH_SIZE counts 128-B requests as 64 B)",
-           "_source": [os.path.basename(fpath), os.path.basename(wpath)]}
+           "_source": [os.path.basename(fpath), os.path.basename(wpath)], "_tag": tag}
     for k in sorted(set(f) | set(w)):
         fv, wv = f.get(k, [0.0]), w.get(k, [0.0])
         fb = sum(fv) / len(fv) * 1024.0 * 2.0
