@@ -91,6 +91,20 @@ int  ohs_engine_process_block(ohs_engine *e, const float *in_l, const float *in_
                               float *out_l, float *out_r, size_t n);
 /* engine.paths[p].ir_fft_partitions.len()  (asserted by the reference test, convolution.rs:395-399) */
 int  ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out);
+/* Real-time mode (no reference counterpart -- the reference runs on the audio
+ * thread's CPU).  enable != 0 starts a RESIDENT kernel (one workgroup) that serves ohs_engine_process_block --
+ * and ohs_chain_process without EQ -- through a mailbox in pinned host memory: a call of n <= 8192 frames
+ * launches nothing, allocates nothing and costs one doorbell round trip + one block's computation.  Results
+ * are bit-identical to the launch-per-call path.  The kernel leaves the GPU when real-time mode is switched
+ * off, on set_ir / clone / destroy / any call it cannot serve (it is restarted by the next call it can), and by
+ * itself after ~2 s without a call.  Same threading rule as every handle: one thread at a time. */
+int  ohs_engine_set_realtime(ohs_engine *e, int enable);
+/* Delay the FIFO adapter of process_block adds for a constant host block size n (convolution.rs:163-181):
+ * 0 when n is a multiple of 512; otherwise the frames answered with silence before the output FIFO can
+ * serve every call (e.g. 256 for n = 256).  What a plugin host reports as its latency for compensation. */
+int  ohs_engine_latency_samples(const ohs_engine *e, size_t n, size_t *latency);
+/* Frames this engine has answered with that silence so far = its current delay in frames. */
+int  ohs_engine_silent_frames(const ohs_engine *e, uint64_t *frames);
 
 /* ---- StereoParametricEQ  (src/dsp/parametric_eq.rs:125-210) ------------------ */
 typedef struct ohs_eq ohs_eq;
@@ -114,6 +128,12 @@ int  ohs_eq_get_band_coeffs(const ohs_eq *eq, size_t band, float coeffs[5], int 
  * finite samples, except that a -0.0 may come out as +0.0; a non-finite INPUT sample makes the output
  * non-finite from up to 16 samples before it (the reference: from that sample on).  DESIGN.md 4.4. */
 int  ohs_eq_process_block(ohs_eq *eq, float *left, float *right, size_t n);
+/* Opt-in exactness for the two special-value corners above (default off): with enable != 0 the EQ runs its
+ * "conveyor" kernel, in which samples move between lanes by register moves only -- a -0.0 stays -0.0 and a
+ * non-finite input sample affects the output from that sample on, exactly as in the reference -- at ~1.4x the
+ * time of the default kernel.  Audio hosts do not produce such samples; offline jobs that must be bit-exact on
+ * arbitrary data switch it on. */
+int  ohs_eq_set_exact_specials(ohs_eq *eq, int enable);
 /* reset_all_bands_state  parametric_eq.rs:181-188 (also Plugin::reset, lib.rs:1152-1154). */
 int  ohs_eq_reset(ohs_eq *eq);
 /* calculate_frequency_response(fs, &[f32]) -> Vec<f32>  parametric_eq.rs:190-209
@@ -193,6 +213,7 @@ int  ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_ty
                               float q, float gain_db, int enabled);
 /* eq_enable / output gain of lib.rs:1179,1202 */
 int  ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable);
+int  ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable);    /* see ohs_eq_set_exact_specials */
 int  ohs_batch_set_gain(ohs_batch *b, float gain);
 /* zero every stream's EQ state, history and overlap (IRs and EQ table kept) */
 int  ohs_batch_reset(ohs_batch *b);

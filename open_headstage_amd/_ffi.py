@@ -45,6 +45,9 @@ PROTOTYPES = {
     "ohs_engine_set_ir": (C.c_int, [vp, C.c_int, fp, C.c_size_t]),
     "ohs_engine_process_block": (C.c_int, [vp, fp, fp, fp, fp, C.c_size_t]),
     "ohs_engine_num_partitions": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
+    "ohs_engine_set_realtime": (C.c_int, [vp, C.c_int]),
+    "ohs_engine_latency_samples": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ohs_engine_silent_frames": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "ohs_biquad_coeffs": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp]),
     "ohs_eq_create": (C.c_int, [C.c_int, C.c_size_t, C.c_float, vpp]),
     "ohs_eq_destroy": (None, [vp]),
@@ -54,6 +57,8 @@ PROTOTYPES = {
     "ohs_eq_get_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.POINTER(C.c_int)]),
     "ohs_eq_process_block": (C.c_int, [vp, fp, fp, C.c_size_t]),
     "ohs_eq_reset": (C.c_int, [vp]),
+    "ohs_eq_set_exact_specials": (C.c_int, [vp, C.c_int]),
+    "ohs_batch_set_eq_exact_specials": (C.c_int, [vp, C.c_int]),
     "ohs_eq_frequency_response": (C.c_int, [vp, C.c_float, fp, C.c_size_t, fp]),
     "ohs_autoeq_parse_csv": (C.c_int, [C.c_char_p, C.POINTER(BandSettingC), C.c_size_t,
                                        C.POINTER(C.c_size_t)]),

@@ -45,6 +45,9 @@ class BatchProcessor:
     def set_eq_enabled(self, eq_enable: bool) -> None:
         check(lib().ohs_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
 
+    def set_eq_exact_specials(self, enable: bool) -> None:
+        check(lib().ohs_batch_set_eq_exact_specials(self._h, int(bool(enable))))
+
     def set_gain(self, gain: float) -> None:
         check(lib().ohs_batch_set_gain(self._h, float(gain)))
 

@@ -90,23 +90,39 @@ struct PlainIO {
 // pinned host memory mapped into the device, or the EQ's device output); output frame j goes
 // straight to the mapped host buffer when it is popped by this call, else to its post-pop position
 // in the device FIFO.  One launch, no separate copies.
-struct EngineIO {
+// SYSTEM = true (the resident kernel): the host-visible accesses -- this call's input frames and its popped
+// output frames, both in pinned host memory -- are system-scope loads / stores (`sc0 sc1`: they bypass this CU's
+// L1 and are written through), so that neither a cache invalidate in front of the call nor a write-back of the
+// whole L2 behind it is needed; the device-resident state goes through the caches as usual.
+template <bool SYSTEM>
+struct EngineIOT {
     EngineCallArgs E;
+    static __device__ __forceinline__ float ld(const float *p)
+    {
+        if constexpr (SYSTEM) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else return *p;
+    }
+    static __device__ __forceinline__ void st(float *p, float v)
+    {
+        if constexpr (SYSTEM) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else *p = v;
+    }
     __device__ __forceinline__ float2 load(size_t idx) const
     {
         if (idx < (size_t)E.in_len) return make_float2(E.in_fifo[idx], E.in_fifo[E.in_cap + idx]);
         const size_t k = idx - E.in_len;
-        return make_float2(E.src_l[k], E.src_r[k]);
+        return make_float2(ld(E.src_l + k), ld(E.src_r + k));
     }
     __device__ __forceinline__ void store(size_t idx, float l, float r) const
     {
         const size_t j = (size_t)E.out_len + idx;
         if (E.emit) {
-            if (j < (size_t)E.n) { E.host_l[j] = l * E.gain_pop; E.host_r[j] = r * E.gain_pop; }
+            if (j < (size_t)E.n) { st(E.host_l + j, l * E.gain_pop); st(E.host_r + j, r * E.gain_pop); }
             else { E.out_fifo[j - E.n] = l; E.out_fifo[E.out_cap + j - E.n] = r; }
         } else { E.out_fifo[j] = l; E.out_fifo[E.out_cap + j] = r; }
     }
 };
+using EngineIO = EngineIOT<false>;
 
 // ---- the three per-block pieces of convolve_path_partitioned, shared by the sequential general body and
 // the one-wave-per-block engine call ----
@@ -236,23 +252,24 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
     conv_general_body(A, io, tab, lds, lane, blockIdx.x);
 }
 
-// One launch = one ConvolutionEngine::process_block call for a single stream (f2).  One WAVE PER BLOCK:
-// the k <= 8 internal blocks of a call only couple through the history ring (P > 1) and the 512-sample
+// One ConvolutionEngine::process_block call for a single stream (f2), executed by one workgroup.  One WAVE PER
+// BLOCK: the k <= 8 internal blocks of a call only couple through the history ring (P > 1) and the 512-sample
 // overlap tails, so they run side by side and exchange those through memory / LDS at two barriers --
 // the call's latency is one block's (forward FFT, MAC, two inverse FFTs), not k of them.
-__global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E)
+// Every thread of the workgroup must call it (it contains workgroup barriers); `tab` holds the twiddle
+// tables, `slabs` n_waves per-wave FFT slabs.
+template <bool SYSTEM>
+__device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const EngineCallArgs &E, float2 *tab,
+                                                 float2 *slabs, int wave, int lane, int n_waves)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float2 *tab = smem;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
-    fill_twiddle_tables(tab, A.tw, threadIdx.x, blockDim.x);
+    using IO = EngineIOT<SYSTEM>;
+    float2 *lds = slabs + wave * kWaveLdsComplex;
     // 1. frames already waiting in the output FIFO: pop what this call takes, slide the rest down
     if (wave == 0 && E.out_len > 0 && E.emit) {
         const int take = E.out_len < E.n ? E.out_len : E.n;
         for (int i = lane; i < take; i += 64) {
-            E.host_l[i] = E.out_fifo[i] * E.gain_pop;
-            E.host_r[i] = E.out_fifo[E.out_cap + i] * E.gain_pop;
+            IO::st(E.host_l + i, E.out_fifo[i] * E.gain_pop);
+            IO::st(E.host_r + i, E.out_fifo[E.out_cap + i] * E.gain_pop);
         }
         for (int base = E.n; base < E.out_len; base += 64) {      // ascending, read-then-write per 64
             const int i = base + lane;
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
     }
     __syncthreads();
     // 2. every complete 512-block (convolution.rs:152-161), block t = wave
-    EngineIO io;
+    IO io;
     io.E = E;
     const int t = wave;
     const bool active = t < A.n_blocks;
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
     __syncthreads();
     if (active) {
         // overlap-add per path, then ear sums (:279-284, :228-231); gain on the popped frames only
-        const float2 *prev = t ? smem + kTabComplex + (wave - 1) * kWaveLdsComplex : A.tails;
+        const float2 *prev = t ? slabs + (wave - 1) * kWaveLdsComplex : A.tails;
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const float2 t1 = prev[a * 64 + lane], t2 = prev[(8 + a) * 64 + lane];
@@ -314,17 +331,105 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
         const int rem = E.in_len + E.n - consumed;
         if (A.n_blocks == 0) {
             for (int i = lane; i < E.n; i += 64) {
-                E.in_fifo[E.in_len + i] = E.src_l[i];
-                E.in_fifo[E.in_cap + E.in_len + i] = E.src_r[i];
+                E.in_fifo[E.in_len + i] = IO::ld(E.src_l + i);
+                E.in_fifo[E.in_cap + E.in_len + i] = IO::ld(E.src_r + i);
             }
         } else {
             // in_len < 512 <= consumed: the remainder lies entirely in this call's new frames
             for (int i = lane; i < rem; i += 64) {
-                E.in_fifo[i] = E.src_l[consumed - E.in_len + i];
-                E.in_fifo[E.in_cap + i] = E.src_r[consumed - E.in_len + i];
+                E.in_fifo[i] = IO::ld(E.src_l + consumed - E.in_len + i);
+                E.in_fifo[E.in_cap + i] = IO::ld(E.src_r + consumed - E.in_len + i);
             }
         }
     }
+}
+
+// One launch = one call.
+__global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, blockDim.x);
+    engine_call_body<false>(A, E, tab, smem + kTabComplex, wave, lane, n_waves);   // its first barrier also covers the table fill
+}
+
+// RESIDENT form ("persistent kernels + pinned-memory mailboxes"): one workgroup of 8
+// waves stays on a CU and serves ConvolutionEngine::process_block calls handed over through a mailbox in
+// pinned, mapped host memory -- the host never launches anything per call:
+//   host  : copies the n input frames and the call's arguments into the mailbox, then stores `doorbell = seq`
+//   device: lane 0 polls the doorbell (one PCIe read per ~1 us), the workgroup runs engine_call_body, every
+//           wave drains its stores, one system-scope release, then `done = seq`
+//   host  : spins on `done`, copies the outputs
+// Exit conditions every wave reaches (the decision is taken by one lane and broadcast through LDS in front of
+// a barrier): `stop` set by the host (ohs_engine_set_realtime(0), set_ir, clone, destroy), or no doorbell for
+// `idle_limit` polls (a host that died or simply went quiet must not leave a wave spinning on the GPU); the
+// kernel announces its exit in `alive` so that a host ringing at that moment re-launches instead of waiting.
+__global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const float2 *tw, unsigned first_seq,
+                                                         unsigned long long idle_limit, unsigned sleep_arg)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *slabs = smem + kTabComplex;
+    __shared__ unsigned s_cmd;
+    __shared__ unsigned s_args[(sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    fill_twiddle_tables(tab, tw, threadIdx.x, 512);
+    unsigned last = first_seq;              // the doorbell value already served
+    for (;;) {
+        if (threadIdx.x == 0) {
+            unsigned cmd = 0;
+            unsigned long long idle = 0;
+            for (;;) {
+                if (__hip_atomic_load(&mb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+                const unsigned d = __hip_atomic_load(&mb->doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (d != last) { last = d; cmd = 1; break; }
+                if (++idle >= idle_limit) break;
+                for (unsigned k = 0; k < sleep_arg; ++k) __builtin_amdgcn_s_sleep(16);     // ~0.4 us each
+            }
+            s_cmd = cmd;
+        }
+        __syncthreads();
+        if (s_cmd == 0) break;              // uniform: s_cmd is read by every thread after the barrier
+        // the host's writes (arguments, input frames) precede its doorbell store; make them visible here
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (wave == 0) {
+            const unsigned *src = reinterpret_cast<const unsigned *>(&mb->conv);
+            constexpr int words = (int)((sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4);
+            for (int i = lane; i < words; i += 64) s_args[i] = src[i];
+        }
+        __syncthreads();
+        const ConvGeneralArgs &A = *reinterpret_cast<const ConvGeneralArgs *>(s_args);
+        const EngineCallArgs &E = *reinterpret_cast<const EngineCallArgs *>(
+            reinterpret_cast<const char *>(s_args) + sizeof(ConvGeneralArgs));
+        engine_call_body<false>(A, E, tab, slabs, wave, lane, 8);
+        // publish: every wave's stores (outputs to host memory, state to device memory) drained, then one
+        // system-scope release in front of the flag.  (Tried: system-scope `sc0 sc1` loads / stores for the
+        // host-visible frames in place of both fences -- engine_call_body<true> -- no faster per call, and not
+        // bit-identical to the launch-per-call path in tests/test_gpu_realtime.py; the fences stay.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&mb->done, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned first_seq, unsigned long long idle_limit,
+                                  unsigned sleep_arg, hipStream_t st)
+{
+    const size_t shmem = (kTabComplex + 8 * (size_t)kWaveLdsComplex) * sizeof(float2);   // 77 KiB
+    static std::atomic<unsigned long long> lds_ok{0};
+    const hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_engine_resident), shmem, lds_ok);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_engine_resident, dim3(1), dim3(512), shmem, st, mb_dev, tw, first_seq, idle_limit, sleep_arg);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st)

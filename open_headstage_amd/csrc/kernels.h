@@ -44,6 +44,20 @@ struct EngineCallArgs {
 };
 hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st);
 
+// Mailbox of the resident real-time kernel, in pinned + mapped host memory (one per engine).  `conv` and `call`
+// must stay adjacent: the kernel copies them into LDS as one block.
+struct RtMailbox {
+    unsigned doorbell;          // host -> device: sequence number of the call to serve
+    unsigned done;              // device -> host: sequence number of the last call completed
+    unsigned stop;              // host -> device: leave
+    unsigned alive;             // device -> host: 0 once the kernel has decided to exit
+    unsigned pad[12];
+    ConvGeneralArgs conv;
+    EngineCallArgs call;
+};
+hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned first_seq, unsigned long long idle_limit,
+                                  unsigned sleep_arg, hipStream_t st);
+
 // Fast path when every path has exactly one partition (taps <= 512): time-parallel over
 // `chunks` contiguous block ranges per stream, one forward + one inverse FFT per block, the
 // combined spectra C = (A - jB)/2, D = (A + jB)/2 (A = H0 + jH1, B = H2 + jH3) held in LDS.
@@ -134,9 +148,12 @@ constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
 // chains = streams * 2 (L, R); chain c -> stream c>>1, channel c&1.
 // state: [chain][kEqStateSlots][2] (s1, s2), indexed by the band's own index.
 // n_bands = bands of this pass (1..16, lanes >= n_bands are unused).
+// exact_specials: use the conveyor form (k_eq_pass: samples move by DPP moves only) also for <= 12 bands; it is
+// bit-exact for -0.0 and for samples next to a non-finite input, where the faster ring form is not (its
+// pass-on lanes run 1*x + 0).
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
                           long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
-                          hipStream_t st);
+                          hipStream_t st, bool exact_specials = false);
 
 // |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
 hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,

@@ -10,6 +10,7 @@
 #include "host_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -386,6 +387,7 @@ struct EqState {
     std::vector<float> coeffs;   // nb * 5  {b0,b1,b2,a1,a2}
     std::vector<int> en;         // nb
     float *d_state = nullptr;    // [chains][kEqStateSlots][2], indexed by band
+    bool exact_specials = false; // ohs_*_set_eq_exact_specials: conveyor kernel, exact for -0.0 / around non-finite input
 };
 
 using ohs_host::rbj;
@@ -436,7 +438,7 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
                 t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
             }
         }
-        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st);
+        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
         did = true;
@@ -510,6 +512,12 @@ struct ohs_engine {
     float *dm_in = nullptr, *dm_out = nullptr;    // the same memory, device addresses
     float *d_eqbuf = nullptr;                     // device [2][hcap]
     size_t hcap = 0;
+    uint64_t silent_frames = 0;                   // frames answered with the zero fill of convolution.rs:176-181
+    // resident real-time kernel (ohs_engine_set_realtime): mailbox in pinned mapped memory, its own stream
+    bool rt_enabled = false, rt_running = false;
+    RtMailbox *mb = nullptr, *mb_dev = nullptr;
+    hipStream_t rt_st = nullptr;
+    unsigned rt_seq = 0;
 };
 
 struct ohs_eq {
@@ -665,6 +673,124 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
     } else {            // convolution.rs:176-181
         std::memset(out_l, 0, n * sizeof(float));
         std::memset(out_r, 0, n * sizeof(float));
+        e->silent_frames += n;
+    }
+    return OHS_OK;
+}
+
+// ---- resident real-time kernel: host side of the mailbox protocol (k_engine_resident) --------------------
+void rt_stop(ohs_engine *e)
+{
+    if (!e->rt_running) return;
+    __atomic_store_n(&e->mb->stop, 1u, __ATOMIC_RELEASE);
+    hipStreamSynchronize(e->rt_st);       // the kernel sees `stop` at its next poll (~1 us) and every wave leaves
+    e->rt_running = false;
+}
+
+int rt_start(ohs_engine *e)
+{
+    if (e->rt_running) {
+        if (__atomic_load_n(&e->mb->alive, __ATOMIC_ACQUIRE)) return OHS_OK;
+        hipStreamSynchronize(e->rt_st);   // it left by its idle limit
+        e->rt_running = false;
+    }
+    if (!e->mb) {
+        HIP_TRY(hipHostMalloc((void **)&e->mb, sizeof(RtMailbox), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&e->mb_dev, e->mb, 0));
+        HIP_TRY(hipStreamCreateWithFlags(&e->rt_st, hipStreamNonBlocking));
+        std::memset(e->mb, 0, sizeof(RtMailbox));
+    }
+    // everything queued on the engine's own stream (set_ir, a launch-per-call block) must have finished: the
+    // resident kernel reads that state without any stream ordering
+    HIP_TRY(hipStreamSynchronize(e->st));
+    e->mb->stop = 0; e->mb->alive = 1;
+    e->mb->doorbell = e->rt_seq; e->mb->done = e->rt_seq;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    static const unsigned long long idle_limit = [] {
+        const char *v = getenv("OHS_RT_IDLE_POLLS");        // polls without a doorbell before the kernel leaves (~2 s)
+        return v ? strtoull(v, nullptr, 10) : 1500000ull;
+    }();
+    static const unsigned sleep_arg = [] {
+        const char *v = getenv("OHS_RT_POLL_SLEEP");
+        return v ? (unsigned)atoi(v) : 2u;
+    }();
+    hipError_t err = launch_engine_resident(e->mb_dev, e->ctx->d_tw, e->rt_seq, idle_limit, sleep_arg, e->rt_st);
+    if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(err));
+    e->rt_running = true;
+    return OHS_OK;
+}
+
+// One process_block call through the mailbox.  Same FIFO arithmetic as engine_process_single_launch; nothing
+// is launched, allocated or freed here while the kernel is resident (growth stops it first).
+int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r, float *out_l, float *out_r,
+                            size_t n, float gain)
+{
+    ConvState &c = e->conv;
+    const size_t k = (e->in.len + n) / BS;
+    const bool emit = e->out.len + k * BS >= n;
+    int maxP = 1;
+    for (int p = 0; p < 4; ++p) maxP = std::max(maxP, c.P[p]);
+    const bool grow = n > e->hcap || e->in.cap < (size_t)2 * BS || e->out.cap < e->out.len + k * BS + 1 || c.cap < maxP + 7;
+    if (grow) {
+        rt_stop(e);
+        int rc = engine_pinned_reserve(e, std::max<size_t>(n, 2048));
+        if (rc == OHS_OK) rc = fifo_reserve(e->in, 2 * BS, e->st);
+        if (rc == OHS_OK) rc = fifo_reserve(e->out, std::max<size_t>(e->out.len + k * BS + 1, 8 * BS + 8192), e->st);
+        if (rc == OHS_OK) rc = conv_grow_ring(c, maxP + 7, e->st);
+        if (rc) return rc;
+    }
+    int rc = rt_start(e);
+    if (rc) return rc;
+    std::memcpy(e->h_in, in_l, n * sizeof(float));
+    std::memcpy(e->h_in + e->hcap, in_r, n * sizeof(float));
+    RtMailbox *mb = e->mb;
+    ConvGeneralArgs &a = mb->conv;
+    a.in = nullptr; a.out = nullptr;
+    a.in_stream_stride = a.in_ch_stride = a.out_stream_stride = a.out_ch_stride = 0;
+    a.n_blocks = (int)k;
+    for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
+    a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
+    a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
+    a.tw = e->ctx->d_tw; a.gain = 1.0f;
+    EngineCallArgs &g = mb->call;
+    g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
+    g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
+    g.src_l = e->dm_in; g.src_r = e->dm_in + e->hcap;
+    g.host_l = e->dm_out; g.host_r = e->dm_out + e->hcap;
+    g.n = (int)n; g.emit = emit ? 1 : 0; g.gain_pop = gain;
+    const unsigned seq = ++e->rt_seq;
+    __atomic_store_n(&mb->doorbell, seq, __ATOMIC_RELEASE);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 1023u) == 0) {
+            if (!__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) && __atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) != seq) {
+                // the kernel left by its idle limit just as this call rang: start it again, it serves `seq`
+                hipStreamSynchronize(e->rt_st);
+                e->rt_running = false;
+                --e->rt_seq;                      // rt_start arms the mailbox with the last SERVED sequence number
+                rc = rt_start(e);
+                if (rc) return rc;
+                ++e->rt_seq;
+                __atomic_store_n(&mb->doorbell, seq, __ATOMIC_RELEASE);
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                rt_stop(e);
+                return fail(OHS_ERR_HIP, "resident kernel did not answer within 5 s");
+            }
+        }
+    }
+    c.cnt += k;
+    for (int p = 0; p < 4; ++p) c.since[p] += (long long)k;
+    e->in.len = e->in.len + n - k * BS;
+    e->out.len = emit ? e->out.len + k * BS - n : e->out.len + k * BS;
+    if (emit) {
+        std::memcpy(out_l, e->h_out, n * sizeof(float));
+        std::memcpy(out_r, e->h_out + e->hcap, n * sizeof(float));
+    } else {            // convolution.rs:176-181
+        std::memset(out_l, 0, n * sizeof(float));
+        std::memset(out_r, 0, n * sizeof(float));
+        e->silent_frames += n;
     }
     return OHS_OK;
 }
@@ -678,9 +804,12 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     if (!in_l || !in_r || !out_l || !out_r) return fail(OHS_ERR_INVALID_ARG, "NULL audio pointer");
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = e->st;
-    // real-time sized calls: everything in one launch; long offline calls: the multi-kernel path below
-    if ((e->in.len + n) / BS <= 8 && n <= 8192 && e->in.len < (size_t)BS)
-        return engine_process_single_launch(e, in_l, in_r, out_l, out_r, n, eq, gain);
+    // real-time sized calls: the resident kernel's mailbox (real-time mode, no EQ in the chain) or everything in
+    // one launch; long offline calls: the multi-kernel path below
+    const bool rt_sized = (e->in.len + n) / BS <= 8 && n <= 8192 && e->in.len < (size_t)BS;
+    if (rt_sized && e->rt_enabled && !eq) return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain);
+    rt_stop(e);         // the paths below launch kernels on the engine's state
+    if (rt_sized) return engine_process_single_launch(e, in_l, in_r, out_l, out_r, n, eq, gain);
     int rc = fifo_reserve(e->in, e->in.len + n, st);
     if (rc) return rc;
     // :149-150 append
@@ -720,6 +849,7 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
         HIP_TRY(hipStreamSynchronize(st));
         std::memset(out_l, 0, n * sizeof(float));
         std::memset(out_r, 0, n * sizeof(float));
+        e->silent_frames += n;
     }
     return OHS_OK;
 }
@@ -814,6 +944,9 @@ void ohs_engine_destroy(ohs_engine *e)
 {
     if (!e) return;
     hipSetDevice(e->device);
+    rt_stop(e);
+    if (e->rt_st) hipStreamDestroy(e->rt_st);
+    if (e->mb) hipHostFree(e->mb);
     if (e->st) hipStreamSynchronize(e->st);
     conv_free(e->conv);
     if (e->in.d) hipFree(e->in.d);
@@ -837,7 +970,9 @@ int ohs_engine_clone(const ohs_engine *src, ohs_engine **out)
     auto bail = [&](int code) { ohs_engine_destroy(e); return code; };
     const ConvState &s = src->conv;
     ConvState &d = e->conv;
+    rt_stop(const_cast<ohs_engine *>(src));      // state at rest (the clone itself starts outside real-time mode)
     hipStreamSynchronize(src->st);
+    e->silent_frames = src->silent_frames;
     for (int p = 0; p < 4; ++p) {
         hipFree(d.d_H[p]); d.d_H[p] = nullptr;
         if (hipMalloc(&d.d_H[p], (size_t)s.P[p] * NF * sizeof(float2)) != hipSuccess) return bail(fail(OHS_ERR_HIP, "hipMalloc"));
@@ -871,6 +1006,7 @@ int ohs_engine_set_ir(ohs_engine *e, int path, const float *ir, size_t len)
 {
     if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
+    rt_stop(e);         // the resident kernel holds pointers to the spectra and the ring; the next call restarts it
     int rc = conv_set_ir(e->conv, e->ctx, path, ir, len, e->st);
     if (rc) return rc;
     // k_engine_call runs the (up to 8) blocks of a call side by side: the ring must hold the P - 1
@@ -891,6 +1027,57 @@ int ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out)
 {
     if (!e || !out || path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "bad argument");
     *out = (size_t)e->conv.P[path];
+    return OHS_OK;
+}
+
+int ohs_engine_set_realtime(ohs_engine *e, int enable)
+{
+    if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    e->rt_enabled = enable != 0;
+    if (!e->rt_enabled) { rt_stop(e); return OHS_OK; }
+    // everything a real-time sized call needs is reserved now, so that the audio thread neither allocates nor
+    // launches: pinned staging for 8192 frames, FIFOs for eight blocks + a host block, the ring for P + 7 spectra
+    int maxP = 1;
+    for (int p = 0; p < 4; ++p) maxP = std::max(maxP, e->conv.P[p]);
+    int rc = engine_pinned_reserve(e, 8192);
+    if (rc == OHS_OK) rc = fifo_reserve(e->in, 2 * BS, e->st);
+    if (rc == OHS_OK) rc = fifo_reserve(e->out, 8 * BS + 8192 + 1, e->st);
+    if (rc == OHS_OK) rc = conv_grow_ring(e->conv, maxP + 7, e->st);
+    if (rc) return rc;
+    return rt_start(e);
+}
+
+int ohs_engine_silent_frames(const ohs_engine *e, uint64_t *frames)
+{
+    if (!e || !frames) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    *frames = e->silent_frames;
+    return OHS_OK;
+}
+
+// The reference adds no latency when n is a multiple of 512; otherwise process_block answers with silence
+// until its output FIFO holds n frames (convolution.rs:163-181), and every silent call delays the stream by n
+// frames for good.  Pure FIFO arithmetic, simulated from an empty engine over several periods of the
+// (n, 512) pattern.
+int ohs_engine_latency_samples(const ohs_engine *e, size_t n, size_t *latency)
+{
+    (void)e;
+    if (!latency) return fail(OHS_ERR_INVALID_ARG, "latency is NULL");
+    if (n == 0 || n > ((size_t)1 << 30)) return fail(OHS_ERR_INVALID_ARG, "n out of range");
+    size_t in_len = 0, out_len = 0, silent = 0;
+    size_t g = n, h = BS;
+    while (h) { const size_t t = g % h; g = h; h = t; }           // gcd(n, 512)
+    const size_t period = (size_t)BS / g;                         // calls after which in_len repeats
+    size_t since_silent = 0;
+    for (size_t i = 0; i < 64 * period + 64 && since_silent <= 4 * period + 4; ++i) {
+        in_len += n;
+        const size_t k = in_len / BS;
+        in_len -= k * BS;
+        out_len += k * BS;
+        if (out_len >= n) { out_len -= n; ++since_silent; }
+        else { silent += n; since_silent = 0; }
+    }
+    *latency = silent;
     return OHS_OK;
 }
 
@@ -1018,6 +1205,13 @@ int ohs_eq_process_block(ohs_eq *q, float *left, float *right, size_t n)
     HIP_TRY(hipMemcpyAsync(left, q->d_buf, n * sizeof(float), hipMemcpyDeviceToHost, q->st));
     HIP_TRY(hipMemcpyAsync(right, q->d_buf + q->buf_cap, n * sizeof(float), hipMemcpyDeviceToHost, q->st));
     HIP_TRY(hipStreamSynchronize(q->st));
+    return OHS_OK;
+}
+
+int ohs_eq_set_exact_specials(ohs_eq *q, int enable)
+{
+    if (!q) return fail(OHS_ERR_INVALID_ARG, "eq is NULL");
+    q->eq.exact_specials = enable != 0;
     return OHS_OK;
 }
 
@@ -1160,6 +1354,13 @@ int ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     b->eq_enable = eq_enable != 0;
+    return OHS_OK;
+}
+
+int ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    b->eq.exact_specials = enable != 0;
     return OHS_OK;
 }
 

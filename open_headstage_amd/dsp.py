@@ -101,6 +101,21 @@ class ConvolutionEngine:
         check(lib().ohs_engine_num_partitions(self._h, int(path), C.byref(n)))
         return int(n.value)
 
+    def set_realtime(self, enable: bool) -> None:
+        """Resident-kernel mode for real-time sized calls (ohs_engine_set_realtime)."""
+        check(lib().ohs_engine_set_realtime(self._h, int(bool(enable))))
+
+    def latency_samples(self, n: int) -> int:
+        """Delay of the FIFO adapter for a constant host block size n (convolution.rs:163-181)."""
+        v = C.c_size_t()
+        check(lib().ohs_engine_latency_samples(self._h, int(n), C.byref(v)))
+        return int(v.value)
+
+    def silent_frames(self) -> int:
+        v = C.c_uint64()
+        check(lib().ohs_engine_silent_frames(self._h, C.byref(v)))
+        return int(v.value)
+
     def process_block(self, input_left, input_right, output_left=None, output_right=None):
         il, ir = _in(input_left), _in(input_right)
         if il.size != ir.size:
@@ -164,6 +179,10 @@ class StereoParametricEQ:
         if input_left.size != input_right.size:
             raise ValueError("left / right length mismatch")
         check(lib().ohs_eq_process_block(self._h, _ptr(input_left), _ptr(input_right), input_left.size))
+
+    def set_exact_specials(self, enable: bool) -> None:
+        """Opt into bit-exact handling of -0.0 and of samples around a non-finite input (ohs_eq_set_exact_specials)."""
+        check(lib().ohs_eq_set_exact_specials(self._h, int(bool(enable))))
 
     def reset_all_bands_state(self) -> None:
         check(lib().ohs_eq_reset(self._h))

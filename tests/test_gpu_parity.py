@@ -550,6 +550,48 @@ def test_eq_ring_documented_edge_cases_signed_zero_and_non_finite_input(ohs, syn
     assert np.isnan(ol[k:]).all() and np.isnan(gl[k:]).all()
 
 
+@pytest.mark.parametrize("nb_on", [1, 7, 10, 12])
+def test_eq_exact_specials_mode_is_bit_exact_on_signed_zeros_and_around_non_finite_input(ohs, synth, oracle, nb_on):
+    """ohs_eq_set_exact_specials / ohs_batch_set_eq_exact_specials: the conveyor kernel moves samples by DPP
+    moves only, so -0.0 keeps its sign bit and a non-finite input sample changes nothing before itself --
+    every bit equals the oracle's, also the NaN pattern after the bad sample's position."""
+    import torch
+    bands = synth.eq_table()[:nb_on]
+    n = 4096
+    for case in ("negzero", "nan", "inf"):
+        eg, eo = _mk_eqs(ohs, oracle, bands)
+        eg.set_exact_specials(True)
+        x = synth.white_noise([40 + nb_on], n)[0]
+        if case == "negzero":
+            x[:, 700:900] = -0.0
+            x[1, :64] = -0.0
+        elif case == "nan":
+            x[0, 2500] = np.nan
+        else:
+            x[1, 1234] = np.inf
+        gl, gr = x[0].copy(), x[1].copy(); ol, orr = x[0].copy(), x[1].copy()
+        eg.process_block(gl, gr); eo.process_block(ol, orr)
+        for g, o, ch in ((gl, ol, "L"), (gr, orr, "R")):
+            fin = np.isfinite(o)
+            assert np.array_equal(np.isfinite(g), fin), (case, ch)
+            assert np.array_equal(g[fin].view(np.uint32), o[fin].view(np.uint32)), (case, ch)
+    # batch entry point: on ordinary samples the two EQ kernels agree bit for bit, so the whole chain does
+    S = 3
+    irs = synth.hrir_set(512)
+    outs = []
+    for exact in (False, True):
+        bp = ohs.BatchProcessor(S, num_bands=len(bands))
+        for p in range(4):
+            bp.set_ir(p, irs[p])
+        for i, b in enumerate(bands):
+            bp.update_band_coeffs(i, synth.FS, b)
+        bp.set_eq_enabled(True)
+        bp.set_eq_exact_specials(exact)
+        x = synth.white_noise(range(S), 80 * 512)
+        outs.append(bp.process(torch.from_numpy(x).cuda()).cpu().numpy())
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
 def test_batch_deferred_join_is_bit_identical_and_mixes_with_everything(ohs, synth, oracle):
     """ohs_batch_process_deferred pipelines back-to-back calls (the next call's EQ starts while the last
     convolution chunk of the previous one finishes).  Same bits as ohs_batch_process, whatever follows a

@@ -1,0 +1,152 @@
+"""Resident real-time mode: ConvolutionEngine::process_block served by a kernel that
+stays on the GPU and is fed through a mailbox in pinned host memory.  Same bits as the launch-per-call path and
+the oracle's FIFO semantics (ragged host blocks, zero fill), restarts after set_ir / clone / oversize calls /
+idle exit, and the latency report of the FIFO adapter."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests.util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ohs():
+    import open_headstage_amd
+    return open_headstage_amd
+
+
+@pytest.fixture()
+def synth():
+    from open_headstage_amd import synth as s
+    return s
+
+
+def _pair(ohs, synth, taps):
+    irs = synth.hrir_set(taps)
+    a, b = ohs.ConvolutionEngine.new(), ohs.ConvolutionEngine.new()
+    for p in range(4):
+        a.set_ir(p, irs[p]); b.set_ir(p, irs[p])
+    return a, b, irs
+
+
+@pytest.mark.parametrize("taps", [128, 512, 1300, 4096])
+def test_realtime_mode_is_bit_identical_to_launch_per_call(ohs, synth, taps):
+    rt, ref, _ = _pair(ohs, synth, taps)
+    rt.set_realtime(True)
+    sizes = [1024, 1024, 256, 100, 512, 37, 2048, 1024, 4096, 1, 511, 513, 1024, 8192, 64, 64, 1024]
+    x = synth.white_noise([5], sum(sizes))[0]
+    o = 0
+    for n in sizes:
+        l, r = x[0, o:o + n].copy(), x[1, o:o + n].copy()
+        gl, gr = rt.process_block(l, r)
+        el, er = ref.process_block(l, r)
+        assert np.array_equal(gl.view(np.uint32), el.view(np.uint32)) and np.array_equal(gr.view(np.uint32), er.view(np.uint32)), (taps, n, o)
+        o += n
+    assert rt.silent_frames() == ref.silent_frames()
+
+
+def test_realtime_mode_against_the_oracle_with_restarts(ohs, synth, oracle):
+    rt, _, irs = _pair(ohs, synth, 512)
+    eo = oracle.ConvolutionEngine()
+    for p in range(4):
+        eo.set_ir(p, irs[p])
+    rt.set_realtime(True)
+    x = synth.white_noise([6], 60000)[0]
+    outs_g, outs_o = [], []
+    o = 0
+    rng = np.random.default_rng(3)
+    step = 0
+    while o + 20000 < x.shape[1]:
+        n = int(rng.choice([1024, 1024, 1024, 480, 256, 2048, 10000]))     # 10000 > 8192: not served by the kernel
+        l, r = x[0, o:o + n].copy(), x[1, o:o + n].copy()
+        outs_g.append(np.stack(rt.process_block(l, r)))
+        outs_o.append(np.stack(eo.process_block(l, r)))
+        o += n
+        step += 1
+        if step == 7:                       # set_ir stops the kernel; the next call restarts it
+            irs2 = synth.hrir_set(700)
+            rt.set_ir(1, irs2[1]); eo.set_ir(1, irs2[1])
+        if step == 11:                      # a clone taken while the kernel is resident carries the state
+            c = rt.clone()
+            co = eo.clone()
+            l2, r2 = x[0, o:o + 1024].copy(), x[1, o:o + 1024].copy()
+            assert_parity(np.stack(c.process_block(l2, r2)), np.stack(co.process_block(l2, r2)), "clone of a real-time engine")
+    assert_parity(np.concatenate(outs_g, 1), np.concatenate(outs_o, 1), "real-time engine vs oracle")
+    rt.set_realtime(False)
+    l, r = x[0, o:o + 1024].copy(), x[1, o:o + 1024].copy()
+    assert_parity(np.stack(rt.process_block(l, r)), np.stack(eo.process_block(l, r)), "after leaving real-time mode")
+
+
+def test_resident_kernel_leaves_by_itself_when_idle_and_is_restarted(ohs, synth):
+    """OHS_RT_IDLE_POLLS is read once per process, so the idle exit is exercised in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+import open_headstage_amd as ohs
+from open_headstage_amd import synth
+irs = synth.hrir_set(512)
+a, b = ohs.ConvolutionEngine.new(), ohs.ConvolutionEngine.new()
+for p in range(4):
+    a.set_ir(p, irs[p]); b.set_ir(p, irs[p])
+a.set_realtime(True)
+x = synth.white_noise([9], 8 * 1024)[0]
+for i in range(8):
+    if i in (3, 6):
+        time.sleep(0.6)            # > idle limit: the kernel has left, this call must restart it
+    l, r = x[0, i*1024:(i+1)*1024].copy(), x[1, i*1024:(i+1)*1024].copy()
+    g = a.process_block(l, r); e = b.process_block(l, r)
+    assert np.array_equal(g[0], e[0]) and np.array_equal(g[1], e[1]), i
+print("idle-exit ok")
+""" % root
+    env = dict(os.environ, OHS_RT_IDLE_POLLS="20000")       # ~30 ms at ~1.5 us per poll
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "idle-exit ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
+
+
+def test_latency_report_matches_the_fifo_rule(ohs, synth, oracle):
+    e = ohs.ConvolutionEngine.new()
+    assert e.latency_samples(512) == 0 and e.latency_samples(1024) == 0 and e.latency_samples(4096) == 0
+    assert e.latency_samples(256) == 256                      # one silent call, then every call is served
+    for n in (1, 37, 100, 256, 300, 480, 511, 513, 700, 1000, 1025, 3000):
+        # the rule itself, straight from convolution.rs:149-181, run long enough to settle
+        in_len = out_len = silent = 0
+        for _ in range(6000):
+            in_len += n
+            k = in_len // 512
+            in_len -= 512 * k
+            out_len += 512 * k
+            if out_len >= n:
+                out_len -= n
+            else:
+                silent += n
+        assert e.latency_samples(n) == silent, n
+    # and the engine's own counter follows it on real calls (delta HRIR: the served calls, put end to end, are
+    # the input stream; the silent calls -- not necessarily the first ones -- are the inserted delay)
+    eng = ohs.ConvolutionEngine.new()
+    d = np.zeros(8, np.float32); d[0] = 1.0
+    eng.set_ir(0, d); eng.set_ir(3, d)
+    n = 300
+    x = synth.white_noise([2], 60 * n)[0]
+    served, in_len, out_len, silent = [], 0, 0, 0
+    for c in range(60):
+        g = np.stack(eng.process_block(x[0, c*n:(c+1)*n].copy(), x[1, c*n:(c+1)*n].copy()))
+        in_len += n
+        k = in_len // 512
+        in_len -= 512 * k
+        out_len += 512 * k
+        if out_len >= n:
+            out_len -= n
+            served.append(g)
+        else:
+            silent += n
+            assert np.all(g == 0), c
+    assert eng.silent_frames() == silent == eng.latency_samples(n) and silent > 0
+    got = np.concatenate(served, 1)
+    assert_parity(got, x[:, :got.shape[1]], "delta HRIR: the served calls are the input stream, end to end")

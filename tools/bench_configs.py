@@ -85,6 +85,15 @@ def run_engine_c2(calls=400, n=1024):
     st = _per_call(lambda l, r: e.process_block(l, r, ol, orr), bl[20:])
     print(json.dumps({"config": f"c2_engine_{n}_blocking", "us_per_call": st["median"], "latency_us": st,
                       "x_realtime": round(n / (st["median"] * 1e-6) / 48000.0, 0)}), flush=True)
+    # the same calls served by the resident kernel (ohs_engine_set_realtime): no launch, no stream sync
+    e.set_realtime(True)
+    bl = blocks()
+    for l, r in bl[:20]:
+        e.process_block(l, r, ol, orr)
+    st = _per_call(lambda l, r: e.process_block(l, r, ol, orr), bl[20:])
+    print(json.dumps({"config": f"c2_engine_{n}_realtime_resident_kernel", "us_per_call": st["median"], "latency_us": st,
+                      "x_realtime": round(n / (st["median"] * 1e-6) / 48000.0, 0)}), flush=True)
+    e.set_realtime(False)
     bl = blocks()
     for l, r in bl[:20]:
         eq.process_block(l, r)
