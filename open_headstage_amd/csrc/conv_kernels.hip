@@ -292,7 +292,9 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     float2 v[16], acc1[16], acc2[16];
     if (active) {
         block_forward(io, t, v, lds, tab, lane);
-        block_store_history(A, hist, t, v, lane);
+        // with one partition everywhere nothing ever reads the ring: a path only sees blocks processed since its
+        // own last set_ir (the `since` gate), and growing a path's partition count IS a set_ir
+        if (maxP > 1) block_store_history(A, hist, t, v, lane);
     }
     __threadfence_block();      // the ring slots written above are read by the other waves' partitions
     __syncthreads();            // (also: every input frame has been read before step 3 rewrites the FIFO)
@@ -357,14 +359,19 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
 // RESIDENT form ("persistent kernels + pinned-memory mailboxes"): one workgroup of 8
 // waves stays on a CU and serves ConvolutionEngine::process_block calls handed over through a mailbox in
 // pinned, mapped host memory -- the host never launches anything per call:
-//   host  : copies the n input frames and the call's arguments into the mailbox, then stores `doorbell = seq`
-//   device: lane 0 polls the doorbell (one PCIe read per ~1 us), the workgroup runs engine_call_body, every
-//           wave drains its stores, one system-scope release, then `done = seq`
-//   host  : spins on `done`, copies the outputs
+//   start : the kernel copies the engine's state description (pointers, capacities, partition counts, block
+//           counters, FIFO fill) from the mailbox into LDS once; from then on it advances the counters itself,
+//           with the same integer arithmetic the host mirrors (convolution.rs:149-181)
+//   call  : host copies the n input frames to pinned memory, writes {n, gain} and then `seq` into ONE 16-byte
+//           word of the mailbox; lane 0 polls that word with a single 16-byte load (one PCIe read per ~1 us)
+//           and gets the call's arguments together with its doorbell
+//   done  : the workgroup runs engine_call_body, every wave drains its stores, one system-scope release, then
+//           `done = seq`; the host spins on it and copies the outputs
 // Exit conditions every wave reaches (the decision is taken by one lane and broadcast through LDS in front of
-// a barrier): `stop` set by the host (ohs_engine_set_realtime(0), set_ir, clone, destroy), or no doorbell for
-// `idle_limit` polls (a host that died or simply went quiet must not leave a wave spinning on the GPU); the
-// kernel announces its exit in `alive` so that a host ringing at that moment re-launches instead of waiting.
+// a barrier): `stop` set by the host (ohs_engine_set_realtime(0), set_ir, clone, destroy, a call the kernel
+// cannot serve), or no doorbell for `idle_limit` polls (a host that died or simply went quiet must not leave a
+// wave spinning on the GPU); the kernel announces its exit in `alive` so that a host ringing at that moment
+// re-launches instead of waiting.
 __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const float2 *tw, unsigned first_seq,
                                                          unsigned long long idle_limit, unsigned sleep_arg)
 {
@@ -372,18 +379,36 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     float2 *tab = smem;
     float2 *slabs = smem + kTabComplex;
     __shared__ unsigned s_cmd;
-    __shared__ unsigned s_args[(sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4];
+    __shared__ int s_n;
+    __shared__ float s_gain;
+    __shared__ __attribute__((aligned(16))) unsigned s_args[(sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     fill_twiddle_tables(tab, tw, threadIdx.x, 512);
+    {
+        const unsigned *src = reinterpret_cast<const unsigned *>(&mb->conv);
+        constexpr int words = (int)((sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4);
+        for (int i = threadIdx.x; i < words; i += 512) s_args[i] = src[i];
+    }
+    __syncthreads();
+    ConvGeneralArgs &A = *reinterpret_cast<ConvGeneralArgs *>(s_args);
+    EngineCallArgs &E = *reinterpret_cast<EngineCallArgs *>(reinterpret_cast<char *>(s_args) + sizeof(ConvGeneralArgs));
     unsigned last = first_seq;              // the doorbell value already served
     for (;;) {
         if (threadIdx.x == 0) {
             unsigned cmd = 0;
             unsigned long long idle = 0;
             for (;;) {
-                if (__hip_atomic_load(&mb->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
-                const unsigned d = __hip_atomic_load(&mb->doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (d != last) { last = d; cmd = 1; break; }
+                // {seq, n, gain, stop}: one aligned 16-byte read, so the arguments arrive with their doorbell
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 w;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=v"(w) : "v"(&mb->call_word[0]) : "memory");      // system scope: never served by a cache
+                if (w.w) break;                                         // stop
+                if (w.x != last) {
+                    last = w.x; cmd = 1;
+                    s_n = (int)w.y; s_gain = __uint_as_float(w.z);
+                    break;
+                }
                 if (++idle >= idle_limit) break;
                 for (unsigned k = 0; k < sleep_arg; ++k) __builtin_amdgcn_s_sleep(16);     // ~0.4 us each
             }
@@ -391,17 +416,17 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         }
         __syncthreads();
         if (s_cmd == 0) break;              // uniform: s_cmd is read by every thread after the barrier
-        // the host's writes (arguments, input frames) precede its doorbell store; make them visible here
+        // the host's writes (input frames) precede its doorbell store; make them visible to this CU
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        if (wave == 0) {
-            const unsigned *src = reinterpret_cast<const unsigned *>(&mb->conv);
-            constexpr int words = (int)((sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4);
-            for (int i = lane; i < words; i += 64) s_args[i] = src[i];
+        if (threadIdx.x == 0) {             // this call's FIFO arithmetic (convolution.rs:149-163)
+            const int n = s_n;
+            const int k = (E.in_len + n) / kBlock;
+            A.n_blocks = k;
+            E.n = n;
+            E.emit = (E.out_len + k * kBlock >= n) ? 1 : 0;
+            E.gain_pop = s_gain;
         }
         __syncthreads();
-        const ConvGeneralArgs &A = *reinterpret_cast<const ConvGeneralArgs *>(s_args);
-        const EngineCallArgs &E = *reinterpret_cast<const EngineCallArgs *>(
-            reinterpret_cast<const char *>(s_args) + sizeof(ConvGeneralArgs));
         engine_call_body<false>(A, E, tab, slabs, wave, lane, 8);
         // publish: every wave's stores (outputs to host memory, state to device memory) drained, then one
         // system-scope release in front of the flag.  (Tried: system-scope `sc0 sc1` loads / stores for the
@@ -413,7 +438,14 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&mb->done, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // advance the counters for the next call
+            const int k = A.n_blocks;
+            A.cnt += (unsigned long long)k;
+            for (int p = 0; p < 4; ++p) A.since[p] += k;
+            E.in_len = E.in_len + E.n - k * kBlock;
+            E.out_len = E.emit ? E.out_len + k * kBlock - E.n : E.out_len + k * kBlock;
         }
+        // (the barrier at the top of the loop orders these updates before the next call reads them)
     }
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

@@ -44,15 +44,15 @@ struct EngineCallArgs {
 };
 hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st);
 
-// Mailbox of the resident real-time kernel, in pinned + mapped host memory (one per engine).  `conv` and `call`
-// must stay adjacent: the kernel copies them into LDS as one block.
+// Mailbox of the resident real-time kernel, in pinned + mapped host memory (one per engine).
+// call_word = {seq, n, gain bits, stop}: the host writes n and gain, then seq (release); the device reads all
+// four with one aligned 16-byte load, so a new seq always comes with its own arguments.  `conv` and `call`
+// describe the engine's state when the kernel starts (it copies them once; they must stay adjacent).
 struct RtMailbox {
-    unsigned doorbell;          // host -> device: sequence number of the call to serve
-    unsigned done;              // device -> host: sequence number of the last call completed
-    unsigned stop;              // host -> device: leave
-    unsigned alive;             // device -> host: 0 once the kernel has decided to exit
-    unsigned pad[12];
-    ConvGeneralArgs conv;
+    alignas(64) unsigned call_word[4];
+    alignas(64) unsigned done;   // device -> host: sequence number of the last call completed
+    unsigned alive;              // device -> host: 0 once the kernel has decided to exit
+    alignas(64) ConvGeneralArgs conv;
     EngineCallArgs call;
 };
 hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned first_seq, unsigned long long idle_limit,

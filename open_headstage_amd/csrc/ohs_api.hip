@@ -682,7 +682,7 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
 void rt_stop(ohs_engine *e)
 {
     if (!e->rt_running) return;
-    __atomic_store_n(&e->mb->stop, 1u, __ATOMIC_RELEASE);
+    __atomic_store_n(&e->mb->call_word[3], 1u, __ATOMIC_RELEASE);
     hipStreamSynchronize(e->rt_st);       // the kernel sees `stop` at its next poll (~1 us) and every wave leaves
     e->rt_running = false;
 }
@@ -703,8 +703,25 @@ int rt_start(ohs_engine *e)
     // everything queued on the engine's own stream (set_ir, a launch-per-call block) must have finished: the
     // resident kernel reads that state without any stream ordering
     HIP_TRY(hipStreamSynchronize(e->st));
-    e->mb->stop = 0; e->mb->alive = 1;
-    e->mb->doorbell = e->rt_seq; e->mb->done = e->rt_seq;
+    // the engine's state as it stands; the kernel advances the counters by itself from here (the host mirrors them)
+    RtMailbox *mb = e->mb;
+    ConvState &c = e->conv;
+    ConvGeneralArgs &a = mb->conv;
+    a.in = nullptr; a.out = nullptr;
+    a.in_stream_stride = a.in_ch_stride = a.out_stream_stride = a.out_ch_stride = 0;
+    a.n_blocks = 0;
+    for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
+    a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
+    a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
+    a.tw = e->ctx->d_tw; a.gain = 1.0f;
+    EngineCallArgs &g = mb->call;
+    g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
+    g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
+    g.src_l = e->dm_in; g.src_r = e->dm_in + e->hcap;
+    g.host_l = e->dm_out; g.host_r = e->dm_out + e->hcap;
+    g.n = 0; g.emit = 0; g.gain_pop = 1.0f;
+    mb->call_word[0] = e->rt_seq; mb->call_word[1] = 0; mb->call_word[2] = 0; mb->call_word[3] = 0;
+    mb->done = e->rt_seq; mb->alive = 1;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     static const unsigned long long idle_limit = [] {
         const char *v = getenv("OHS_RT_IDLE_POLLS");        // polls without a doorbell before the kernel leaves (~2 s)
@@ -712,7 +729,7 @@ int rt_start(ohs_engine *e)
     }();
     static const unsigned sleep_arg = [] {
         const char *v = getenv("OHS_RT_POLL_SLEEP");
-        return v ? (unsigned)atoi(v) : 2u;
+        return v ? (unsigned)atoi(v) : 1u;
     }();
     hipError_t err = launch_engine_resident(e->mb_dev, e->ctx->d_tw, e->rt_seq, idle_limit, sleep_arg, e->rt_st);
     if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(err));
@@ -720,8 +737,8 @@ int rt_start(ohs_engine *e)
     return OHS_OK;
 }
 
-// One process_block call through the mailbox.  Same FIFO arithmetic as engine_process_single_launch; nothing
-// is launched, allocated or freed here while the kernel is resident (growth stops it first).
+// One process_block call through the mailbox.  Same FIFO arithmetic as engine_process_single_launch (the kernel
+// runs it too); nothing is launched, allocated or freed here while the kernel is resident (growth stops it first).
 int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r, float *out_l, float *out_r,
                             size_t n, float gain)
 {
@@ -733,9 +750,9 @@ int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r,
     const bool grow = n > e->hcap || e->in.cap < (size_t)2 * BS || e->out.cap < e->out.len + k * BS + 1 || c.cap < maxP + 7;
     if (grow) {
         rt_stop(e);
-        int rc = engine_pinned_reserve(e, std::max<size_t>(n, 2048));
+        int rc = engine_pinned_reserve(e, std::max<size_t>(n, 8192));
         if (rc == OHS_OK) rc = fifo_reserve(e->in, 2 * BS, e->st);
-        if (rc == OHS_OK) rc = fifo_reserve(e->out, std::max<size_t>(e->out.len + k * BS + 1, 8 * BS + 8192), e->st);
+        if (rc == OHS_OK) rc = fifo_reserve(e->out, std::max<size_t>(e->out.len + k * BS + 1, 8 * BS + 8192 + 1), e->st);
         if (rc == OHS_OK) rc = conv_grow_ring(c, maxP + 7, e->st);
         if (rc) return rc;
     }
@@ -744,35 +761,29 @@ int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r,
     std::memcpy(e->h_in, in_l, n * sizeof(float));
     std::memcpy(e->h_in + e->hcap, in_r, n * sizeof(float));
     RtMailbox *mb = e->mb;
-    ConvGeneralArgs &a = mb->conv;
-    a.in = nullptr; a.out = nullptr;
-    a.in_stream_stride = a.in_ch_stride = a.out_stream_stride = a.out_ch_stride = 0;
-    a.n_blocks = (int)k;
-    for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
-    a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
-    a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
-    a.tw = e->ctx->d_tw; a.gain = 1.0f;
-    EngineCallArgs &g = mb->call;
-    g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
-    g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
-    g.src_l = e->dm_in; g.src_r = e->dm_in + e->hcap;
-    g.host_l = e->dm_out; g.host_r = e->dm_out + e->hcap;
-    g.n = (int)n; g.emit = emit ? 1 : 0; g.gain_pop = gain;
     const unsigned seq = ++e->rt_seq;
-    __atomic_store_n(&mb->doorbell, seq, __ATOMIC_RELEASE);
+    unsigned gbits;
+    std::memcpy(&gbits, &gain, sizeof(gbits));
+    auto ring = [&]() {
+        mb->call_word[1] = (unsigned)n;
+        mb->call_word[2] = gbits;
+        __atomic_store_n(&mb->call_word[0], seq, __ATOMIC_RELEASE);
+    };
+    ring();
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) != seq) {
         if ((++spins & 1023u) == 0) {
             if (!__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) && __atomic_load_n(&mb->done, __ATOMIC_ACQUIRE) != seq) {
-                // the kernel left by its idle limit just as this call rang: start it again, it serves `seq`
+                // the kernel left by its idle limit just as this call rang: start it again (from the state before
+                // this call -- the host's counters have not been advanced yet), it then serves `seq`
                 hipStreamSynchronize(e->rt_st);
                 e->rt_running = false;
                 --e->rt_seq;                      // rt_start arms the mailbox with the last SERVED sequence number
                 rc = rt_start(e);
                 if (rc) return rc;
                 ++e->rt_seq;
-                __atomic_store_n(&mb->doorbell, seq, __ATOMIC_RELEASE);
+                ring();
             }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                 rt_stop(e);

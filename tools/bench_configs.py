@@ -93,6 +93,18 @@ def run_engine_c2(calls=400, n=1024):
     st = _per_call(lambda l, r: e.process_block(l, r, ol, orr), bl[20:])
     print(json.dumps({"config": f"c2_engine_{n}_realtime_resident_kernel", "us_per_call": st["median"], "latency_us": st,
                       "x_realtime": round(n / (st["median"] * 1e-6) / 48000.0, 0)}), flush=True)
+    # protocol floor: 8-frame calls (64 of them fill one block), i.e. mailbox round trips with almost no work
+    e2 = ohs.ConvolutionEngine.new()
+    for p in range(4):
+        e2.set_ir(p, irs[p])
+    e2.set_realtime(True)
+    tiny = [(np.zeros(8, np.float32), np.zeros(8, np.float32)) for _ in range(400)]
+    o8 = np.empty(8, np.float32); o8b = np.empty(8, np.float32)
+    for l, r in tiny[:20]:
+        e2.process_block(l, r, o8, o8b)
+    st = _per_call(lambda l, r: e2.process_block(l, r, o8, o8b), tiny[20:])
+    print(json.dumps({"config": "c2_resident_mailbox_round_trip_8_frames", "us_per_call": st["median"], "latency_us": st}), flush=True)
+    e2.set_realtime(False)
     e.set_realtime(False)
     bl = blocks()
     for l, r in bl[:20]:

@@ -1,0 +1,59 @@
+/* Per-call latency of ConvolutionEngine::process_block through the C ABI, as a native audio host sees it
+ * (no Python in the loop): launch-per-call path vs the resident real-time kernel, 1024-frame host blocks and a
+ * near-empty call (mailbox round trip).  4 x 512-tap HRIRs.
+ *   gcc -O2 -std=c99 -Iinclude -o tools/bin/rt_latency tools/rt_latency.c -Lopen_headstage_amd -lohs_hip -lm \
+ *       -Wl,-rpath,/root/repo/open_headstage_amd
+ *   gpurun -- tools/bin/rt_latency */
+#define _POSIX_C_SOURCE 199309L
+#include "ohs_hip.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_us(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
+}
+static int cmp(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return x < y ? -1 : x > y; }
+
+static void run(ohs_engine *e, size_t n, int calls, const char *what)
+{
+    float *il = calloc(n, 4), *ir = calloc(n, 4), *ol = calloc(n, 4), *orr = calloc(n, 4);
+    double *t = malloc(sizeof(double) * (size_t)calls);
+    unsigned s = 12345;
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; il[i] = (float)(s >> 8) / 8388608.0f - 1.0f; ir[i] = -il[i]; }
+    for (int c = 0; c < 50; ++c) ohs_engine_process_block(e, il, ir, ol, orr, n);
+    for (int c = 0; c < calls; ++c) {
+        const double t0 = now_us();
+        if (ohs_engine_process_block(e, il, ir, ol, orr, n)) { printf("error: %s\n", ohs_last_error()); exit(1); }
+        t[c] = now_us() - t0;
+    }
+    qsort(t, (size_t)calls, sizeof(double), cmp);
+    printf("{\"config\": \"%s\", \"frames\": %zu, \"us_median\": %.1f, \"us_p99\": %.1f, \"us_max\": %.1f, \"us_min\": %.1f}\n", what, n,
+           t[calls / 2], t[(int)(calls * 0.99)], t[calls - 1], t[0]);
+    free(il); free(ir); free(ol); free(orr); free(t);
+}
+
+int main(void)
+{
+    ohs_engine *e = NULL;
+    if (ohs_engine_create(0, &e)) { printf("create: %s\n", ohs_last_error()); return 1; }
+    float h[512];
+    for (int p = 0; p < 4; ++p) {
+        for (int i = 0; i < 512; ++i) h[i] = (i == 30 + 15 * (p == 1 || p == 2)) ? 1.0f : 0.3f * expf(-i / 85.0f) * ((i * 7919 % 13) - 6) / 60.0f;
+        ohs_engine_set_ir(e, p, h, 512);
+    }
+    run(e, 1024, 2000, "c_host_engine_1024_launch_per_call");
+    ohs_engine_set_realtime(e, 1);
+    run(e, 1024, 2000, "c_host_engine_1024_resident_kernel");
+    run(e, 8, 2000, "c_host_mailbox_round_trip_8_frames");
+    run(e, 256, 2000, "c_host_engine_256_resident_kernel");
+    ohs_engine_set_realtime(e, 0);
+    run(e, 256, 2000, "c_host_engine_256_launch_per_call");
+    ohs_engine_destroy(e);
+    return 0;
+}
