@@ -162,13 +162,27 @@ int  ohs_autoeq_parse_csv_text(const char *text, size_t len, ohs_band_setting *o
 
 /* ---- SOFA HRIR source  (src/sofa/loader.rs:79-199 + system libmysofa) -- SURVEY section 8 row f1 -- */
 /* A minimal reader for AES69 SimpleFreeFieldHRIR files (HDF5 subset, see csrc/sofa_reader.cpp).
- * Deliberately NOT libmysofa's extras: no loudness normalisation, no neighbour interpolation, no
- * resampling inside open (use ohs_sofa_resample_ir).  Angles are DEGREES, AES69 convention: azimuth
+ * ohs_sofa_open returns the file's own measurements untouched; libmysofa's conditioning (resampling inside
+ * open, loudness normalisation, neighbour interpolation) is opt-in through ohs_sofa_open_ex.  Angles are DEGREES, AES69 convention: azimuth
  * counter-clockwise from the front (positive = left), elevation up; radius in metres. */
 typedef struct ohs_sofa ohs_sofa;
 /* MySofa::open(path, ..)  loader.rs:79-130.  OHS_ERR_IO when the file cannot be opened
  * (SofaError::FileOpen, tested at loader.rs:244-257), OHS_ERR_PARSE when it is not a readable SOFA file. */
 int  ohs_sofa_open(const char *path, ohs_sofa **out);
+/* mysofa_open as the reference calls it (loader.rs:83-90) also CONDITIONS the data; ohs_sofa_open_ex does the same,
+ * step by step opt-in.  PARITY UNPINNED: libmysofa is not vendored under the reference and not available here;
+ * the steps restate its published algorithm (csrc/sofa_conditioning.cpp cites the libmysofa functions).
+ *   OHS_SOFA_RESAMPLE     every IR resampled to target_fs (Data.Delay scaled), as mysofa_resample -- with this
+ *                         build's Kaiser-sinc resampler, not libmysofa's speex resampler
+ *   OHS_SOFA_LOUDNESS     mysofa_loudness: all IRs scaled so that the frontal measurement's two ears have energy 2
+ *   OHS_SOFA_INTERPOLATE  ohs_sofa_get_hrtf_irs = mysofa_getfilter_float: query projected onto the measured radius
+ *                         range, inverse-distance interpolation of the nearest measurement with its neighbours in
+ *                         azimuth / elevation / radius, delays likewise */
+enum { OHS_SOFA_RESAMPLE = 1, OHS_SOFA_LOUDNESS = 2, OHS_SOFA_INTERPOLATE = 4, OHS_SOFA_MYSOFA_DEFAULTS = 7 };
+int  ohs_sofa_open_ex(const char *path, unsigned flags, float target_fs, ohs_sofa **out);
+int  ohs_sofa_loudness_factor(const ohs_sofa *s, float *factor);    /* what OHS_SOFA_LOUDNESS multiplied by (1 if off) */
+/* the six neighbours mysofa_neighborhood would hold for measurement m: +az, -az, +el, -el, +r, -r (-1 = none) */
+int  ohs_sofa_neighbors(const ohs_sofa *s, size_t m, int out[6]);
 void ohs_sofa_close(ohs_sofa *s);                                   /* Drop -> mysofa_close  loader.rs:64-73 */
 /* M measurements x R receivers x N taps, Data.SamplingRate (hrtf.N / DataSamplingRate, loader.rs:102-118) */
 int  ohs_sofa_info(const ohs_sofa *s, size_t *M, size_t *R, size_t *N, float *fs);

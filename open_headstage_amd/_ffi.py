@@ -65,6 +65,9 @@ PROTOTYPES = {
     "ohs_autoeq_parse_csv_text": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(BandSettingC), C.c_size_t,
                                             C.POINTER(C.c_size_t)]),
     "ohs_sofa_open": (C.c_int, [C.c_char_p, vpp]),
+    "ohs_sofa_open_ex": (C.c_int, [C.c_char_p, C.c_uint, C.c_float, vpp]),
+    "ohs_sofa_loudness_factor": (C.c_int, [vp, fp]),
+    "ohs_sofa_neighbors": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_int)]),
     "ohs_sofa_close": (None, [vp]),
     "ohs_sofa_info": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                 C.POINTER(C.c_float)]),

@@ -437,14 +437,7 @@ struct Reader {
 
 }  // namespace ohs_sofa_detail
 
-struct ohs_sofa {
-    size_t M = 0, R = 0, N = 0;
-    float fs = 0.f;
-    std::vector<float> ir;          // [M][R][N]
-    std::vector<float> pos_sph;     // [M][3] azimuth deg, elevation deg, radius m
-    std::vector<float> pos_xyz;     // [M][3]
-    std::vector<float> delay;       // [M][R] (or broadcast of [1][R]), samples
-};
+#include "sofa_internal.h"
 
 extern "C" void ohs_internal_set_error(const char *msg);     // ohs_api.hip: feeds ohs_last_error()
 namespace {
@@ -608,6 +601,13 @@ int ohs_sofa_nearest(const ohs_sofa *s, float az_deg, float el_deg, float radius
     if (!s || !index || s->M == 0) return sfail(OHS_ERR_INVALID_ARG, "bad argument");
     double q[3];
     s2c(az_deg, el_deg, radius_m, q);
+    if (s->flags & OHS_SOFA_INTERPOLATE) {      // mysofa_lookup projects the query onto the measured radius range first
+        const double r = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        double f = 1.0;
+        if (r > s->radius_max && r > 0) f = s->radius_max / r;
+        else if (r < s->radius_min && r > 0) f = s->radius_min / r;
+        q[0] *= f; q[1] *= f; q[2] *= f;
+    }
     double best = 1e300;
     size_t bi = 0;
     for (size_t m = 0; m < s->M; ++m) {       // nearest in Cartesian space, as a kd-tree lookup would return
@@ -634,6 +634,8 @@ int ohs_sofa_get_hrtf_irs(const ohs_sofa *s, float az_deg, float el_deg, float r
     if (!s || !left || !right) return sfail(OHS_ERR_INVALID_ARG, "NULL argument");
     if (s->N == 0) return sfail(OHS_ERR_PARSE, "Filter length is zero.");      // loader.rs:147-149
     if (s->R < 2) return sfail(OHS_ERR_PARSE, "need two receivers (left, right ear)");
+    if (s->flags & OHS_SOFA_INTERPOLATE)
+        return ohs_sofa_internal_interpolated(s, az_deg, el_deg, radius_m, left, right, capacity, delay_left, delay_right);
     size_t m = 0;
     int rc = ohs_sofa_nearest(s, az_deg, el_deg, radius_m, &m);
     if (rc) return rc;

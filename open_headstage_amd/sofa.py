@@ -13,11 +13,19 @@ from ._ffi import check, fp, lib
 from .dsp import ConvolutionPath
 
 
+# ohs_sofa_open_ex flags (include/ohs_hip.h)
+SOFA_RESAMPLE, SOFA_LOUDNESS, SOFA_INTERPOLATE, SOFA_MYSOFA_DEFAULTS = 1, 2, 4, 7
+
+
 class MySofa:
-    def __init__(self, filepath):
+    def __init__(self, filepath, flags: int = 0, target_samplerate: float = 0.0):
         h = C.c_void_p()
-        check(lib().ohs_sofa_open(os.fsencode(filepath), C.byref(h)))
+        if flags:
+            check(lib().ohs_sofa_open_ex(os.fsencode(filepath), int(flags), float(target_samplerate), C.byref(h)))
+        else:
+            check(lib().ohs_sofa_open(os.fsencode(filepath), C.byref(h)))
         self._h = h
+        self.flags = int(flags)
         M, R, N, fs = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_float()
         check(lib().ohs_sofa_info(h, C.byref(M), C.byref(R), C.byref(N), C.byref(fs)))
         self.num_measurements, self.num_receivers = int(M.value), int(R.value)
@@ -29,6 +37,25 @@ class MySofa:
         s = cls(filepath)
         s.target_samplerate = target_samplerate
         return s
+
+    @classmethod
+    def open_like_mysofa(cls, filepath, target_samplerate: float, flags: int = SOFA_MYSOFA_DEFAULTS) -> "MySofa":
+        """What the reference's MySofa::open gets from mysofa_open (loader.rs:83-90): data resampled to the
+        target rate, loudness-normalised, get_hrtf_irs interpolating between neighbours.  Parity unpinned
+        (csrc/sofa_conditioning.cpp)."""
+        s = cls(filepath, flags, target_samplerate)
+        s.target_samplerate = None          # already at the target rate
+        return s
+
+    def loudness_factor(self) -> float:
+        v = C.c_float()
+        check(lib().ohs_sofa_loudness_factor(self._h, C.byref(v)))
+        return float(v.value)
+
+    def neighbors(self, m: int):
+        out = (C.c_int * 6)()
+        check(lib().ohs_sofa_neighbors(self._h, int(m), out))
+        return [int(v) for v in out]
 
     @staticmethod
     def spherical_to_cartesian(spherical) -> np.ndarray:      # loader.rs:203-213

@@ -103,3 +103,109 @@ def test_fixture_is_what_the_reader_returns_and_resampling_is_sane():
     H0 = np.abs(np.exp(-2j * np.pi * np.outer(f, np.arange(200)) / 44100.0) @ irs[0].astype(np.float64))
     H1 = np.abs(np.exp(-2j * np.pi * np.outer(f, np.arange(218)) / 48000.0) @ r.astype(np.float64))
     assert np.max(np.abs(20 * np.log10(H1 / H0))) < 0.1
+
+
+# ---- pin against the reference's own processed_hrir.wav (fixture: tools/make_sofa_fixture.py) ----------------------
+@need_asset
+def test_get_ir_matches_the_references_processed_hrir_wav():
+    """data/hrtf/processed_hrir.wav holds measurements 355 and 171 of subject_003.sofa (receivers 0, 1) as
+    16-bit PCM: every sample of ohs_sofa_get_ir, quantised the same way (clipping included), is within 1 LSB."""
+    from open_headstage_amd.sofa import MySofa
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "processed_hrir_wav.npz"))
+    s = MySofa(SOFA)
+    assert float(g["fs"]) == s.source_samplerate and g["pcm"].shape == (s.filter_length, 4)
+    for ch in range(4):
+        ir = s.ir(int(g["measurement"][ch]), int(g["receiver"][ch]))
+        q = np.clip(np.round(ir.astype(np.float64) * 32768.0), -32768, 32767)
+        assert np.abs(q - g["pcm"][:, ch]).max() <= 1, ch
+        # and it is THAT measurement, not a neighbour: the next-best measurement is far off
+        other = s.ir(int(g["measurement"][ch]) + 1, int(g["receiver"][ch]))
+        assert np.abs(np.clip(np.round(other * 32768.0), -32768, 32767) - g["pcm"][:, ch]).max() > 100
+
+
+# ---- libmysofa-style conditioning (ohs_sofa_open_ex; parity unpinned, checked against independent numpy) -----------
+@need_asset
+def test_loudness_normalisation_as_mysofa_loudness():
+    from open_headstage_amd import sofa
+    raw = sofa.MySofa(SOFA)
+    s = sofa.MySofa(SOFA, sofa.SOFA_LOUDNESS)
+    pos = np.stack([raw.position(m) for m in range(raw.num_measurements)])
+    key = pos[:, 0] + pos[:, 1]
+    frontal = int(np.argmin(key))                       # libmysofa: smallest azimuth + elevation (first on ties)
+    e = sum(float(np.sum(raw.ir(frontal, r).astype(np.float64) ** 2)) for r in (0, 1))
+    factor = np.sqrt(2.0 / e)
+    assert abs(s.loudness_factor() - factor) < 1e-5 * factor
+    assert abs(sum(float(np.sum(s.ir(frontal, r).astype(np.float64) ** 2)) for r in (0, 1)) - 2.0) < 1e-4
+    for m in (0, 308, 908, 1249):
+        assert np.allclose(s.ir(m, 1), raw.ir(m, 1) * np.float32(s.loudness_factor()), rtol=1e-6, atol=0)
+    assert raw.loudness_factor() == 1.0
+
+
+@need_asset
+def test_neighbours_and_interpolation_as_mysofa_getfilter():
+    from open_headstage_amd import sofa
+    s = sofa.MySofa(SOFA, sofa.SOFA_INTERPOLATE)
+    raw = sofa.MySofa(SOFA)
+    M = s.num_measurements
+    pos = np.stack([s.position(m) for m in range(M)]).astype(np.float64)
+    az, el = np.radians(pos[:, 0]), np.radians(pos[:, 1])
+    xyz = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1) * pos[:, 2:3]
+
+    def nearest(a_deg, e_deg, r=1.0):
+        q = np.array([np.cos(np.radians(e_deg)) * np.cos(np.radians(a_deg)), np.cos(np.radians(e_deg)) * np.sin(np.radians(a_deg)),
+                      np.sin(np.radians(e_deg))]) * r
+        return int(np.argmin(((xyz - q) ** 2).sum(1))), q
+
+    # neighbours: first different nearest measurement when stepping 0.5 degrees in azimuth / elevation
+    for m in (308, 908, 400, 13):
+        nb = s.neighbors(m)
+        assert nb[4] == -1 and nb[5] == -1                # one radius in the file: no radial neighbours
+        for k, (da, de) in enumerate(((0.5, 0), (-0.5, 0), (0, 0.5), (0, -0.5))):
+            want = -1
+            for step in range(1, 91):
+                j, _ = nearest(pos[m, 0] + da * step, pos[m, 1] + de * step)
+                if j != m:
+                    want = j
+                    break
+            assert nb[k] == want, (m, k, nb, want)
+    # a query ON a measurement returns it untouched; the plain handle agrees
+    l, r = s.get_hrtf_irs(30.0, 0.0)
+    assert np.array_equal(l, raw.ir(308, 0)) and np.array_equal(r, raw.ir(308, 1))
+    # a query between measurements: inverse-distance weights over the nearest and the closer neighbour per axis
+    qa, qe = 31.7, 1.2
+    m0, q = nearest(qa, qe)
+    nb = s.neighbors(m0)
+    d0 = np.linalg.norm(q - xyz[m0])
+    terms = [(m0, 1.0 / d0)]
+    for a, b in ((0, 1), (2, 3)):
+        if nb[a] >= 0 and nb[b] >= 0:
+            da_, db_ = np.linalg.norm(q - xyz[nb[a]]), np.linalg.norm(q - xyz[nb[b]])
+            if abs(da_ - db_) >= 1e-5:
+                terms.append((nb[a], 1.0 / da_) if da_ < db_ else (nb[b], 1.0 / db_))
+        elif nb[a] >= 0:
+            terms.append((nb[a], 1.0 / np.linalg.norm(q - xyz[nb[a]])))
+        elif nb[b] >= 0:
+            terms.append((nb[b], 1.0 / np.linalg.norm(q - xyz[nb[b]])))
+    wsum = sum(w for _, w in terms)
+    for rcv, got in zip((0, 1), s.get_hrtf_irs(qa, qe)):
+        want = sum(raw.ir(m, rcv).astype(np.float64) * w for m, w in terms) / wsum
+        assert len(terms) >= 2 and np.max(np.abs(got - want)) < 2e-6 * max(1.0, np.abs(want).max())
+    # a far-away query is projected onto the measured radius first
+    l5, r5 = s.get_hrtf_irs(qa, qe, 5.0)
+    l1, r1 = s.get_hrtf_irs(qa, qe, 1.0)
+    assert np.allclose(l5, l1, atol=1e-7) and np.allclose(r5, r1, atol=1e-7)
+
+
+@need_asset
+def test_open_like_mysofa_resamples_everything_to_the_target_rate():
+    from open_headstage_amd import sofa
+    raw = sofa.MySofa(SOFA)
+    s = sofa.MySofa.open_like_mysofa(SOFA, 48000.0)
+    assert s.source_samplerate == 48000.0 and s.filter_length == 218          # ceil(200 * 48000 / 44100)
+    f = np.float32(s.loudness_factor())
+    want = sofa.resample_ir(raw.ir(308, 0), 44100.0, 48000.0)
+    assert np.allclose(s.ir(308, 0), want * f, rtol=1e-6, atol=1e-9)
+    irs = sofa.speaker_hrirs(s)                                              # no second resampling
+    assert all(h.size == 218 for h in irs)
+    with pytest.raises(Exception):
+        sofa.MySofa(SOFA, 64)                                               # unknown flag

@@ -33,6 +33,17 @@ static int exercise(const char *path)
     ohs_sofa_get_hrtf_irs(s, -30.f, 10.f, 1.f, l.data(), r.data(), N, &dl, &dr);
     float p3[3]; if (M) ohs_sofa_position(s, M - 1, p3);
     ohs_sofa_close(s);
+    // the same file through the libmysofa-style conditioning (resample + loudness + neighbour interpolation)
+    ohs_sofa *c = nullptr;
+    if (ohs_sofa_open_ex(path, OHS_SOFA_MYSOFA_DEFAULTS, 48000.0f, &c) == OHS_OK) {
+        size_t M2 = 0, R2 = 0, N2 = 0; float fs2 = 0;
+        ohs_sofa_info(c, &M2, &R2, &N2, &fs2);
+        std::vector<float> l2(N2 + 1), r2(N2 + 1); float a, b;
+        ohs_sofa_get_hrtf_irs(c, 31.7f, 1.2f, 3.0f, l2.data(), r2.data(), N2, &a, &b);
+        ohs_sofa_get_hrtf_irs(c, -120.f, -40.f, 0.2f, l2.data(), r2.data(), N2, &a, &b);
+        int nb[6]; if (M2) ohs_sofa_neighbors(c, M2 / 2, nb);
+        ohs_sofa_close(c);
+    }
     return OHS_OK;
 }
 

@@ -22,3 +22,19 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "cipic003_pm30.npz"),
                     index_left=il, index_right=ir, pos_left=s.position(il), pos_right=s.position(ir),
                     fs=s.source_samplerate, irs_44100=np.stack(irs441), irs_48000=np.stack(irs48))
 print("indices", il, ir, "taps", irs441[0].size, irs48[0].size)
+
+# The reference's second data asset, data/hrtf/processed_hrir.wav (a data file: 16-bit PCM, 4 channels, 200 frames,
+# 44.1 kHz): its channels are measurements 355 and 171 of the same SOFA file, receivers 0 and 1, quantised to int16
+# (channels 0 / 2 clip).  Kept as a fixture: it pins ohs_sofa_get_ir against data the reference itself holds.
+import struct  # noqa: E402
+
+raw = open("/root/reference/data/hrtf/processed_hrir.wav", "rb").read()
+assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE"
+fmt_tag, channels, rate, _, _, bits = struct.unpack("<HHIIHH", raw[20:36])
+assert (fmt_tag, channels, bits) == (1, 4, 16)
+i = raw.index(b"data")
+nbytes = struct.unpack("<I", raw[i + 4:i + 8])[0]
+pcm = np.frombuffer(raw[i + 8:i + 8 + nbytes], dtype="<i2").reshape(-1, channels).copy()
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "processed_hrir_wav.npz"), pcm=pcm, fs=np.float32(rate),
+                    measurement=np.array([355, 355, 171, 171]), receiver=np.array([0, 1, 0, 1]))
+print("processed_hrir.wav:", pcm.shape, rate)
