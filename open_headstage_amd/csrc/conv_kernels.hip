@@ -808,16 +808,21 @@ hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float
     return hipGetLastError();
 }
 
-// F: one wave per (stream, block)
-__global__ __launch_bounds__(256) void k_conv_tp_forward(const ConvTpArgs A)
+// F: one wave per (stream, block).  kTpWaves waves per workgroup (one workgroup per CU): the 9 KiB of twiddle
+// tables are fetched once per 16 waves instead of once per 4, and a CU holds 16 waves instead of 12.
+#ifndef OHS_TP_WAVES
+#define OHS_TP_WAVES 16
+#endif
+constexpr int kTpWaves = OHS_TP_WAVES;      // LDS: 9 KiB + 16 x 8.5 KiB = 145 KiB
+__global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_forward(const ConvTpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
-    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kTpWaves);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const long long gw = (long long)blockIdx.x * kTpWaves + wave;
     if (gw >= (long long)A.n_streams * A.seg_blocks) return;
     const size_t s = (size_t)(gw / A.seg_blocks);
     const int t = (int)(gw % A.seg_blocks);
@@ -837,22 +842,25 @@ __global__ __launch_bounds__(256) void k_conv_tp_forward(const ConvTpArgs A)
 }
 hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st)
 {
-    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
+    const size_t shmem = (kTabComplex + kTpWaves * kWaveLdsComplex) * sizeof(float2);
+    static std::atomic<unsigned long long> lds_ok{0};
+    const hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_tp_forward), shmem, lds_ok);
+    if (e != hipSuccess) return e;
     const long long waves = (long long)a.n_streams * a.seg_blocks;
-    hipLaunchKernelGGL(k_conv_tp_forward, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
+    hipLaunchKernelGGL(k_conv_tp_forward, dim3((unsigned)((waves + kTpWaves - 1) / kTpWaves)), dim3(64 * kTpWaves), shmem, st, a);
     return hipGetLastError();
 }
 
 // I: one wave per (stream, block < n_mac)
-__global__ __launch_bounds__(256) void k_conv_tp_inverse(const ConvTpArgs A)
+__global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_inverse(const ConvTpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
-    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
+    fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kTpWaves);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const long long gw = (long long)blockIdx.x * kTpWaves + wave;
     if (gw >= (long long)A.n_streams * A.n_mac) return;
     const size_t s = (size_t)(gw / A.n_mac);
     const int t = (int)(gw % A.n_mac);
@@ -927,9 +935,12 @@ hipError_t launch_conv_tp_tails(const ConvTpArgs &a, hipStream_t st)
 hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st)
 {
     if (a.n_mac <= 0) return hipSuccess;
-    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
+    const size_t shmem = (kTabComplex + kTpWaves * kWaveLdsComplex) * sizeof(float2);
+    static std::atomic<unsigned long long> lds_ok{0};
+    const hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_tp_inverse), shmem, lds_ok);
+    if (e != hipSuccess) return e;
     const long long waves = (long long)a.n_streams * a.n_mac;
-    hipLaunchKernelGGL(k_conv_tp_inverse, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
+    hipLaunchKernelGGL(k_conv_tp_inverse, dim3((unsigned)((waves + kTpWaves - 1) / kTpWaves)), dim3(64 * kTpWaves), shmem, st, a);
     return hipGetLastError();
 }
 
