@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void k_ir_spectrum(const float *__restrict__ ir
         const int idx = part * kBlock + 64 * a + lane;
         v[a] = make_float2((a < 8 && idx < len) ? ir[idx] : 0.0f, 0.0f);
     }
-    wave_fft_fwd(v, lds, tab, lane);
+    wave_fft_fwd_zpad(v, lds, tab, lane);
     float2 *o = dst + (size_t)part * kFft;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r * 64 + lane] = v[r];
@@ -136,7 +136,7 @@ __device__ __forceinline__ void block_forward(const IO &io, int t, float2 (&v)[1
     for (int a = 0; a < 8; ++a) v[a] = io.load((size_t)t * kBlock + 64 * a + lane);
 #pragma unroll
     for (int a = 8; a < 16; ++a) v[a] = make_float2(0.0f, 0.0f);   // zero pad (:248-254)
-    wave_fft_fwd(v, lds, tab, lane);
+    wave_fft_fwd_zpad(v, lds, tab, lane);
 }
 
 // (2) history[history_index] = spectrum (:258); one packed ring per stream
@@ -540,7 +540,11 @@ __device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float2 zz = z[r], m = w[r];
+#ifdef OHS_KO_CD
+        const float2 c = make_float2(0.5f, 0.001f * (float)lane), d = make_float2(0.25f, 0.002f * (float)lane);
+#else
         const float2 c = lds_ld(&cd[r * 64 + lane]), d = lds_ld(&cd[kFft + r * 64 + lane]);
+#endif
         w[r].x = zz.x * c.x - zz.y * c.y + m.x * d.x + m.y * d.y;
         w[r].y = zz.x * c.y + zz.y * c.x + m.x * d.y - m.y * d.x;
     }
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
         }
         float2 w[16];
 #ifdef OHS_P1_BPERMUTE_MIRROR
-        wave_fft_fwd(v, lds, tab, lane);
+        wave_fft_fwd_zpad(v, lds, tab, lane);
         wave_mirror(v, w, lane);
 #else
         wave_fft_fwd_mirror(v, w, lds, tab, lane);
@@ -637,8 +641,14 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #endif
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
+#ifdef OHS_KO_STORE
+            if (w[a].x == 123.456f) {       // never true: the stores stay in the code, none is executed
+#endif
             ql[64 * a] = (w[a].x * scale + tail[a].x) * A.gain;
             qr[64 * a] = (w[a].y * scale + tail[a].y) * A.gain;
+#ifdef OHS_KO_STORE
+            }
+#endif
             tail[a] = make_float2(w[a + 8].x * scale, w[a + 8].y * scale);
         }
         ql += kBlock; qr += kBlock;
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_forward(const ConvTpA
         v[a] = make_float2(in_l[idx], in_r[idx]);
         v[a + 8] = make_float2(0.f, 0.f);
     }
-    wave_fft_fwd(v, lds, tab, lane);
+    wave_fft_fwd_zpad(v, lds, tab, lane);
     float2 *hs = A.hist + (s * (size_t)A.cap + (size_t)((A.cnt + (unsigned long long)t) & (unsigned long long)(A.cap - 1))) * kFft;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hs[r * 64 + lane] = v[r];

@@ -73,6 +73,12 @@ __device__ __forceinline__ void wave_lds_sync()
 // ds_read_b64 (MI355X: 2 x 32-lane groups per b64 read, 4 x 16 per half of a read2; measured by
 // tools/ubench_lds.py).  A volatile access is left alone by that pass; program order among them is what the
 // exchanges want anyway.
+// timing experiments only (wrong results): OHS_KO_TW replaces every twiddle-table read by a register value
+#ifdef OHS_KO_TW
+#define OHS_TW_LD(p) make_float2(0.99f, 0.01f * (float)lane)
+#else
+#define OHS_TW_LD(p) lds_ld(p)
+#endif
 #ifndef OHS_LDS_MERGE
 // (accessed as one 64-bit integer, not as a <2 x float> vector: with a vector type in play hipcc packs the
 // following complex arithmetic into v_pk_* instructions and pays for it in register moves)
@@ -125,13 +131,27 @@ __device__ __forceinline__ float2 mul_w16(float2 a)
     else /* E == 9 */ return ctw<INV>(a, make_float2(-C1, S1));
 }
 
-// 16-point DFT on registers, natural order in, natural order out.
-template <bool INV>
+// forward 4-point DFT whose inputs 2 and 3 are zero (the zero-padded upper half of a block, convolution.rs:248-254):
+// 8 real additions instead of 16.  hipcc cannot do this by itself: x + 0.0 is not x under IEEE rules (-0.0).
+__device__ __forceinline__ void dft4_fwd_upper_zero(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 a0 = a, b0 = b;
+    a = cadd(a0, b0);
+    b = make_float2(a0.x + b0.y, a0.y - b0.x);      // a - j b
+    c = csub(a0, b0);
+    d = make_float2(a0.x - b0.y, a0.y + b0.x);      // a + j b
+}
+
+// 16-point DFT on registers, natural order in, natural order out.  ZPAD: inputs 8..15 are zero.
+template <bool INV, bool ZPAD = false>
 __device__ __forceinline__ void dft16(float2 (&v)[16])
 {
     // n = 4 n1 + n2 ; k = k1 + 4 k2
 #pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    for (int n2 = 0; n2 < 4; ++n2) {
+        if constexpr (ZPAD && !INV) dft4_fwd_upper_zero(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+        else dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    }
     // now v[4 k1 + n2] = t[n2][k1]; twiddle by w16^(n2 k1)
     v[5] = mul_w16<INV, 1>(v[5]);
     v[6] = mul_w16<INV, 2>(v[6]);
@@ -190,13 +210,14 @@ __host__ __device__ __forceinline__ constexpr int t2_index(int rr, int sigma) { 
 // those of lane 63 - L (k = 4L + j + 256 r, j != 0  ->  N - k = 4(63 - L) + (4 - j) + 256 (3 - r)) and, for
 // j == 0, of lane 64 - L -- and runs four more DFT4s: 16 ds_read_b64 + 64 adds instead of the 32
 // ds_bpermute_b32 of wave_mirror (5.7 LDS cycles each, tools/ubench_lds.py).
-template <bool MIRROR>
+// ZPAD: the caller guarantees v[8..15] == 0 on entry (a 512-frame block padded to 1024).
+template <bool MIRROR, bool ZPAD>
 __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[16], float2 *lds, const float2 *tab,
                                                   int lane)
 {
-    dft16<false>(v);                                        // over a -> p
+    dft16<false, ZPAD>(v);                                  // over a -> p
 #pragma unroll
-    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], lds_ld(&tab[kTabA + t1_index(p, lane)]));
+    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], OHS_TW_LD(&tab[kTabA + t1_index(p, lane)]));
 #pragma unroll
     for (int p = 0; p < 16; ++p) lds_st(&lds[t1_index(p, lane)], v[p]);  // T1
     wave_lds_sync();
@@ -207,7 +228,7 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
     wave_lds_sync();
     dft16<false>(v);                                        // over b -> q
 #pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], lds_ld(&tab[kTabB + 4 * q + (lane & 3)]));
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], OHS_TW_LD(&tab[kTabB + 4 * q + (lane & 3)]));
     const int p_lo = pp & 3, p_hi = pp >> 2;
     const int rrw = 4 * p_lo + c;
 #pragma unroll
@@ -253,12 +274,19 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
 __device__ __forceinline__ void wave_fft_fwd(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
 {
     float2 unused[16];
-    wave_fft_fwd_impl<false>(v, unused, lds, tab, lane);
+    wave_fft_fwd_impl<false, false>(v, unused, lds, tab, lane);
 }
+// the same for a zero-padded block: v[8..15] must be zero
+__device__ __forceinline__ void wave_fft_fwd_zpad(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
+{
+    float2 unused[16];
+    wave_fft_fwd_impl<false, true>(v, unused, lds, tab, lane);
+}
+// zero-padded block in, spectrum and mirror spectrum out (the P = 1 kernels)
 __device__ __forceinline__ void wave_fft_fwd_mirror(float2 (&v)[16], float2 (&zm)[16], float2 *lds, const float2 *tab,
                                                     int lane)
 {
-    wave_fft_fwd_impl<true>(v, zm, lds, tab, lane);
+    wave_fft_fwd_impl<true, true>(v, zm, lds, tab, lane);
 }
 
 // bin layout -> time layout (unnormalised inverse DFT)
@@ -275,7 +303,7 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
-        const float2 w = lds_ld(&tab[kTabB + 4 * (lane >> 2) + c]);
+        const float2 w = OHS_TW_LD(&tab[kTabB + 4 * (lane >> 2) + c]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
     }
@@ -292,7 +320,7 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     dft16<true>(v);                                         // over q -> b
     const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
 #pragma unroll
-    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], lds_ld(&tab[kTabA + t1r + 4 * b]));   // w1024^((4b+c) p), conj
+    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], OHS_TW_LD(&tab[kTabA + t1r + 4 * b]));   // w1024^((4b+c) p), conj
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds_st(&lds[t1r + 4 * b], v[b]);    // T1'
     wave_lds_sync();
