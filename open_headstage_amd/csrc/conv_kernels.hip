@@ -492,8 +492,8 @@ hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e,
 //   w  = IFFT(W):  re = out_l, im = out_r        one inverse transform for both ears
 //
 // Blocks of one stream only couple through the 512-sample overlap tail, so a stream is cut
-// into `chunks` contiguous block ranges that run as independent waves; the tail leaving each
-// chunk goes to a scratch slab and k_conv_p1_fixup adds it to the next chunk's first block.
+// into `chunks` contiguous block ranges that run as independent waves; the tail ENTERING each
+// chunk is computed beforehand by the pre-pass (k_conv_p1_edges, below).
 // The spectrum history ring is not written: with one partition it is never read
 // (convolution.rs:261-273 with P = 1 touches history[idx] only in the block that wrote it).
 // The last block of the launch keeps the reference's four separate overlap buffers (two

@@ -82,7 +82,7 @@ int get_ctx(int device, DeviceCtx **out)
         const double ang = -2.0 * 3.14159265358979323846264338327950288 * (double)k / (double)NF;
         tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
     }
-    // every kernel receives the EXPANDED, lane-ordered tables (17 KiB) and copies them to LDS
+    // every kernel receives the EXPANDED, lane-ordered tables (9 KiB) and copies them to LDS
     std::vector<float2> expanded(kTabComplex);
     expand_twiddle_tables(tw.data(), expanded.data());
     if (hipMalloc(&c->d_tw, kTabComplex * sizeof(float2)) != hipSuccess) {
@@ -258,7 +258,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
                 bool allow_fast = true)
 {
-    if (n_blocks <= 0) return OHS_OK;       // nothing to do (k_conv_p1_last would index block -1)
+    if (n_blocks <= 0) return OHS_OK;       // nothing to do (the pre-pass would index block -1)
     const bool p1 = c.P[0] == 1 && c.P[1] == 1 && c.P[2] == 1 && c.P[3] == 1;
     if (p1 && allow_fast) {
         // every path has one partition: time-parallel single-FFT-pair kernel

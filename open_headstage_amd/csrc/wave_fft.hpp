@@ -174,7 +174,7 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
     t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
-// The 17 KiB of per-workgroup twiddle tables are expanded ONCE per device on the host
+// The 9 KiB of per-workgroup twiddle tables are expanded ONCE per device on the host
 // (expand_twiddle_tables, from exp(-2 pi i e / 1024) computed in f64 and rounded to f32, as rustfft
 // does); a kernel only copies them into LDS with 16-byte loads.
 __device__ __forceinline__ void fill_twiddle_tables(float2 *tab, const float2 *__restrict__ gtab,
