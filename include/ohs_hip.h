@@ -103,6 +103,12 @@ int  ohs_engine_set_realtime(ohs_engine *e, int enable);
  * 0 when n is a multiple of 512; otherwise the frames answered with silence before the output FIFO can
  * serve every call (e.g. 256 for n = 256).  What a plugin host reports as its latency for compensation. */
 int  ohs_engine_latency_samples(const ohs_engine *e, size_t n, size_t *latency);
+/* Diagnostics of the resident kernel: 100 MHz device timestamps of the last call it served -- doorbell seen,
+ * inputs visible (after the acquire), body done, every wave's stores drained, released; out[5] = shader-clock
+ * cycles between the first and the last (their ratio is the clock the wave really ran at); out[8..14] = the
+ * same clock inside the call: entry, FIFO pop done, inputs transformed, barrier, MAC done, inverse FFTs done,
+ * outputs stored (wave 0 only). */
+int  ohs_engine_debug_rt_stamps(const ohs_engine *e, uint64_t out[16]);
 /* Frames this engine has answered with that silence so far = its current delay in frames. */
 int  ohs_engine_silent_frames(const ohs_engine *e, uint64_t *frames);
 

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "ohs_engine_set_realtime": (C.c_int, [vp, C.c_int]),
     "ohs_engine_latency_samples": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ohs_engine_silent_frames": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "ohs_engine_debug_rt_stamps": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "ohs_biquad_coeffs": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp]),
     "ohs_eq_create": (C.c_int, [C.c_int, C.c_size_t, C.c_float, vpp]),
     "ohs_eq_destroy": (None, [vp]),

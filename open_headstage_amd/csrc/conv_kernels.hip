@@ -107,19 +107,28 @@ struct EngineIOT {
         if constexpr (SYSTEM) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         else *p = v;
     }
+    // Branch-free: the source / destination is chosen by a POINTER select and the access itself is
+    // unconditional, so the 16 loads of a block are issued back to back.  (With the `if` around each access
+    // hipcc waited for every load before the next branch: eight dependent PCIe round trips, 14 of the 17 us of
+    // a 1024-frame call.)
     __device__ __forceinline__ float2 load(size_t idx) const
     {
-        if (idx < (size_t)E.in_len) return make_float2(E.in_fifo[idx], E.in_fifo[E.in_cap + idx]);
-        const size_t k = idx - E.in_len;
-        return make_float2(ld(E.src_l + k), ld(E.src_r + k));
+        const bool old = idx < (size_t)E.in_len;
+        const size_t k = idx - (size_t)E.in_len;
+        const float *pl = old ? E.in_fifo + idx : E.src_l + k;
+        const float *pr = old ? E.in_fifo + E.in_cap + idx : E.src_r + k;
+        return make_float2(ld(pl), ld(pr));
     }
     __device__ __forceinline__ void store(size_t idx, float l, float r) const
     {
         const size_t j = (size_t)E.out_len + idx;
-        if (E.emit) {
-            if (j < (size_t)E.n) { st(E.host_l + j, l * E.gain_pop); st(E.host_r + j, r * E.gain_pop); }
-            else { E.out_fifo[j - E.n] = l; E.out_fifo[E.out_cap + j - E.n] = r; }
-        } else { E.out_fifo[j] = l; E.out_fifo[E.out_cap + j] = r; }
+        const bool pop = E.emit && j < (size_t)E.n;                    // popped by this call: to the host, with gain
+        const size_t f = E.emit ? j - (size_t)E.n : j;                 // else: its post-pop position in the FIFO
+        float *pl = pop ? E.host_l + j : E.out_fifo + f;
+        float *pr = pop ? E.host_r + j : E.out_fifo + E.out_cap + f;
+        const float g = pop ? E.gain_pop : 1.0f;
+        st(pl, l * g);
+        st(pr, r * g);
     }
 };
 using EngineIO = EngineIOT<false>;
@@ -173,19 +182,27 @@ __device__ __forceinline__ void block_mac(const ConvGeneralArgs &A, const float2
             for (int r = 0; r < 16; ++r) zi[r] = hs[r * 64 + lane];
         }
         wave_mirror(zi, zm, lane);
-        const float2 *h0 = A.H[0] + (size_t)i * kFft;
-        const float2 *h1 = A.H[1] + (size_t)i * kFft;
-        const float2 *h2 = A.H[2] + (size_t)i * kFft;
-        const float2 *h3 = A.H[3] + (size_t)i * kFft;
+        // Branch-free over the four paths: every spectrum is loaded (partition index clamped into the path's own
+        // range) and a gated-off path's value is multiplied by 0, an active one by 1 (exact).  With an `if` around
+        // each product hipcc kept every load inside its branch and waited for it there -- 64 dependent L2 round
+        // trips, 8.8 of the 16.4 us a 1024-frame call spent in the kernel; a separate straight-line path for the
+        // all-active case made it demote the register arrays to scratch memory.
+        const float f0 = g0 ? 1.0f : 0.0f, f1 = g1 ? 1.0f : 0.0f, f2 = g2 ? 1.0f : 0.0f, f3 = g3 ? 1.0f : 0.0f;
+        const float2 *h0 = A.H[0] + (size_t)(i < A.P[0] ? i : A.P[0] - 1) * kFft;
+        const float2 *h1 = A.H[1] + (size_t)(i < A.P[1] ? i : A.P[1] - 1) * kFft;
+        const float2 *h2 = A.H[2] + (size_t)(i < A.P[2] ? i : A.P[2] - 1) * kFft;
+        const float2 *h3 = A.H[3] + (size_t)(i < A.P[3] ? i : A.P[3] - 1) * kFft;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            float2 c0 = h0[r * 64 + lane], c1 = h1[r * 64 + lane], c2 = h2[r * 64 + lane], c3 = h3[r * 64 + lane];
+            c0.x *= f0; c0.y *= f0; c1.x *= f1; c1.y *= f1; c2.x *= f2; c2.y *= f2; c3.x *= f3; c3.y *= f3;
             // X_l = (Z + conj(Zm))/2 ; X_r = -j (Z - conj(Zm))/2
             const float2 xl = make_float2(0.5f * (zi[r].x + zm[r].x), 0.5f * (zi[r].y - zm[r].y));
             const float2 xr = make_float2(0.5f * (zi[r].y + zm[r].y), -0.5f * (zi[r].x - zm[r].x));
-            if (g0) { const float2 y = cmul(xl, h0[r * 64 + lane]); acc1[r].x += y.x; acc1[r].y += y.y; }
-            if (g1) { const float2 y = cmul(xl, h1[r * 64 + lane]); acc1[r].x -= y.y; acc1[r].y += y.x; }
-            if (g2) { const float2 y = cmul(xr, h2[r * 64 + lane]); acc2[r].x += y.x; acc2[r].y += y.y; }
-            if (g3) { const float2 y = cmul(xr, h3[r * 64 + lane]); acc2[r].x -= y.y; acc2[r].y += y.x; }
+            cmac(acc1[r], xl, c0);
+            cmac_j(acc1[r], xl, c1);
+            cmac(acc2[r], xr, c2);
+            cmac_j(acc2[r], xr, c3);
         }
     }
 }
@@ -222,10 +239,10 @@ __device__ __forceinline__ void conv_general_body(const ConvGeneralArgs &A, cons
         // overlap-add per path, then ear sums (:279-284, :228-231), then gain (lib.rs:1202-1207)
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            const float lsl = acc1[a].x * scale + tail1[a].x;
-            const float lsr = acc1[a].y * scale + tail1[a].y;
-            const float rsl = acc2[a].x * scale + tail2[a].x;
-            const float rsr = acc2[a].y * scale + tail2[a].y;
+            const float lsl = fmaf(acc1[a].x, scale, tail1[a].x);
+            const float lsr = fmaf(acc1[a].y, scale, tail1[a].y);
+            const float rsl = fmaf(acc2[a].x, scale, tail2[a].x);
+            const float rsr = fmaf(acc2[a].y, scale, tail2[a].y);
             tail1[a] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
             tail2[a] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
             const size_t idx = (size_t)t * kBlock + 64 * a + lane;
@@ -258,10 +275,13 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
 // the call's latency is one block's (forward FFT, MAC, two inverse FFTs), not k of them.
 // Every thread of the workgroup must call it (it contains workgroup barriers); `tab` holds the twiddle
 // tables, `slabs` n_waves per-wave FFT slabs.
+#define OHS_DBG_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 template <bool SYSTEM>
 __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const EngineCallArgs &E, float2 *tab,
-                                                 float2 *slabs, int wave, int lane, int n_waves)
+                                                 float2 *slabs, int wave, int lane, int n_waves,
+                                                 unsigned long long *dbg = nullptr)
 {
+    OHS_DBG_STAMP(8);
     using IO = EngineIOT<SYSTEM>;
     float2 *lds = slabs + wave * kWaveLdsComplex;
     // 1. frames already waiting in the output FIFO: pop what this call takes, slide the rest down
@@ -290,8 +310,10 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
 #pragma unroll
     for (int p = 1; p < 4; ++p) maxP = A.P[p] > maxP ? A.P[p] : maxP;
     float2 v[16], acc1[16], acc2[16];
+    OHS_DBG_STAMP(9);
     if (active) {
         block_forward(io, t, v, lds, tab, lane);
+        OHS_DBG_STAMP(10);
         // with one partition everywhere nothing ever reads the ring: a path only sees blocks processed since its
         // own last set_ir (the `since` gate), and growing a path's partition count IS a set_ir
         if (maxP > 1) block_store_history(A, hist, t, v, lane);
@@ -299,10 +321,13 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     __threadfence_block();      // the ring slots written above are read by the other waves' partitions
     __syncthreads();            // (also: every input frame has been read before step 3 rewrites the FIFO)
     const float scale = 1.0f / (float)kFft;   // convolution.rs:280
+    OHS_DBG_STAMP(11);
     if (active) {
         block_mac(A, hist, t, maxP, v, acc1, acc2, lane);
+        OHS_DBG_STAMP(12);
         wave_fft_inv(acc1, lds, tab, lane);   // re = lsl, im = lsr   (:276)
         wave_fft_inv(acc2, lds, tab, lane);   // re = rsl, im = rsr
+        OHS_DBG_STAMP(13);
         // this block's overlaps (upper halves) into its own slab, for the next block's wave
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -317,11 +342,12 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const float2 t1 = prev[a * 64 + lane], t2 = prev[(8 + a) * 64 + lane];
-            const float lsl = acc1[a].x * scale + t1.x, lsr = acc1[a].y * scale + t1.y;
-            const float rsl = acc2[a].x * scale + t2.x, rsr = acc2[a].y * scale + t2.y;
+            const float lsl = fmaf(acc1[a].x, scale, t1.x), lsr = fmaf(acc1[a].y, scale, t1.y);
+            const float rsl = fmaf(acc2[a].x, scale, t2.x), rsr = fmaf(acc2[a].y, scale, t2.y);
             io.store((size_t)t * kBlock + 64 * a + lane, lsl + rsl, lsr + rsr);
         }
     }
+    OHS_DBG_STAMP(14);
     __syncthreads();            // tails_out may alias tails: block 0 has read the old state by now
     if (active && t == A.n_blocks - 1) {
 #pragma unroll
@@ -416,9 +442,13 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         }
         __syncthreads();
         if (s_cmd == 0) break;              // uniform: s_cmd is read by every thread after the barrier
+        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, ck0 = 0;
+        if (threadIdx.x == 0) { st0 = __builtin_amdgcn_s_memrealtime(); ck0 = __builtin_amdgcn_s_memtime(); }
         // the host's writes (input frames) precede its doorbell store; make them visible to this CU
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         if (threadIdx.x == 0) {             // this call's FIFO arithmetic (convolution.rs:149-163)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st1 = __builtin_amdgcn_s_memrealtime();
             const int n = s_n;
             const int k = (E.in_len + n) / kBlock;
             A.n_blocks = k;
@@ -427,7 +457,8 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             E.gain_pop = s_gain;
         }
         __syncthreads();
-        engine_call_body<false>(A, E, tab, slabs, wave, lane, 8);
+        engine_call_body<false>(A, E, tab, slabs, wave, lane, 8, mb->stamps);
+        if (threadIdx.x == 0) st2 = __builtin_amdgcn_s_memrealtime();
         // publish: every wave's stores (outputs to host memory, state to device memory) drained, then one
         // system-scope release in front of the flag.  (Tried: system-scope `sc0 sc1` loads / stores for the
         // host-visible frames in place of both fences -- engine_call_body<true> -- no faster per call, and not
@@ -435,8 +466,15 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
+            st3 = __builtin_amdgcn_s_memrealtime();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
+            // diagnostics (read by ohs_engine_debug_rt_stamps after the call): doorbell seen, inputs visible,
+            // body done, stores drained, released -- written BEFORE the flag, so they are in place when it is seen
+            mb->stamps[0] = st0; mb->stamps[1] = st1; mb->stamps[2] = st2; mb->stamps[3] = st3; mb->stamps[4] = st4;
+            mb->stamps[5] = __builtin_amdgcn_s_memtime() - ck0;         // shader-clock cycles over the same span
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             __hip_atomic_store(&mb->done, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             // advance the counters for the next call
             const int k = A.n_blocks;
@@ -545,8 +583,8 @@ __device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float
 #else
         const float2 c = lds_ld(&cd[r * 64 + lane]), d = lds_ld(&cd[kFft + r * 64 + lane]);
 #endif
-        w[r].x = zz.x * c.x - zz.y * c.y + m.x * d.x + m.y * d.y;
-        w[r].y = zz.x * c.y + zz.y * c.x + m.x * d.y - m.y * d.x;
+        w[r].x = fmaf(m.y, d.y, fmaf(m.x, d.x, fmaf(-zz.y, c.y, zz.x * c.x)));
+        w[r].y = fmaf(-m.y, d.x, fmaf(m.x, d.y, fmaf(zz.y, c.x, zz.x * c.y)));
     }
 }
 
@@ -644,8 +682,8 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #ifdef OHS_KO_STORE
             if (w[a].x == 123.456f) {       // never true: the stores stay in the code, none is executed
 #endif
-            ql[64 * a] = (w[a].x * scale + tail[a].x) * A.gain;
-            qr[64 * a] = (w[a].y * scale + tail[a].y) * A.gain;
+            ql[64 * a] = fmaf(w[a].x, scale, tail[a].x) * A.gain;
+            qr[64 * a] = fmaf(w[a].y, scale, tail[a].y) * A.gain;
 #ifdef OHS_KO_STORE
             }
 #endif
@@ -735,19 +773,19 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Arg
     for (int r = 0; r < 16; ++r) {
         const float2 xl = make_float2(0.5f * (v[r].x + zm[r].x), 0.5f * (v[r].y - zm[r].y));
         const float2 xr = make_float2(0.5f * (v[r].y + zm[r].y), -0.5f * (v[r].x - zm[r].x));
-        const float2 y0 = cmul(xl, A.H[0][r * 64 + lane]);
-        const float2 y1 = cmul(xl, A.H[1][r * 64 + lane]);
-        const float2 y2 = cmul(xr, A.H[2][r * 64 + lane]);
-        const float2 y3 = cmul(xr, A.H[3][r * 64 + lane]);
-        acc1[r] = make_float2(y0.x - y1.y, y0.y + y1.x);
-        acc2[r] = make_float2(y2.x - y3.y, y2.y + y3.x);
+        acc1[r] = make_float2(0.0f, 0.0f);
+        acc2[r] = make_float2(0.0f, 0.0f);
+        cmac(acc1[r], xl, A.H[0][r * 64 + lane]);
+        cmac_j(acc1[r], xl, A.H[1][r * 64 + lane]);
+        cmac(acc2[r], xr, A.H[2][r * 64 + lane]);
+        cmac_j(acc2[r], xr, A.H[3][r * 64 + lane]);
     }
     wave_fft_inv(acc1, lds, tab, lane);
     wave_fft_inv(acc2, lds, tab, lane);
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-        out_l[base + 64 * a] = ((acc1[a].x * scale + tin[a].x) + acc2[a].x * scale) * A.gain;
-        out_r[base + 64 * a] = ((acc1[a].y * scale + tin[a].y) + acc2[a].y * scale) * A.gain;
+        out_l[base + 64 * a] = fmaf(acc2[a].x, scale, fmaf(acc1[a].x, scale, tin[a].x)) * A.gain;
+        out_r[base + 64 * a] = fmaf(acc2[a].y, scale, fmaf(acc1[a].y, scale, tin[a].y)) * A.gain;
         tails_out[a * 64 + lane] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
         tails_out[(8 + a) * 64 + lane] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
     }

@@ -52,6 +52,7 @@ struct RtMailbox {
     alignas(64) unsigned call_word[4];
     alignas(64) unsigned done;   // device -> host: sequence number of the last call completed
     unsigned alive;              // device -> host: 0 once the kernel has decided to exit
+    alignas(64) unsigned long long stamps[16];   // diagnostics: s_memrealtime (100 MHz) at the phases of the last call
     alignas(64) ConvGeneralArgs conv;
     EngineCallArgs call;
 };

@@ -1059,6 +1059,14 @@ int ohs_engine_set_realtime(ohs_engine *e, int enable)
     return rt_start(e);
 }
 
+// diagnostics: device timestamps (100 MHz) of the last call served by the resident kernel
+int ohs_engine_debug_rt_stamps(const ohs_engine *e, uint64_t out[16])
+{
+    if (!e || !out || !e->mb) return fail(OHS_ERR_INVALID_ARG, "no resident kernel has run");
+    for (int i = 0; i < 16; ++i) out[i] = e->mb->stamps[i];
+    return OHS_OK;
+}
+
 int ohs_engine_silent_frames(const ohs_engine *e, uint64_t *frames)
 {
     if (!e || !frames) return fail(OHS_ERR_INVALID_ARG, "NULL argument");

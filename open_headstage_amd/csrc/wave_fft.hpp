@@ -47,14 +47,30 @@ __host__ __device__ __forceinline__ constexpr int t1_index(int p, int m) { retur
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// Fused multiply-adds are written out (fmaf) and the files that include this header are built with
+// -ffp-contract=off: which products get fused is then the same in every kernel that inlines these helpers,
+// whatever the register pressure around them -- the single-stream paths (k_engine_call, k_engine_resident,
+// k_conv_general) must agree bit for bit, and with implicit contraction they did so only by luck.
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 // a * conj(b)
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b)
 {
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+// acc += a * b
+__device__ __forceinline__ void cmac(float2 &acc, float2 a, float2 b)
+{
+    acc.x = fmaf(-a.y, b.y, fmaf(a.x, b.x, acc.x));
+    acc.y = fmaf(a.y, b.x, fmaf(a.x, b.y, acc.y));
+}
+// acc += j * (a * b)
+__device__ __forceinline__ void cmac_j(float2 &acc, float2 a, float2 b)
+{
+    acc.x = fmaf(-a.y, b.x, fmaf(-a.x, b.y, acc.x));
+    acc.y = fmaf(-a.y, b.y, fmaf(a.x, b.x, acc.y));
 }
 template <bool CONJ>
 __device__ __forceinline__ float2 ctw(float2 a, float2 w) { return CONJ ? cmulc(a, w) : cmul(a, w); }

@@ -7,6 +7,7 @@
 #define _POSIX_C_SOURCE 199309L
 #include "ohs_hip.h"
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,6 +32,17 @@ static void run(ohs_engine *e, size_t n, int calls, const char *what)
         const double t0 = now_us();
         if (ohs_engine_process_block(e, il, ir, ol, orr, n)) { printf("error: %s\n", ohs_last_error()); exit(1); }
         t[c] = now_us() - t0;
+    }
+    {   /* device-side phases of the last call, if the resident kernel served it (10 ns ticks) */
+        uint64_t st[16];
+        if (ohs_engine_debug_rt_stamps(e, st) == 0 && st[4] > st[0] && st[4] - st[0] < 100000)
+            printf("  device phases of the last call [us]: acquire %.2f, body %.2f, drain+barrier %.2f, release %.2f, total %.2f; shader clock %.0f MHz\n",
+                   (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[4] - st[0]) * 0.01,
+                   (double)st[5] / ((st[4] - st[0]) * 0.01));
+        if (ohs_engine_debug_rt_stamps(e, st) == 0 && st[14] > st[8] && st[14] - st[8] < 100000)
+            printf("  inside the body [us]: pop %.2f, load+fwd FFT %.2f, barrier %.2f, MAC %.2f, 2 inverse FFTs %.2f, tails+barrier+store %.2f\n",
+                   (st[9] - st[8]) * 0.01, (st[10] - st[9]) * 0.01, (st[11] - st[10]) * 0.01, (st[12] - st[11]) * 0.01,
+                   (st[13] - st[12]) * 0.01, (st[14] - st[13]) * 0.01);
     }
     qsort(t, (size_t)calls, sizeof(double), cmp);
     printf("{\"config\": \"%s\", \"frames\": %zu, \"us_median\": %.1f, \"us_p99\": %.1f, \"us_max\": %.1f, \"us_min\": %.1f}\n", what, n,
