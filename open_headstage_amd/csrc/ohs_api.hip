@@ -254,6 +254,32 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     return OHS_OK;
 }
 
+// Chunks per stream of the P = 1 kernel: at least two rounds of resident waves (CUs x 15), and a wave count
+// S * K that FILLS its last round -- all waves of a launch take the same time, so 2.13 rounds cost 3 (1024 and
+// 2048 streams with K = ceil(2 R / S) ran at 71 % for that reason).  K is the smallest value from ceil(2 R / S)
+// upwards whose last round is >= 97 % full (S * K = 8 R at 2048 streams).
+long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override)
+{
+    const long long R = (long long)ctx->num_cus * conv_p1_waves_per_cu();
+    long long K;
+    if (target_override > 0) {
+        K = (target_override + (long long)S - 1) / (long long)S;
+    } else {
+        const long long k0 = std::max<long long>(1, (2 * R + (long long)S - 1) / (long long)S);
+        K = k0;
+        double best = 0.0;
+        for (long long k = k0; k < k0 + 32; ++k) {
+            const double rounds = (double)((long long)S * k) / (double)R;
+            const double eff = rounds / std::ceil(rounds - 1e-9);
+            if (eff > best + 1e-9) { best = eff; K = k; }
+            if (eff >= 0.97) break;
+        }
+    }
+    if (K > n_blocks - 1) K = n_blocks - 1;                        // the last block belongs to the pre-pass
+    if (K < 1) K = 1;
+    return K;
+}
+
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
                 float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
                 bool allow_fast = true)
@@ -272,11 +298,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         // tuning experiments (read per call so that one process can sweep them: tools/tune_p1.py)
         const char *env_tw = getenv("OHS_P1_TARGET_WAVES");
         const long long target_override = env_tw ? atoll(env_tw) : 0LL;
-        const long long target_waves =
-            target_override > 0 ? target_override : 2LL * ctx->num_cus * conv_p1_waves_per_cu();
-        long long K = (target_waves + (long long)c.S - 1) / (long long)c.S;
-        if (K > n_blocks - 1) K = n_blocks - 1;                        // the last block has its own kernel
-        if (K < 1) K = 1;
+        const long long K = conv_p1_chunks(ctx, c.S, n_blocks, target_override);
         if ((size_t)K > c.chunk_tails_cap) {
             HIP_TRY(hipStreamSynchronize(st));
             if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
@@ -1751,9 +1773,7 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
     const uint64_t eq_sb = 4096u + 4096u + 520u;
     *eq_bytes = b->eq_enable ? nbk * S * eq_sb : 0;
     if (P == 1) {
-        uint64_t K = (2ull * (uint64_t)b->ctx->num_cus * (uint64_t)conv_p1_waves_per_cu() + S - 1) / S;
-        if (nbk < 2) K = 1; else if (K > nbk - 1) K = nbk - 1;
-        if (K < 1) K = 1;
+        const uint64_t K = (uint64_t)conv_p1_chunks(b->ctx, (size_t)S, (long long)nbk, 0);
         *conv_bytes = nbk * S * 8192u + S * (K * 2u * 4096u + 2u * 8192u);
     } else {
         *conv_bytes = nbk * S * (4096u + 8192u + 8192u + 8192u + 8192u + 4096u);
