@@ -12,6 +12,7 @@
 //   * all global traffic is lane-contiguous ([reg][lane] images, 512 B per wave load).
 #include "kernels.h"
 #include "wave_fft.hpp"
+#include "eq_ring_body.hpp"     // the resident kernel runs the chain's EQ; this file is built -ffp-contract=off too
 
 #include <atomic>
 
@@ -357,17 +358,26 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     if (wave == n_waves - 1) {
         const int consumed = A.n_blocks * kBlock;
         const int rem = E.in_len + E.n - consumed;
-        if (A.n_blocks == 0) {
-            for (int i = lane; i < E.n; i += 64) {
-                E.in_fifo[E.in_len + i] = IO::ld(E.src_l + i);
-                E.in_fifo[E.in_cap + E.in_len + i] = IO::ld(E.src_r + i);
-            }
-        } else {
-            // in_len < 512 <= consumed: the remainder lies entirely in this call's new frames
-            for (int i = lane; i < rem; i += 64) {
-                E.in_fifo[i] = IO::ld(E.src_l + consumed - E.in_len + i);
-                E.in_fifo[E.in_cap + i] = IO::ld(E.src_r + consumed - E.in_len + i);
-            }
+        // fewer than 512 frames, i.e. at most 8 per lane and channel: all loads first (clamped index, no branch around
+        // a load -- the source is pinned host memory, and one PCIe round trip per loop iteration is what a branchy
+        // loop costs), then the stores
+        const int n_copy = A.n_blocks == 0 ? E.n : rem;                       // <= 511 either way
+        // in_len < 512 <= consumed: the remainder lies entirely in this call's new frames.  Nothing to copy: the
+        // (unconditional) loads read frame 0, which every call has.
+        const int src_off = (A.n_blocks == 0 || n_copy <= 0) ? 0 : consumed - E.in_len;
+        const int dst_off = A.n_blocks == 0 ? E.in_len : 0;
+        const int last = n_copy > 0 ? n_copy - 1 : 0;
+        float l[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = k * 64 + lane, ic = i < last ? i : last;
+            l[k] = IO::ld(E.src_l + src_off + ic);
+            r[k] = IO::ld(E.src_r + src_off + ic);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = k * 64 + lane;
+            if (i < n_copy) { E.in_fifo[dst_off + i] = l[k]; E.in_fifo[E.in_cap + dst_off + i] = r[k]; }
         }
     }
 }
@@ -398,6 +408,16 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
 // cannot serve), or no doorbell for `idle_limit` polls (a host that died or simply went quiet must not leave a
 // wave spinning on the GPU); the kernel announces its exit in `alive` so that a host ringing at that moment
 // re-launches instead of waiting.
+// The EQ is an out-of-line function of the resident kernel: inlined next to the convolution body hipcc needed
+// more than the 256 VGPRs two waves per SIMD leave and spilled 350 bytes per lane into the path where every
+// microsecond counts (a 1024-frame call without EQ went from 16 to 26 us); as a call it has its own allocation.
+// (The body itself stays inlined: out of line it saves and restores ~100 callee-saved registers per call.)
+__device__ __attribute__((noinline)) void rt_eq_call(float *buf, long long stride, long long n, int nb,
+                                                     const EqPassTable *tab, float *state)
+{
+    eq_ring_wave(buf, buf, 0, stride, n, 2, nb, *tab, state, 0);
+}
+
 __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const float2 *tw, unsigned first_seq,
                                                          unsigned long long idle_limit, unsigned sleep_arg)
 {
@@ -405,8 +425,11 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     float2 *tab = smem;
     float2 *slabs = smem + kTabComplex;
     __shared__ unsigned s_cmd;
-    __shared__ int s_n;
+    __shared__ int s_n, s_eq;
+    __shared__ unsigned s_eq_ver_call;      // the EQ block version this call wants (low 15 bits, from the call word)
     __shared__ float s_gain;
+    __shared__ unsigned s_eq_version;
+    __shared__ __attribute__((aligned(16))) unsigned s_eq_blk[(sizeof(RtMailbox) - offsetof(RtMailbox, eq_version) + 3) / 4];
     __shared__ __attribute__((aligned(16))) unsigned s_args[(sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     fill_twiddle_tables(tab, tw, threadIdx.x, 512);
@@ -418,6 +441,8 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     __syncthreads();
     ConvGeneralArgs &A = *reinterpret_cast<ConvGeneralArgs *>(s_args);
     EngineCallArgs &E = *reinterpret_cast<EngineCallArgs *>(reinterpret_cast<char *>(s_args) + sizeof(ConvGeneralArgs));
+    if (threadIdx.x == 0) s_eq_version = 0xffffffffu;       // no EQ block held yet (the host counts from 1)
+    const float *const host_src_l = E.src_l, *const host_src_r = E.src_r;
     unsigned last = first_seq;              // the doorbell value already served
     for (;;) {
         if (threadIdx.x == 0) {
@@ -432,7 +457,9 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
                 if (w.w) break;                                         // stop
                 if (w.x != last) {
                     last = w.x; cmd = 1;
-                    s_n = (int)w.y; s_gain = __uint_as_float(w.z);
+                    // w.y = n (bits 0..15) | EQ block version, low 15 bits (16..30) | run the EQ (31)
+                    s_n = (int)(w.y & 0xffffu); s_eq = (int)(w.y >> 31); s_eq_ver_call = (w.y >> 16) & 0x7fffu;
+                    s_gain = __uint_as_float(w.z);
                     break;
                 }
                 if (++idle >= idle_limit) break;
@@ -446,9 +473,59 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         if (threadIdx.x == 0) { st0 = __builtin_amdgcn_s_memrealtime(); ck0 = __builtin_amdgcn_s_memtime(); }
         // the host's writes (input frames) precede its doorbell store; make them visible to this CU
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (s_eq) {
+            // lib.rs:1194: the EQ runs on this host block before the engine sees it.  (1) the EQ block (table,
+            // state pointer, staging buffer) if the host has changed it, (2) the block's frames from pinned
+            // host memory to the device staging buffer, all waves -- the EQ kernel's one-group prefetch cannot
+            // cover a PCIe read --, (3) wave 0 = the two chains L, R in place, (4) the convolution reads from there.
+            constexpr int eq_words = (int)((sizeof(RtMailbox) - offsetof(RtMailbox, eq_version) + 3) / 4);
+            // the version the call wants travels in the call word, so an unchanged block costs no PCIe read
+            if (s_eq_ver_call != (s_eq_version & 0x7fffu) || s_eq_version == 0xffffffffu) {      // uniform
+                __syncthreads();
+                const unsigned *src = reinterpret_cast<const unsigned *>(&mb->eq_version);
+                for (int i = threadIdx.x; i < eq_words; i += 512) s_eq_blk[i] = src[i];
+                __syncthreads();
+                if (threadIdx.x == 0) s_eq_version = s_eq_blk[0];
+                __syncthreads();
+            }
+            const RtMailbox *const eqb = reinterpret_cast<const RtMailbox *>(reinterpret_cast<const char *>(s_eq_blk) -
+                                                                              offsetof(RtMailbox, eq_version));
+            float *const buf = eqb->eq_buf;
+            const long long stride = eqb->eq_buf_stride;
+            const int n = s_n;
+            // eight PCIe reads per thread in flight (clamped index instead of a branch around each load: one round
+            // trip for a 1024-frame block, not one per loop iteration)
+            for (int base = 0; base < n; base += 4 * 512) {
+                float l[4], r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = base + k * 512 + (int)threadIdx.x, ic = i < n ? i : n - 1;
+                    l[k] = host_src_l[ic]; r[k] = host_src_r[ic];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = base + k * 512 + (int)threadIdx.x;
+                    if (i < n) { buf[i] = l[k]; buf[stride + i] = r[k]; }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wave == 0) {
+                if (threadIdx.x == 0) mb->stamps[6] = __builtin_amdgcn_s_memrealtime();
+                rt_eq_call(buf, stride, (long long)n, eqb->eq_nb, &eqb->eq_tab, eqb->eq_state);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (threadIdx.x == 0) mb->stamps[7] = __builtin_amdgcn_s_memrealtime();
+            }
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {             // this call's FIFO arithmetic (convolution.rs:149-163)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             st1 = __builtin_amdgcn_s_memrealtime();
+            if (s_eq) {
+                const RtMailbox *const eqb2 = reinterpret_cast<const RtMailbox *>(reinterpret_cast<const char *>(s_eq_blk) -
+                                                                                   offsetof(RtMailbox, eq_version));
+                E.src_l = eqb2->eq_buf; E.src_r = eqb2->eq_buf + eqb2->eq_buf_stride;
+            } else { E.src_l = host_src_l; E.src_r = host_src_r; }
             const int n = s_n;
             const int k = (E.in_len + n) / kBlock;
             A.n_blocks = k;

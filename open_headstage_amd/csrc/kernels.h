@@ -5,6 +5,30 @@
 
 namespace ohs {
 
+// ---- EQ ------------------------------------------------------------------------
+// One pass of up to 16 cascaded DF2T bands (parametric_eq.rs:116-122,166-179).
+// Only ENABLED bands are handed to the kernel (a disabled band is the identity and keeps its state,
+// parametric_eq.rs:118-120), so lane j of a row is the j-th enabled band of this pass and `slot[j]` is
+// that band's index in the per-chain state array.
+struct EqPassTable {
+    float b0[16], b1[16], b2[16], a1[16], a2[16];
+    int slot[16];
+};
+constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
+// chains = streams * 2 (L, R); chain c -> stream c>>1, channel c&1.
+// state: [chain][kEqStateSlots][2] (s1, s2), indexed by the band's own index.
+// n_bands = bands of this pass (1..16, lanes >= n_bands are unused).
+// exact_specials: use the conveyor form (k_eq_pass: samples move by DPP moves only) also for <= 12 bands; it is
+// bit-exact for -0.0 and for samples next to a non-finite input, where the faster ring form is not (its
+// pass-on lanes run 1*x + 0).
+hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
+                          long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
+                          hipStream_t st, bool exact_specials = false);
+
+// |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
+hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,
+                                   const float *d_freqs, int n, float *d_out, hipStream_t st);
+
 // ---- convolution -------------------------------------------------------------
 // "General" kernel: faithful per-path semantics of src/dsp/convolution.rs
 // (per-path partition count, per-path history reset, four separate overlap tails).
@@ -55,6 +79,14 @@ struct RtMailbox {
     alignas(64) unsigned long long stamps[16];   // diagnostics: s_memrealtime (100 MHz) at the phases of the last call
     alignas(64) ConvGeneralArgs conv;
     EngineCallArgs call;
+    // the chain's EQ (lib.rs:1179-1194), run by the kernel in front of the convolution when call_word[1] has bit
+    // 31 set: the kernel re-reads this block whenever eq_version differs from the one it holds
+    alignas(64) unsigned eq_version;
+    int eq_nb;                   // enabled bands (<= 12: the ring form)
+    float *eq_state;             // the ohs_eq handle's [2][kEqStateSlots][2] state
+    float *eq_buf;               // device [2][eq_buf_stride] staging: the EQ runs in place here, the convolution reads it
+    long long eq_buf_stride;
+    EqPassTable eq_tab;
 };
 hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned first_seq, unsigned long long idle_limit,
                                   unsigned sleep_arg, hipStream_t st);
@@ -135,29 +167,5 @@ hipError_t launch_debug_fft(const float2 *in, float2 *out, int inverse, int batc
 
 // dst[i] = src[i] * gain  (n floats)
 hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st);
-
-// ---- EQ ------------------------------------------------------------------------
-// One pass of up to 16 cascaded DF2T bands (parametric_eq.rs:116-122,166-179).
-// Only ENABLED bands are handed to the kernel (a disabled band is the identity and keeps its state,
-// parametric_eq.rs:118-120), so lane j of a row is the j-th enabled band of this pass and `slot[j]` is
-// that band's index in the per-chain state array.
-struct EqPassTable {
-    float b0[16], b1[16], b2[16], a1[16], a2[16];
-    int slot[16];
-};
-constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
-// chains = streams * 2 (L, R); chain c -> stream c>>1, channel c&1.
-// state: [chain][kEqStateSlots][2] (s1, s2), indexed by the band's own index.
-// n_bands = bands of this pass (1..16, lanes >= n_bands are unused).
-// exact_specials: use the conveyor form (k_eq_pass: samples move by DPP moves only) also for <= 12 bands; it is
-// bit-exact for -0.0 and for samples next to a non-finite input, where the faster ring form is not (its
-// pass-on lanes run 1*x + 0).
-hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
-                          long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
-                          hipStream_t st, bool exact_specials = false);
-
-// |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
-hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,
-                                   const float *d_freqs, int n, float *d_out, hipStream_t st);
 
 }  // namespace ohs

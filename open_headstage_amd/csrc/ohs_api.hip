@@ -437,6 +437,26 @@ int eq_reset(EqState &e, hipStream_t st)
     return OHS_OK;
 }
 
+// the enabled bands, in cascade order, as ONE pass table; returns their number (the caller checks <= 16 / <= 12)
+int eq_single_pass_table(const EqState &e, EqPassTable &t)
+{
+    std::memset(&t, 0, sizeof(t));
+    int nbp = 0;
+    size_t last = 0;
+    for (size_t b = 0; b < e.nb; ++b) {
+        if (!e.en[b]) continue;
+        if (nbp < 16) {
+            t.slot[nbp] = (int)b;
+            t.b0[nbp] = e.coeffs[5 * b + 0]; t.b1[nbp] = e.coeffs[5 * b + 1]; t.b2[nbp] = e.coeffs[5 * b + 2];
+            t.a1[nbp] = e.coeffs[5 * b + 3]; t.a2[nbp] = e.coeffs[5 * b + 4];
+            last = b;
+        }
+        ++nbp;
+    }
+    for (int j = std::min(nbp, 16); j < 16; ++j) t.slot[j] = (int)last;    // unused lanes shadow the last band's slot (never stored)
+    return nbp;
+}
+
 // run the cascade over n frames of `chains` chains, in place allowed
 int eq_launch(EqState &e, const float *in, float *out, long long ss, long long cs, long long n,
               hipStream_t st, bool *did_anything = nullptr)
@@ -540,6 +560,7 @@ struct ohs_engine {
     RtMailbox *mb = nullptr, *mb_dev = nullptr;
     hipStream_t rt_st = nullptr;
     unsigned rt_seq = 0;
+    unsigned rt_eq_version = 0;     // version of the EQ block in the mailbox (bumped whenever its content changes)
 };
 
 struct ohs_eq {
@@ -762,7 +783,7 @@ int rt_start(ohs_engine *e)
 // One process_block call through the mailbox.  Same FIFO arithmetic as engine_process_single_launch (the kernel
 // runs it too); nothing is launched, allocated or freed here while the kernel is resident (growth stops it first).
 int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r, float *out_l, float *out_r,
-                            size_t n, float gain)
+                            size_t n, float gain, EqState *eq, const EqPassTable *eq_tab, int eq_nb)
 {
     ConvState &c = e->conv;
     const size_t k = (e->in.len + n) / BS;
@@ -783,11 +804,20 @@ int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r,
     std::memcpy(e->h_in, in_l, n * sizeof(float));
     std::memcpy(e->h_in + e->hcap, in_r, n * sizeof(float));
     RtMailbox *mb = e->mb;
+    if (eq) {   // the chain's EQ block: rewritten (and its version bumped) only when something in it changed
+        if (mb->eq_nb != eq_nb || mb->eq_state != eq->d_state || mb->eq_buf != e->d_eqbuf ||
+            mb->eq_buf_stride != (long long)e->hcap || std::memcmp(&mb->eq_tab, eq_tab, sizeof(EqPassTable)) != 0 ||
+            e->rt_eq_version == 0) {
+            mb->eq_nb = eq_nb; mb->eq_state = eq->d_state; mb->eq_buf = e->d_eqbuf; mb->eq_buf_stride = (long long)e->hcap;
+            std::memcpy(&mb->eq_tab, eq_tab, sizeof(EqPassTable));
+            mb->eq_version = ++e->rt_eq_version;
+        }
+    }
     const unsigned seq = ++e->rt_seq;
     unsigned gbits;
     std::memcpy(&gbits, &gain, sizeof(gbits));
     auto ring = [&]() {
-        mb->call_word[1] = (unsigned)n;
+        mb->call_word[1] = (unsigned)n | ((e->rt_eq_version & 0x7fffu) << 16) | (eq ? 0x80000000u : 0u);    // n <= 8192
         mb->call_word[2] = gbits;
         __atomic_store_n(&mb->call_word[0], seq, __ATOMIC_RELEASE);
     };
@@ -840,7 +870,15 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     // real-time sized calls: the resident kernel's mailbox (real-time mode, no EQ in the chain) or everything in
     // one launch; long offline calls: the multi-kernel path below
     const bool rt_sized = (e->in.len + n) / BS <= 8 && n <= 8192 && e->in.len < (size_t)BS;
-    if (rt_sized && e->rt_enabled && !eq) return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain);
+    if (rt_sized && e->rt_enabled) {
+        // the resident kernel serves the call unless the chain's EQ needs more than the ring form's 12 bands
+        if (!eq) return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0);
+        EqPassTable t;
+        const int nb_on = eq_single_pass_table(eq->eq, t);
+        if (nb_on == 0) return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0);
+        if (nb_on <= 12 && !eq->eq.exact_specials)
+            return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, &eq->eq, &t, nb_on);
+    }
     rt_stop(e);         // the paths below launch kernels on the engine's state
     if (rt_sized) return engine_process_single_launch(e, in_l, in_r, out_l, out_r, n, eq, gain);
     int rc = fifo_reserve(e->in, e->in.len + n, st);

@@ -150,3 +150,63 @@ def test_latency_report_matches_the_fifo_rule(ohs, synth, oracle):
     assert eng.silent_frames() == silent == eng.latency_samples(n) and silent > 0
     got = np.concatenate(served, 1)
     assert_parity(got, x[:, :got.shape[1]], "delta HRIR: the served calls are the input stream, end to end")
+
+
+@pytest.mark.parametrize("nb_on", [1, 4, 10, 12])
+def test_chain_with_eq_through_the_resident_kernel_is_bit_identical_and_matches_the_oracle(ohs, synth, oracle, nb_on):
+    """lib.rs:1179-1207 served by the resident kernel: EQ (ring form, <= 12 enabled bands) -> convolution -> gain in
+    one mailbox round trip; per-call coefficient refresh as the plugin does it (the EQ block is re-sent when it
+    changes); same bits as the launch-per-call chain, parity with the oracle."""
+    bands = synth.eq_table()
+    irs = synth.hrir_set(512)
+
+    def make(rt):
+        e = ohs.ConvolutionEngine.new()
+        for p in range(4):
+            e.set_ir(p, irs[p])
+        q = ohs.StereoParametricEQ.new(len(bands) + 2, synth.FS)
+        for i, b in enumerate(bands[:nb_on]):
+            q.update_band_coeffs(i, synth.FS, b)
+        if rt:
+            e.set_realtime(True)
+        return e, q
+
+    er, qr = make(True)
+    el, ql = make(False)
+    eo = oracle.ConvolutionEngine()
+    for p in range(4):
+        eo.set_ir(p, irs[p])
+    qo = oracle.StereoParametricEQ(len(bands) + 2, synth.FS)
+    for i in range(nb_on):
+        c, en = qr.get_band_coeffs(i)
+        qo.set_band_coeffs(i, c, en)
+    sizes = [1024, 1024, 512, 256, 100, 2048, 1024, 37, 1024, 4096, 1024]
+    x = synth.white_noise([77], sum(sizes))[0]
+    o = 0
+    got, want = [], []
+    for k, n in enumerate(sizes):
+        if k == 4:                                  # a parameter change between callbacks: band 0 retuned, band 1 off / on
+            nb = ohs.BandConfig(ohs.FilterType.Peak, 900.0, 1.1, -5.0, True)
+            for q in (qr, ql):
+                q.update_band_coeffs(0, synth.FS, nb)
+            qo.set_band_coeffs(0, qr.get_band_coeffs(0)[0], True)
+        gain = 0.5 + 0.05 * k
+        a_l, a_r = x[0, o:o + n].copy(), x[1, o:o + n].copy()
+        b_l, b_r = a_l.copy(), a_r.copy()
+        c_l, c_r = a_l.copy(), a_r.copy()
+        ohs.process_chain(er, qr, a_l, a_r, eq_enable=True, output_gain=gain)
+        ohs.process_chain(el, ql, b_l, b_r, eq_enable=True, output_gain=gain)
+        oracle.chain_process(eo, qo, c_l, c_r, eq_enable=True, gain=gain)
+        assert np.array_equal(a_l.view(np.uint32), b_l.view(np.uint32)) and np.array_equal(a_r.view(np.uint32), b_r.view(np.uint32)), (k, n)
+        got.append(np.stack([a_l, a_r])); want.append(np.stack([c_l, c_r]))
+        o += n
+    assert_parity(np.concatenate(got, 1), np.concatenate(want, 1), "resident chain vs oracle")
+    # EQ disabled / bypass through the same entry point
+    a_l, a_r = x[0, :1024].copy(), x[1, :1024].copy()
+    b_l, b_r = a_l.copy(), a_r.copy()
+    ohs.process_chain(er, qr, a_l, a_r, eq_enable=False, output_gain=1.0)
+    ohs.process_chain(el, ql, b_l, b_r, eq_enable=False, output_gain=1.0)
+    assert np.array_equal(a_l, b_l) and np.array_equal(a_r, b_r)
+    keep = a_l.copy()
+    ohs.process_chain(er, qr, a_l, a_r, master_bypass=True, eq_enable=True)
+    assert np.array_equal(a_l, keep)

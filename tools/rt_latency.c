@@ -21,26 +21,41 @@ static double now_us(void)
 }
 static int cmp(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return x < y ? -1 : x > y; }
 
+static ohs_eq *g_eq = NULL;      /* != NULL: time ohs_chain_process (EQ -> convolution -> gain) instead of process_block */
+
+static int one_call(ohs_engine *e, float *il, float *ir, float *ol, float *orr, size_t n)
+{
+    if (!g_eq) return ohs_engine_process_block(e, il, ir, ol, orr, n);
+    memcpy(ol, il, n * 4); memcpy(orr, ir, n * 4);          /* the chain works in place */
+    /* per-callback coefficient refresh, as lib.rs:1180-1193 does it */
+    for (size_t b = 0; b < 10; ++b)
+        ohs_eq_update_band(g_eq, b, 48000.0f, b == 0 ? OHS_FILTER_LOWSHELF : (b == 9 ? OHS_FILTER_HIGHSHELF : OHS_FILTER_PEAK),
+                           60.0f * (float)(1 << b) > 18000.0f ? 18000.0f : 60.0f * (float)(1 << b), 1.2f, (b & 1) ? 2.0f : -2.5f, 1);
+    return ohs_chain_process(e, g_eq, 0, 1, 0.9f, ol, orr, n);
+}
+
 static void run(ohs_engine *e, size_t n, int calls, const char *what)
 {
     float *il = calloc(n, 4), *ir = calloc(n, 4), *ol = calloc(n, 4), *orr = calloc(n, 4);
     double *t = malloc(sizeof(double) * (size_t)calls);
     unsigned s = 12345;
     for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; il[i] = (float)(s >> 8) / 8388608.0f - 1.0f; ir[i] = -il[i]; }
-    for (int c = 0; c < 50; ++c) ohs_engine_process_block(e, il, ir, ol, orr, n);
+    for (int c = 0; c < 50; ++c) one_call(e, il, ir, ol, orr, n);
     for (int c = 0; c < calls; ++c) {
         const double t0 = now_us();
-        if (ohs_engine_process_block(e, il, ir, ol, orr, n)) { printf("error: %s\n", ohs_last_error()); exit(1); }
+        if (one_call(e, il, ir, ol, orr, n)) { printf("error: %s\n", ohs_last_error()); exit(1); }
         t[c] = now_us() - t0;
     }
     {   /* device-side phases of the last call, if the resident kernel served it (10 ns ticks) */
         uint64_t st[16];
         if (ohs_engine_debug_rt_stamps(e, st) == 0 && st[4] > st[0] && st[4] - st[0] < 100000)
-            printf("  device phases of the last call [us]: acquire %.2f, body %.2f, drain+barrier %.2f, release %.2f, total %.2f; shader clock %.0f MHz\n",
+            printf("# device phases of the last call [us]: acquire %.2f, body %.2f, drain+barrier %.2f, release %.2f, total %.2f; shader clock %.0f MHz\n",
                    (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[4] - st[0]) * 0.01,
                    (double)st[5] / ((st[4] - st[0]) * 0.01));
+        if (g_eq && st[7] > st[6] && st[7] - st[6] < 100000)
+            printf("# EQ inside the resident kernel [us]: copy-in + table %.2f, EQ %.2f\n", (st[6] - st[0]) * 0.01, (st[7] - st[6]) * 0.01);
         if (ohs_engine_debug_rt_stamps(e, st) == 0 && st[14] > st[8] && st[14] - st[8] < 100000)
-            printf("  inside the body [us]: pop %.2f, load+fwd FFT %.2f, barrier %.2f, MAC %.2f, 2 inverse FFTs %.2f, tails+barrier+store %.2f\n",
+            printf("# inside the body [us]: pop %.2f, load+fwd FFT %.2f, barrier %.2f, MAC %.2f, 2 inverse FFTs %.2f, tails+barrier+store %.2f\n",
                    (st[9] - st[8]) * 0.01, (st[10] - st[9]) * 0.01, (st[11] - st[10]) * 0.01, (st[12] - st[11]) * 0.01,
                    (st[13] - st[12]) * 0.01, (st[14] - st[13]) * 0.01);
     }
@@ -66,6 +81,13 @@ int main(void)
     run(e, 256, 2000, "c_host_engine_256_resident_kernel");
     ohs_engine_set_realtime(e, 0);
     run(e, 256, 2000, "c_host_engine_256_launch_per_call");
+    /* the plugin's whole chain: 10-band EQ (coefficients refreshed per call) -> convolution -> gain */
+    if (ohs_eq_create(0, 10, 48000.0f, &g_eq)) { printf("eq create: %s\n", ohs_last_error()); return 1; }
+    run(e, 1024, 2000, "c_host_chain_eq_conv_gain_1024_launch_per_call");
+    ohs_engine_set_realtime(e, 1);
+    run(e, 1024, 2000, "c_host_chain_eq_conv_gain_1024_resident_kernel");
+    ohs_engine_set_realtime(e, 0);
+    ohs_eq_destroy(g_eq);
     ohs_engine_destroy(e);
     return 0;
 }
