@@ -5,7 +5,10 @@ ragged host blocks, impulse responses replaced in mid-stream (per path, differen
 retuned / toggled / reset between calls, engine clones -- so that every hand-over of state between the
 single-launch engine call, the general kernel, the one-partition fast path, the time-parallel long-IR
 path and the two EQ kernels gets exercised.  Bars as in test_gpu_parity.py: EQ bit-exact, everything that
-passes through an FFT <= 1e-6 RMS (absolute and relative) against the oracle.
+passes through an FFT <= 1e-6 RMS (absolute and relative) against the oracle.  Odd seeds run the engine in
+real-time mode (resident kernel + mailbox, round 2) and toggle it in mid-sequence, so that the hand-over of
+state between the resident kernel and every launched path -- in both directions, around set_ir, clone and the
+chain's EQ -- is part of the mix.
 """
 import os
 
@@ -69,7 +72,13 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
     stream = synth.white_noise([200 + seed], 45 * 9000)[0]        # 45 steps of <= 9000 frames
     pos = 0
     got, ref = [], []
+    rt = bool(seed & 1)
+    if rt:
+        eg.set_realtime(True)
     for step in range(45):
+        if (seed & 1) and step in (13, 27, 36):                   # leave / re-enter real-time mode in mid-stream
+            rt = not rt
+            eg.set_realtime(rt)
         op = rng.random()
         if op < 0.62:                   # the lib.rs:1169-1207 chain on one host block
             n = int(rng.choice(sizes))
@@ -100,8 +109,10 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
             _sync_band(qg, qo, i)
         elif op < 0.95:
             qg.reset_all_bands_state(); qo.reset_all_bands_state()
-        else:                           # continue on deep copies
+        else:                           # continue on deep copies (a clone starts outside real-time mode)
             eg, eo = eg.clone(), eo.clone()
+            if rt:
+                eg.set_realtime(True)
     if got:
         assert_parity(np.concatenate(got, 1), np.concatenate(ref, 1), f"fuzz chain seed {seed}")
 

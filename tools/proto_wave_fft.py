@@ -159,4 +159,45 @@ if __name__ == "__main__":
           "read", worst(halves, lambda L, q: addr2((L >> 2) & 3, L & 3, q, L >> 4), 32))
     print("T1 inv write", worst(g16, lambda L, b: addr1(L >> 2, 4 * b + (L & 3)), 16),
           "read", worst(halves, lambda m, p: addr1(p, m), 32))
+    # round 2: the mirror spectrum is read from the T2 image (wave_fft_fwd_mirror) -- groups j' = 1..3 of lane
+    # 63 - L, group j' = 0 of lane 64 - L -- and one twiddle table w1024^(m p) in the T1 layout serves both
+    # directions (rows forward, columns inverse)
+    print("T2 mirror reads", worst(halves, lambda L, g: addr2(g >> 2, g & 3, (63 - L) >> 2, (63 - L) & 3), 32),
+          worst(halves, lambda L, g: addr2(0, g & 3, ((64 - L) & 63) >> 2, ((64 - L) & 63) & 3), 32))
+    print("twiddle table rows / columns", worst(halves, lambda m, p: addr1(p, m), 32),
+          worst(halves, lambda L, b: addr1(L >> 2, 4 * b + (L & 3)), 32))
+    # the mirror trick itself: DFT4 over c of the T2-image groups of the mirror lanes gives Z[N - k]
+    def t2_image(z):
+        regs = np.zeros((64, 16), complex)
+        for m in range(64):
+            u = dft_small(np.array([z[64 * a + m] for a in range(16)]), 16, +1)
+            for pp in range(16):
+                regs[m, pp] = u[pp] * w(1024, m * pp)
+        lds = np.zeros(16 * 68, complex)
+        for m in range(64):
+            for pp in range(16):
+                lds[addr1(pp, m)] = regs[m, pp]
+        for L1 in range(64):
+            pp, c = L1 >> 2, L1 & 3
+            u = dft_small(np.array([lds[addr1(pp, 4 * b + c)] for b in range(16)]), 16, +1)
+            for q in range(16):
+                regs[L1, q] = u[q] * w(64, c * q)
+        img = np.zeros(16 * 65 + 64, complex)
+        for L1 in range(64):
+            pp, c = L1 >> 2, L1 & 3
+            for q in range(16):
+                img[addr2(pp & 3, c, q, pp >> 2)] = regs[L1, q]
+        return img
+    img = t2_image(z)
+    for L in range(64):
+        la, lb = 63 - L, (64 - L) & 63
+        m = np.zeros(16, complex)
+        for jj in range(4):
+            src = lb if jj == 0 else la
+            m[4 * jj:4 * jj + 4] = dft_small(np.array([img[addr2(jj, c, src >> 2, src & 3)] for c in range(4)]), 4, +1)
+        for r in range(4):
+            for j in range(4):
+                got = m[4 * (4 - j) + (3 - r)] if j else (m[(4 - r) & 3] if L == 0 else m[3 - r])
+                assert abs(got - ref[(N - bins_of(L, 4 * r + j)) % N]) < 1e-9, (L, r, j)
+    print("mirror from the T2 image: OK")
     print("OK")
