@@ -658,7 +658,8 @@ __device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float
 #ifdef OHS_KO_CD
         const float2 c = make_float2(0.5f, 0.001f * (float)lane), d = make_float2(0.25f, 0.002f * (float)lane);
 #else
-        const float2 c = lds_ld(&cd[r * 64 + lane]), d = lds_ld(&cd[kFft + r * 64 + lane]);
+        float2 c, d;        // interleaved in LDS: one ds_read_b128 per register instead of two ds_read_b64
+        lds_ld2(reinterpret_cast<const float4 *>(cd) + r * 64 + lane, c, d);
 #endif
         w[r].x = fmaf(m.y, d.y, fmaf(m.x, d.x, fmaf(-zz.y, c.y, zz.x * c.x)));
         w[r].y = fmaf(-m.y, d.x, fmaf(m.x, d.y, fmaf(zz.y, c.x, zz.x * c.y)));
@@ -676,10 +677,12 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     float2 *tab = smem;
     float2 *cd = smem + kTabComplex;                    // [2][16][64]
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kP1Waves);
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(A.CD);
+    {   // C and D interleaved position by position: cd4[i] = (C[i], D[i])
         float4 *dst = reinterpret_cast<float4 *>(cd);
-        for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) {
+            const float2 c = A.CD[i], d = A.CD[kFft + i];
+            dst[i] = make_float4(c.x, c.y, d.x, d.y);
+        }
     }
     __syncthreads();
     // wave-uniform quantities are forced into SGPRs: stream, chunk, block range and the four audio base
@@ -778,10 +781,12 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Arg
     float2 *tab = smem;
     float2 *cd = smem + kTabComplex;
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kP1Waves);
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(A.CD);
+    {   // C and D interleaved position by position: cd4[i] = (C[i], D[i])
         float4 *dst = reinterpret_cast<float4 *>(cd);
-        for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) {
+            const float2 c = A.CD[i], d = A.CD[kFft + i];
+            dst[i] = make_float4(c.x, c.y, d.x, d.y);
+        }
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;

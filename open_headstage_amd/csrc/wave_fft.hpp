@@ -108,7 +108,20 @@ __device__ __forceinline__ void lds_st(float2 *p, float2 v)
     *(volatile __attribute__((address_space(3))) unsigned long long *)p =
         (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
 }
+// 16-byte LDS read (ds_read_b128: one instruction, one queue slot for two complex values)
+typedef unsigned lds_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_ld2(const float4 *p, float2 &a, float2 &b)
+{
+    const lds_u32x4 t = *(const volatile __attribute__((address_space(3))) lds_u32x4 *)p;
+    a = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+    b = make_float2(__uint_as_float(t.z), __uint_as_float(t.w));
+}
 #else
+__device__ __forceinline__ void lds_ld2(const float4 *p, float2 &a, float2 &b)
+{
+    const float4 t = *p;
+    a = make_float2(t.x, t.y); b = make_float2(t.z, t.w);
+}
 __device__ __forceinline__ float2 lds_ld(const float2 *p) { return *p; }
 __device__ __forceinline__ void lds_st(float2 *p, float2 v) { *p = v; }
 #endif
