@@ -208,6 +208,61 @@ __device__ __forceinline__ void block_mac(const ConvGeneralArgs &A, const float2
     }
 }
 
+// One ear pair's share of (3) for the single-stream call, which gives the two halves to two waves: h = 0 -> paths
+// 0, 1 (acc = lsl + j lsr), h = 1 -> paths 2, 3 (rsl + j rsr).  Same operations in the same order as block_mac (and
+// the same skip rule over all four gates), so the two agree bit for bit.  LDS_P0: partition 0 of path p is read from
+// hl[p][1024] in LDS (the resident kernel's copy) instead of A.H[p].
+template <bool LDS_P0>
+__device__ __forceinline__ void block_mac_half(const ConvGeneralArgs &A, const float2 *hist, const float2 *hl, int t,
+                                               int maxP, int h, const float2 (&v)[16], float2 (&acc)[16], int lane)
+{
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+    const int Pa = h ? A.P[2] : A.P[0], Pb = h ? A.P[3] : A.P[1];
+    const float2 *Ha = h ? A.H[2] : A.H[0], *Hb = h ? A.H[3] : A.H[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = make_float2(0.f, 0.f);
+    for (int i = 0; i < maxP; ++i) {
+        const bool g0 = i < A.P[0] && (long long)i <= A.since[0] + t;
+        const bool g1 = i < A.P[1] && (long long)i <= A.since[1] + t;
+        const bool g2 = i < A.P[2] && (long long)i <= A.since[2] + t;
+        const bool g3 = i < A.P[3] && (long long)i <= A.since[3] + t;
+        if (!(g0 || g1 || g2 || g3)) continue;
+        const bool ga = h ? g2 : g0, gb = h ? g3 : g1;
+
+        float2 zi[16], zm[16], ca[16], cb[16];
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zi[r] = v[r];
+        } else {
+            const float2 *hs = hist + ((A.cnt + (unsigned long long)t - (unsigned long long)i) & mask) * kFft;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zi[r] = hs[r * 64 + lane];
+        }
+        if (LDS_P0 && i == 0) {
+            const float2 *la = hl + (2 * h) * kFft, *lb = la + kFft;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ca[r] = la[r * 64 + lane]; cb[r] = lb[r * 64 + lane]; }
+        } else {                            // one branch around the whole batch: its 32 loads are in flight together
+            const float2 *ha = Ha + (size_t)(i < Pa ? i : Pa - 1) * kFft;
+            const float2 *hb = Hb + (size_t)(i < Pb ? i : Pb - 1) * kFft;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ca[r] = ha[r * 64 + lane]; cb[r] = hb[r * 64 + lane]; }
+        }
+        wave_mirror(zi, zm, lane);
+        const float fa = ga ? 1.0f : 0.0f, fb = gb ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float2 c0 = ca[r], c1 = cb[r];
+            c0.x *= fa; c0.y *= fa; c1.x *= fb; c1.y *= fb;
+            const float2 xl = make_float2(0.5f * (zi[r].x + zm[r].x), 0.5f * (zi[r].y - zm[r].y));
+            const float2 xr = make_float2(0.5f * (zi[r].y + zm[r].y), -0.5f * (zi[r].x - zm[r].x));
+            const float2 x = h ? xr : xl;
+            cmac(acc[r], x, c0);
+            cmac_j(acc[r], x, c1);
+        }
+    }
+}
+
 template <class IO>
 __device__ __forceinline__ void conv_general_body(const ConvGeneralArgs &A, const IO &io, float2 *tab, float2 *lds,
                                                   int lane, size_t s)
@@ -276,10 +331,18 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
 // the call's latency is one block's (forward FFT, MAC, two inverse FFTs), not k of them.
 // Every thread of the workgroup must call it (it contains workgroup barriers); `tab` holds the twiddle
 // tables, `slabs` n_waves per-wave FFT slabs.
+// twiddle tables + 8 per-wave FFT slabs + 149 KiB of the CU's 160 either way:
+//   k_engine_call     : 8 spectrum hand-over areas + the stored overlaps
+//   k_engine_resident : 4 hand-over areas (it serves calls of up to kResidentMaxBlocks blocks, each with a pair of
+//                       waves) + the overlaps + partition 0 of the four paths' spectra
+constexpr size_t kEngineLdsBytes = (kTabComplex + 8 * (size_t)kWaveLdsComplex + 9 * (size_t)kFft) * sizeof(float2);
 #define OHS_DBG_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-template <bool SYSTEM>
+// RESIDENT (k_engine_resident): `cache` holds, across calls, the overlaps the engine carries ([16][64], kept up to
+// date here) and partition 0 of the four paths' spectra ([4][1024], filled when the kernel starts): the 34 loads
+// per wave they replace cost the CU's one address unit ~16 clocks each, next to the PCIe reads everyone waits for.
+template <bool SYSTEM, bool RESIDENT>
 __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const EngineCallArgs &E, float2 *tab,
-                                                 float2 *slabs, int wave, int lane, int n_waves,
+                                                 float2 *slabs, float2 *zx, float2 *cache, int wave, int lane, int n_waves,
                                                  unsigned long long *dbg = nullptr)
 {
     OHS_DBG_STAMP(8);
@@ -301,58 +364,107 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
         }
     }
     __syncthreads();
-    // 2. every complete 512-block (convolution.rs:152-161), block t = wave
+    // 2. every complete 512-block (convolution.rs:152-161).  A block's work after the forward transform is two
+    // independent halves (paths 0, 1 -> lsl + j lsr; paths 2, 3 -> rsl + j rsr: a MAC and an inverse transform each);
+    // with k <= n_waves / 2 blocks in the call every block gets a PAIR of waves, one per half (the even one also
+    // runs the forward transform and hands the spectrum over through LDS), otherwise one wave does both halves in
+    // turn.  Per (block, half) the results -- overlap for the next block and the raw lower half -- are parked in
+    // LDS, and after a barrier the block's waves share the 8 output rows.  Same arithmetic either way.
     IO io;
     io.E = E;
-    const int t = wave;
+    const bool split = 2 * A.n_blocks <= n_waves;
+    const int t = split ? wave >> 1 : wave;
+    const int h0 = split ? (wave & 1) : 0, h1 = split ? h0 + 1 : 2;
     const bool active = t < A.n_blocks;
     float2 *hist = A.hist;
+    float2 *tails_lds = cache;                      // [16][64]: the overlaps the engine holds from its previous call
+    const float2 *hl = cache + kFft;                // RESIDENT: [4][1024] partition 0 of the four paths
+    float2 *zt = zx + t * kFft;                     // block t's spectrum, [reg][lane]; later (one wave, both halves) half 0's results
     int maxP = A.P[0];
 #pragma unroll
     for (int p = 1; p < 4; ++p) maxP = A.P[p] > maxP ? A.P[p] : maxP;
-    float2 v[16], acc1[16], acc2[16];
+    const float scale = 1.0f / (float)kFft;         // convolution.rs:280
+    // where (block tt, half hh) parks its results: [0, 512) overlap (scaled), [512, 1024) lower half (raw)
+    auto parked = [&](int tt, int hh) -> float2 * {
+        return split ? slabs + (2 * tt + hh) * kWaveLdsComplex : (hh ? slabs + tt * kWaveLdsComplex : zx + tt * kFft);
+    };
+    float2 v[16], acc[16];
+    const int a0 = split ? 4 * h0 : 0;              // this wave's output rows: a0 .. a0+3 (pair) or 0 .. 7 (alone)
     OHS_DBG_STAMP(9);
-    if (active) {
+    // The CU's address unit takes ~16 clocks per load instruction whatever it fetches, so every load issued now
+    // -- by any wave -- stands between the PCIe reads of the input frames and the transform that waits for them
+    // (prefetching the spectra here, or keeping the other waves in step with dummy loads, cost 1 - 2.5 us).  Only
+    // the waves with a forward transform load, and only their frames.
+    const bool fwd = active && h0 == 0;
+    if (fwd) {
         block_forward(io, t, v, lds, tab, lane);
         OHS_DBG_STAMP(10);
-        // with one partition everywhere nothing ever reads the ring: a path only sees blocks processed since its
-        // own last set_ir (the `since` gate), and growing a path's partition count IS a set_ir
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zt[r * 64 + lane] = v[r];
+        // with one partition everywhere nothing ever reads the ring: a path only sees blocks processed since
+        // its own last set_ir (the `since` gate), and growing a path's partition count IS a set_ir
         if (maxP > 1) block_store_history(A, hist, t, v, lane);
+    }
+    if constexpr (!RESIDENT) {
+        // the engine's stored overlaps (block 0 adds them) into LDS, two rows per wave, so that the output stage
+        // finds every block's predecessor in LDS
+        const int tr = 2 * wave;                    // n_waves == 8: 16 rows
+        const float2 told0 = A.tails[tr * 64 + lane], told1 = A.tails[(tr + 1) * 64 + lane];
+        tails_lds[tr * 64 + lane] = told0;
+        tails_lds[(tr + 1) * 64 + lane] = told1;
     }
     __threadfence_block();      // the ring slots written above are read by the other waves' partitions
     __syncthreads();            // (also: every input frame has been read before step 3 rewrites the FIFO)
-    const float scale = 1.0f / (float)kFft;   // convolution.rs:280
     OHS_DBG_STAMP(11);
     if (active) {
-        block_mac(A, hist, t, maxP, v, acc1, acc2, lane);
-        OHS_DBG_STAMP(12);
-        wave_fft_inv(acc1, lds, tab, lane);   // re = lsl, im = lsr   (:276)
-        wave_fft_inv(acc2, lds, tab, lane);   // re = rsl, im = rsr
-        OHS_DBG_STAMP(13);
-        // this block's overlaps (upper halves) into its own slab, for the next block's wave
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            lds[a * 64 + lane] = make_float2(acc1[a + 8].x * scale, acc1[a + 8].y * scale);
-            lds[(8 + a) * 64 + lane] = make_float2(acc2[a + 8].x * scale, acc2[a + 8].y * scale);
+        for (int r = 0; r < 16; ++r) v[r] = zt[r * 64 + lane];
+        for (int h = h0; h < h1; ++h) {
+            block_mac_half<RESIDENT>(A, hist, hl, t, maxP, h, v, acc, lane);
+            OHS_DBG_STAMP(12);
+            wave_fft_inv(acc, lds, tab, lane);      // re = lsl | rsl, im = lsr | rsr   (:276)
+            OHS_DBG_STAMP(13);
+            float2 *park = (h == h1 - 1) ? lds : zt;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                park[a * 64 + lane] = make_float2(acc[a + 8].x * scale, acc[a + 8].y * scale);
+                park[(8 + a) * 64 + lane] = acc[a];
+            }
         }
     }
     __syncthreads();
     if (active) {
         // overlap-add per path, then ear sums (:279-284, :228-231); gain on the popped frames only
-        const float2 *prev = t ? slabs + (wave - 1) * kWaveLdsComplex : A.tails;
+        const float2 *lo1 = parked(t, 0) + 512, *lo2 = parked(t, 1) + 512;
+        const float2 *pv1 = t ? parked(t - 1, 0) : tails_lds, *pv2 = t ? parked(t - 1, 1) : tails_lds + 512;
+        for (int ab = a0; ab < (split ? a0 + 4 : 8); ab += 4) {
+            float2 l1[4], l2[4], t1[4], t2[4];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const float2 t1 = prev[a * 64 + lane], t2 = prev[(8 + a) * 64 + lane];
-            const float lsl = fmaf(acc1[a].x, scale, t1.x), lsr = fmaf(acc1[a].y, scale, t1.y);
-            const float rsl = fmaf(acc2[a].x, scale, t2.x), rsr = fmaf(acc2[a].y, scale, t2.y);
-            io.store((size_t)t * kBlock + 64 * a + lane, lsl + rsl, lsr + rsr);
+            for (int k = 0; k < 4; ++k) {
+                const int a = ab + k;
+                l1[k] = lo1[a * 64 + lane]; l2[k] = lo2[a * 64 + lane];
+                t1[k] = pv1[a * 64 + lane]; t2[k] = pv2[a * 64 + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lsl = fmaf(l1[k].x, scale, t1[k].x), lsr = fmaf(l1[k].y, scale, t1[k].y);
+                const float rsl = fmaf(l2[k].x, scale, t2[k].x), rsr = fmaf(l2[k].y, scale, t2[k].y);
+                io.store((size_t)t * kBlock + 64 * (ab + k) + lane, lsl + rsl, lsr + rsr);
+            }
         }
     }
     OHS_DBG_STAMP(14);
     __syncthreads();            // tails_out may alias tails: block 0 has read the old state by now
     if (active && t == A.n_blocks - 1) {
+        for (int h = h0; h < h1; ++h) {
+            const float2 *park = parked(t, h);
 #pragma unroll
-        for (int a = 0; a < 16; ++a) A.tails_out[a * 64 + lane] = lds[a * 64 + lane];
+            for (int a = 0; a < 8; ++a) {
+                const float2 u = park[a * 64 + lane];
+                A.tails_out[(8 * h + a) * 64 + lane] = u;
+                if constexpr (RESIDENT) tails_lds[(8 * h + a) * 64 + lane] = u;     // the next call's block 0 reads it here
+            }
+        }
     }
     // 3. what is left of the input (< 512 frames) becomes the FIFO content for the next call
     if (wave == n_waves - 1) {
@@ -389,7 +501,9 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
     float2 *tab = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     fill_twiddle_tables(tab, A.tw, threadIdx.x, blockDim.x);
-    engine_call_body<false>(A, E, tab, smem + kTabComplex, wave, lane, n_waves);   // its first barrier also covers the table fill
+    float2 *slabs = smem + kTabComplex;
+    float2 *zx = slabs + n_waves * kWaveLdsComplex;
+    engine_call_body<false, false>(A, E, tab, slabs, zx, zx + n_waves * kFft, wave, lane, n_waves);   // its first barrier also covers the table fill
 }
 
 // RESIDENT form ("persistent kernels + pinned-memory mailboxes"): one workgroup of 8
@@ -412,12 +526,24 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
 // more than the 256 VGPRs two waves per SIMD leave and spilled 350 bytes per lane into the path where every
 // microsecond counts (a 1024-frame call without EQ went from 16 to 26 us); as a call it has its own allocation.
 // (The body itself stays inlined: out of line it saves and restores ~100 callee-saved registers per call.)
+template <class T>
+__device__ __forceinline__ void uniform_copy(T &dst, const T &src_lds)
+{
+    static_assert(sizeof(T) % 4 == 0, "word copy");
+    const unsigned *s = reinterpret_cast<const unsigned *>(&src_lds);
+    unsigned w[sizeof(T) / 4];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)s[i]);
+    __builtin_memcpy(&dst, w, sizeof(T));
+}
+
 __device__ __attribute__((noinline)) void rt_eq_call(float *buf, long long stride, long long n, int nb,
                                                      const EqPassTable *tab, float *state)
 {
     eq_ring_wave(buf, buf, 0, stride, n, 2, nb, *tab, state, 0);
 }
 
+static_assert(kTabComplex + 8 * kWaveLdsComplex + (kResidentMaxBlocks + 1 + 4) * kFft <= kEngineLdsBytes / sizeof(float2), "LDS plan");
 __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const float2 *tw, unsigned first_seq,
                                                          unsigned long long idle_limit, unsigned sleep_arg)
 {
@@ -442,6 +568,14 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     ConvGeneralArgs &A = *reinterpret_cast<ConvGeneralArgs *>(s_args);
     EngineCallArgs &E = *reinterpret_cast<EngineCallArgs *>(reinterpret_cast<char *>(s_args) + sizeof(ConvGeneralArgs));
     if (threadIdx.x == 0) s_eq_version = 0xffffffffu;       // no EQ block held yet (the host counts from 1)
+    // what the kernel keeps in LDS for as long as it lives (anything that changes it on the host side -- set_ir, a
+    // launch-per-call block, clone -- stops the kernel first): the engine's overlaps and partition 0 of every path
+    float2 *zx = slabs + 8 * kWaveLdsComplex;
+    float2 *cache = zx + kResidentMaxBlocks * kFft;
+    for (int i = threadIdx.x; i < kFft; i += 512) cache[i] = A.tails[i];
+    for (int p = 0; p < 4; ++p)
+        for (int i = threadIdx.x; i < kFft; i += 512) cache[kFft + p * kFft + i] = A.H[p][i];
+    __syncthreads();
     const float *const host_src_l = E.src_l, *const host_src_r = E.src_r;
     unsigned last = first_seq;              // the doorbell value already served
     for (;;) {
@@ -527,14 +661,22 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
                 E.src_l = eqb2->eq_buf; E.src_r = eqb2->eq_buf + eqb2->eq_buf_stride;
             } else { E.src_l = host_src_l; E.src_r = host_src_r; }
             const int n = s_n;
-            const int k = (E.in_len + n) / kBlock;
+            const int k = (E.in_len + n) / kBlock;  // <= kResidentMaxBlocks: the host routes longer calls elsewhere
             A.n_blocks = k;
             E.n = n;
             E.emit = (E.out_len + k * kBlock >= n) ? 1 : 0;
             E.gain_pop = s_gain;
         }
         __syncthreads();
-        engine_call_body<false>(A, E, tab, slabs, wave, lane, 8, mb->stamps);
+        {
+            // the call's descriptors out of LDS into SGPRs (they are uniform, but values read from LDS live in
+            // VGPRs, two per pointer, and the body has none to spare)
+            ConvGeneralArgs Ar;
+            EngineCallArgs Er;
+            uniform_copy(Ar, A);
+            uniform_copy(Er, E);
+            engine_call_body<false, true>(Ar, Er, tab, slabs, zx, cache, wave, lane, 8, mb->stamps);
+        }
         if (threadIdx.x == 0) st2 = __builtin_amdgcn_s_memrealtime();
         // publish: every wave's stores (outputs to host memory, state to device memory) drained, then one
         // system-scope release in front of the flag.  (Tried: system-scope `sc0 sc1` loads / stores for the
@@ -571,7 +713,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
 hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned first_seq, unsigned long long idle_limit,
                                   unsigned sleep_arg, hipStream_t st)
 {
-    const size_t shmem = (kTabComplex + 8 * (size_t)kWaveLdsComplex) * sizeof(float2);   // 77 KiB
+    const size_t shmem = kEngineLdsBytes;
     static std::atomic<unsigned long long> lds_ok{0};
     const hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_engine_resident), shmem, lds_ok);
     if (e != hipSuccess) return e;
@@ -589,13 +731,11 @@ hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStrea
 hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st)
 {
     if (a.n_blocks < 0 || a.n_blocks > 8) return hipErrorInvalidValue;
-    const int waves = a.n_blocks > 0 ? a.n_blocks : 1;
-    const size_t shmem = (kTabComplex + (size_t)waves * kWaveLdsComplex) * sizeof(float2);   // <= 85 KiB
+    // always the full workgroup: up to 4 blocks get a pair of waves each
     static std::atomic<unsigned long long> lds_ok{0};
-    const hipError_t e2 = allow_large_lds(reinterpret_cast<const void *>(k_engine_call),
-                                          (kTabComplex + 8 * kWaveLdsComplex) * sizeof(float2), lds_ok);
+    const hipError_t e2 = allow_large_lds(reinterpret_cast<const void *>(k_engine_call), kEngineLdsBytes, lds_ok);
     if (e2 != hipSuccess) return e2;
-    hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(64 * waves), shmem, st, a, e);
+    hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(512), kEngineLdsBytes, st, a, e);
     return hipGetLastError();
 }
 

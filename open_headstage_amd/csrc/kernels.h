@@ -88,6 +88,7 @@ struct RtMailbox {
     long long eq_buf_stride;
     EqPassTable eq_tab;
 };
+constexpr int kResidentMaxBlocks = 4;     // 512-blocks per call the resident kernel serves (host blocks of up to 2048 frames and a FIFO remainder)
 hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned first_seq, unsigned long long idle_limit,
                                   unsigned sleep_arg, hipStream_t st);
 

@@ -870,7 +870,8 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     // real-time sized calls: the resident kernel's mailbox (real-time mode, no EQ in the chain) or everything in
     // one launch; long offline calls: the multi-kernel path below
     const bool rt_sized = (e->in.len + n) / BS <= 8 && n <= 8192 && e->in.len < (size_t)BS;
-    if (rt_sized && e->rt_enabled) {
+    // (the resident kernel gives every block of a call a pair of waves: up to kResidentMaxBlocks blocks)
+    if (rt_sized && e->rt_enabled && (e->in.len + n) / BS <= (size_t)kResidentMaxBlocks) {
         // the resident kernel serves the call unless the chain's EQ needs more than the ring form's 12 bands
         if (!eq) return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0);
         EqPassTable t;
