@@ -41,7 +41,6 @@ def _units():
         ("conv_mac_kernels.hip", [f"-DOHS_MAC_TB={os.environ.get('OHS_MAC_TB', '16')}",
                                   f"-DOHS_MAC_PI={os.environ.get('OHS_MAC_PI', '16')}"]),
         ("eq_kernels.hip", ["-ffp-contract=off"]),
-        ("rt_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),   # persistent real-time adapter
         ("ohs_api.hip", []),
         ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
         ("sofa_conditioning.cpp", ["-x", "hip"]),   # host-only C++ (libmysofa-style loudness / interpolation)
@@ -80,7 +79,7 @@ def _unit_hash(src: str, extra: list[str]) -> str:
 
 
 def _current_hashes() -> dict:
-    return {src: _unit_hash(src, extra) for src, extra in _units() if os.path.exists(os.path.join(CSRC, src))}
+    return {src: _unit_hash(src, extra) for src, extra in _units()}
 
 
 def _read_stamp() -> dict:
@@ -97,7 +96,10 @@ def is_current() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    units = [(s, e) for s, e in _units() if os.path.exists(os.path.join(CSRC, s))]
+    units = _units()
+    missing = [s for s, _ in units if not os.path.exists(os.path.join(CSRC, s))]
+    if missing:
+        raise RuntimeError(f"source files missing under {CSRC}: {missing}")
     want = _current_hashes()
     have = _read_stamp()
     if not force and os.path.exists(LIB) and have == want:
