@@ -251,7 +251,7 @@ int  ohs_batch_process_deferred(ohs_batch *b, const float *d_in, float *d_out, s
                                 size_t stream_stride, size_t channel_stride, void *hip_stream);
 int  ohs_batch_join(ohs_batch *b, void *hip_stream);
 /* The same processing with HOST buffers (same planar layout and strides, host pointers): the frames are cut
- * into time chunks of `chunk_blocks` blocks (0 = library default, ~96 MiB per direction) and copy-in of
+ * into time chunks of `chunk_blocks` blocks (0 = library default, ~32 MiB per direction) and copy-in of
  * chunk i + 1, the kernels of chunk i and copy-out of chunk i - 1 run concurrently on three internal
  * streams.  Blocking: h_out is complete on return.  h_in may equal h_out.  Pinned (page-locked) host memory
  * is needed for the copies to overlap at link speed; pageable memory works but serialises.  Results are

@@ -1649,17 +1649,29 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
         return fail(OHS_ERR_INVALID_ARG, "strides smaller than the processed region");
     HIP_TRY(hipSetDevice(b->device));
     if (chunk_blocks == 0) {
-        // default: ~96 MiB per chunk and direction (2.4 ms of link time at 40 GB/s), at least 64 blocks so that the
-        // EQ / convolution overlap inside ohs_batch_process stays on, at most the whole call
+        // default: ~32 MiB per chunk and direction (0.7 ms of link time; 16 ... 64 MiB measure alike, smaller chunks pay
+        // per-copy overhead, larger ones a longer fill and drain), at most an eighth of the call so that small batches
+        // pipeline too, at least 16 blocks
         const size_t per_block = S * 2 * BS * sizeof(float);
-        chunk_blocks = std::max<size_t>(64, ((size_t)96 << 20) / per_block);
+        chunk_blocks = ((size_t)32 << 20) / per_block;
+        chunk_blocks = std::min(chunk_blocks, std::max<size_t>(n_blocks / 8, 1));
+        chunk_blocks = std::max<size_t>(chunk_blocks, 16);
     }
     chunk_blocks = std::min(chunk_blocks, n_blocks);
     const size_t cf = chunk_blocks * BS;
     if (!b->st_h2d) {
-        HIP_TRY(hipStreamCreateWithFlags(&b->st_h2d, hipStreamNonBlocking));
+        // The runtime multiplexes streams onto a few hardware queues per PRIORITY level (4 by default,
+        // GPU_MAX_HW_QUEUES), and a stream that shares its queue with a copy stream waits behind every chunk
+        // copy: with plain streams the convolution launches of chunk i + 1 sat behind the copy-out of chunk i
+        // (rocprofv3 --memory-copy-trace: 2.6 ms per chunk instead of 2.1).  The two copy streams therefore get
+        // priority levels of their own, where nothing else of this process lives.
+        int pr_least = 0, pr_greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        const char *flat = getenv("OHS_HOST_PIPE_FLAT_PRIORITIES");      // experiment: the old behaviour
+        if (flat && flat[0] == '1') pr_least = pr_greatest = 0;
+        HIP_TRY(hipStreamCreateWithPriority(&b->st_h2d, hipStreamNonBlocking, pr_greatest));
         HIP_TRY(hipStreamCreateWithFlags(&b->st_comp, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&b->st_d2h, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&b->st_d2h, hipStreamNonBlocking, pr_least != 0 ? pr_least : pr_greatest));
         for (int k = 0; k < ohs_batch::kHostSlots; ++k) {
             HIP_TRY(hipEventCreateWithFlags(&b->ev_h2d[k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&b->ev_comp[k], hipEventDisableTiming));

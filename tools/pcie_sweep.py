@@ -11,7 +11,7 @@ for i, b in enumerate(synth.eq_table()): bp.update_band_coeffs(i, synth.FS, b)
 bp.set_eq_enabled(True)
 hx = synth.white_noise_torch(0, S, frames, torch.device("cuda:0")).cpu().pin_memory()
 hy = torch.empty_like(hx).pin_memory()
-for cb in (24, 48, 96, 192, 320, 938):
+for cb in [int(v) for v in os.environ.get("OHS_SWEEP", "24,48,96,192,320,938").split(",")]:
     bp.process_host(hx, out=hy, chunk_blocks=cb)
     t0 = time.perf_counter()
     for _ in range(3): bp.process_host(hx, out=hy, chunk_blocks=cb)
