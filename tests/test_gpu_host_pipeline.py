@@ -40,7 +40,8 @@ def test_host_pipeline_matches_chunked_device_calls_bit_for_bit(S, n_blocks, chu
     bp2, _, _ = _make(S, taps)
     xd = torch.from_numpy(x).cuda()
     yd = torch.empty_like(xd)
-    cb = chunk if chunk else max(64, (96 << 20) // (S * 2 * 512 * 4))
+    # (chunk 0 = the library's default rule: ~32 MiB per direction, at most an eighth of the call, at least 16 blocks)
+    cb = chunk if chunk else max(16, min((32 << 20) // (S * 2 * 512 * 4), max(n_blocks // 8, 1)))
     cb = min(cb, n_blocks)
     for b0 in range(0, n_blocks, cb):
         nb = min(cb, n_blocks - b0)
