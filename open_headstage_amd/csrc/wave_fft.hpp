@@ -247,14 +247,16 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
     dft16<false, ZPAD>(v);                                  // over a -> p
 #pragma unroll
     for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], OHS_TW_LD(&tab[kTabA + t1_index(p, lane)]));
+    const int pp = lane >> 2, c = lane & 3;
+    const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
+#ifndef OHS_KO_T1       // timing experiment (wrong results): the transform without its T1 exchanges
 #pragma unroll
     for (int p = 0; p < 16; ++p) lds_st(&lds[t1_index(p, lane)], v[p]);  // T1
     wave_lds_sync();
-    const int pp = lane >> 2, c = lane & 3;
-    const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
 #pragma unroll
     for (int b = 0; b < 16; ++b) v[b] = lds_ld(&lds[t1r + 4 * b]);
     wave_lds_sync();
+#endif
     dft16<false>(v);                                        // over b -> q
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], OHS_TW_LD(&tab[kTabB + 4 * q + (lane & 3)]));
@@ -350,12 +352,14 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
 #pragma unroll
     for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], OHS_TW_LD(&tab[kTabA + t1r + 4 * b]));   // w1024^((4b+c) p), conj
+#ifndef OHS_KO_T1
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds_st(&lds[t1r + 4 * b], v[b]);    // T1'
     wave_lds_sync();
 #pragma unroll
     for (int p = 0; p < 16; ++p) v[p] = lds_ld(&lds[t1_index(p, lane)]);
     wave_lds_sync();
+#endif
     dft16<true>(v);                                         // over p -> a
 }
 
