@@ -393,6 +393,27 @@ def main() -> int:
 
     # ---- extras, N = 1 only, after the timed region ----
     if world == 1 and not args.no_extras and not strong:
+        # PCIe-inclusive: the same step from / to pinned host memory, H2D || kernels || D2H over time chunks
+        S = args.streams
+        try:
+            hx = synth.white_noise_torch(0, S, frames, device).cpu().pin_memory()
+            hy = torch.empty_like(hx).pin_memory()
+            bp.reset()
+            bp.process_host(hx, out=hy)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                bp.process_host(hx, out=hy)
+            dt = (time.perf_counter() - t0) / 2
+            out["pcie_inclusive"] = {"ms_per_step": round(dt * 1e3, 3),
+                                     "Msamples_s": round(S * frames / dt / 1e6, 1),
+                                     "GBps_each_way": round(S * frames * 8 / dt / 1e9, 2),
+                                     "how": "ohs_batch_process_host, pinned host buffers, 3 streams / 3 slots"}
+            del hx, hy
+        except Exception as e:      # noqa: BLE001 -- never let an extra break the contract line
+            out["pcie_inclusive"] = {"error": str(e)[:200]}
+        # (The PCIe leg runs first: on this platform every hipFree in the process re-rolls the rate of two-way host
+        # copies -- plain hipMemcpyAsync pairs measured 29 ... 49 GB/s each way after frees of various sizes,
+        # tools/pcie_state_exp3.py -- and empty_cache() below is such a free.)
         del x, y
         torch.cuda.empty_cache()
         sat = []
@@ -415,24 +436,6 @@ def main() -> int:
             del bp2, x2, y2
             torch.cuda.empty_cache()
         out["saturation"] = sat
-        # PCIe-inclusive: the same step from / to pinned host memory, H2D || kernels || D2H over time chunks
-        S = args.streams
-        try:
-            hx = synth.white_noise_torch(0, S, frames, device).cpu().pin_memory()
-            hy = torch.empty_like(hx).pin_memory()
-            bp.reset()
-            bp.process_host(hx, out=hy)
-            t0 = time.perf_counter()
-            for _ in range(2):
-                bp.process_host(hx, out=hy)
-            dt = (time.perf_counter() - t0) / 2
-            out["pcie_inclusive"] = {"ms_per_step": round(dt * 1e3, 3),
-                                     "Msamples_s": round(S * frames / dt / 1e6, 1),
-                                     "GBps_each_way": round(S * frames * 8 / dt / 1e9, 2),
-                                     "how": "ohs_batch_process_host, pinned host buffers, 3 streams / 3 slots"}
-            del hx, hy
-        except Exception as e:      # noqa: BLE001 -- never let an extra break the contract line
-            out["pcie_inclusive"] = {"error": str(e)[:200]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)

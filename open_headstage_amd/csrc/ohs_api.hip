@@ -1669,8 +1669,10 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
         HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
         const char *flat = getenv("OHS_HOST_PIPE_FLAT_PRIORITIES");      // experiment: the old behaviour
         if (flat && flat[0] == '1') pr_least = pr_greatest = 0;
+        // (the pipeline's compute stream too: which normal-priority stream it would share a queue with depends on how
+        // many streams the process has created before -- bench.py measured 21.7 or 25.6 ms depending on its step count)
         HIP_TRY(hipStreamCreateWithPriority(&b->st_h2d, hipStreamNonBlocking, pr_greatest));
-        HIP_TRY(hipStreamCreateWithFlags(&b->st_comp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&b->st_comp, hipStreamNonBlocking, pr_greatest));
         HIP_TRY(hipStreamCreateWithPriority(&b->st_d2h, hipStreamNonBlocking, pr_least != 0 ? pr_least : pr_greatest));
         for (int k = 0; k < ohs_batch::kHostSlots; ++k) {
             HIP_TRY(hipEventCreateWithFlags(&b->ev_h2d[k], hipEventDisableTiming));
@@ -1713,27 +1715,56 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
     };
     const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
     int rc = OHS_OK;
+    // OHS_HOST_PIPE_TRACE=1: device timestamps around every stage of every chunk, printed after the call
+    // (diagnostic; it adds six event records per chunk)
+    static const bool trace = [] { const char *v = getenv("OHS_HOST_PIPE_TRACE"); return v && v[0] == '1'; }();
+    std::vector<hipEvent_t> tev;
+    auto mark = [&](hipStream_t st) {
+        if (!trace) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) == hipSuccess) { hipEventRecord(e, st); tev.push_back(e); }
+    };
+    const auto host_t0 = std::chrono::steady_clock::now();
+    std::vector<double> host_ms;
     for (size_t i = 0; i < n_chunks && rc == OHS_OK; ++i) {
         const int k = (int)(i % ohs_batch::kHostSlots);
         const size_t blk0 = i * chunk_blocks, nb = std::min(chunk_blocks, n_blocks - blk0);
         const size_t off = blk0 * BS, nf = nb * BS;
         if (i >= (size_t)ohs_batch::kHostSlots) HIP_TRY(hipStreamWaitEvent(b->st_h2d, b->ev_d2h[k], 0));   // slot free again
+        mark(b->st_h2d);
         rc = copy(true, b->d_slot[k], off, nf, b->st_h2d);
         if (rc) break;
+        mark(b->st_h2d);
         HIP_TRY(hipEventRecord(b->ev_h2d[k], b->st_h2d));
         HIP_TRY(hipStreamWaitEvent(b->st_comp, b->ev_h2d[k], 0));
+        mark(b->st_comp);
         rc = batch_process_impl(b, b->d_slot[k], b->d_slot[k], nb, 2 * b->slot_frames, b->slot_frames, b->st_comp, false);
         if (rc) break;
+        mark(b->st_comp);
         HIP_TRY(hipEventRecord(b->ev_comp[k], b->st_comp));
         HIP_TRY(hipStreamWaitEvent(b->st_d2h, b->ev_comp[k], 0));
+        mark(b->st_d2h);
         rc = copy(false, b->d_slot[k], off, nf, b->st_d2h);
         if (rc) break;
+        mark(b->st_d2h);
         HIP_TRY(hipEventRecord(b->ev_d2h[k], b->st_d2h));
+        if (trace) host_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
     }
     // blocking call: the outputs are complete on return (also on a failure half-way: nothing may still be
     // writing into the caller's buffers)
     const hipError_t e1 = hipStreamSynchronize(b->st_h2d), e2 = hipStreamSynchronize(b->st_comp),
                      e3 = hipStreamSynchronize(b->st_d2h);
+    if (trace && !tev.empty()) {
+        fprintf(stderr, "[ohs host pipeline] %zu chunks of %zu blocks; per chunk [ms since the first copy began]: "
+                        "h2d begin-end | kernels begin-end | d2h begin-end | host enqueued at\n", n_chunks, chunk_blocks);
+        for (size_t i = 0; i + 5 < tev.size(); i += 6) {
+            float t[6];
+            for (int j = 0; j < 6; ++j) if (hipEventElapsedTime(&t[j], tev[0], tev[i + j]) != hipSuccess) t[j] = -1.f;
+            fprintf(stderr, "  %2zu: %6.2f-%6.2f | %6.2f-%6.2f | %6.2f-%6.2f | %6.2f\n", i / 6, t[0], t[1], t[2], t[3], t[4], t[5],
+                    i / 6 < host_ms.size() ? host_ms[i / 6] : -1.0);
+        }
+        for (hipEvent_t e : tev) hipEventDestroy(e);
+    }
     if (rc) return rc;
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(OHS_ERR_HIP, "host pipeline: stream sync failed");
     return OHS_OK;

@@ -12,7 +12,12 @@ export TMPDIR=/tmp
 python3 bench.py --steps 10 --warmup 3 > "$out/bench.json" 2> "$out/bench.err"
 echo "bench done"; cat "$out/bench.json"
 python3 tools/bench_configs.py > "$out/other_configs.jsonl" 2> "$out/other_configs.err"
-timeout -k 10 120 tools/bin/rt_latency >> "$out/other_configs.jsonl" 2>> "$out/other_configs.err" || true
+# native latency harness: the JSON lines join the other configs, the whole output (with the device-side phases) is kept too
+timeout -k 10 120 tools/bin/rt_latency > "$out/rt_latency.txt" 2>> "$out/other_configs.err" || true
+grep -v '^#' "$out/rt_latency.txt" >> "$out/other_configs.jsonl" || true
+# micro-benchmarks the design decisions quote
+timeout -k 10 120 tools/bin/ubench_lds > "$out/ubench_lds.txt" 2>&1 || true
+timeout -k 10 120 tools/bin/ubench_pcie > "$out/ubench_pcie.txt" 2>&1 || true
 echo "other configs done"
 cd /tmp
 prof() {   # prof <name> <rocprofv3 args...> -- <program...>

@@ -71,6 +71,14 @@ int main()
             snprintf(name, sizeof name, "copy kernel 2-D %3d x %4d  both", wgs, thr); time_it(name, k_h2d, k_d2h, true, true);
         }
     }
+    // mixed: one direction on an SDMA engine, the other by a copy kernel
+    for (int wgs : {32, 64, 128, 256}) {
+        auto k_h2d = [&] { hipLaunchKernelGGL(k_copy2d, dim3(wgs), dim3(256), 0, s1, dh_in, pitch_full, d_a, row_bytes, row_bytes, rows); };
+        auto k_d2h = [&] { hipLaunchKernelGGL(k_copy2d, dim3(wgs), dim3(256), 0, s2, d_b, row_bytes, dh_out, pitch_full, row_bytes, rows); };
+        char name[96];
+        snprintf(name, sizeof name, "SDMA H2D + copy kernel D2H %3d x 256", wgs); time_it(name, sdma2_h2d, k_d2h, true, true);
+        snprintf(name, sizeof name, "copy kernel H2D %3d x 256 + SDMA D2H", wgs); time_it(name, k_h2d, sdma2_d2h, true, true);
+    }
     // verify one kernel copy
     CK(hipMemset(d_a, 0, bytes));
     hipLaunchKernelGGL(k_copy2d, dim3(64), dim3(256), 0, s1, dh_in, pitch_full, d_a, row_bytes, row_bytes, rows);
