@@ -543,6 +543,7 @@ __device__ __attribute__((noinline)) void rt_eq_call(float *buf, long long strid
     eq_ring_wave(buf, buf, 0, stride, n, 2, nb, *tab, state, 0);
 }
 
+constexpr unsigned kRtPollBurst = 32;     // pairs of polls per asm statement of the resident kernel's doorbell loop
 static_assert(kTabComplex + 8 * kWaveLdsComplex + (kResidentMaxBlocks + 1 + 4) * kFft <= kEngineLdsBytes / sizeof(float2), "LDS plan");
 __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const float2 *tw, unsigned first_seq,
                                                          unsigned long long idle_limit, unsigned sleep_arg)
@@ -583,11 +584,60 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             unsigned cmd = 0;
             unsigned long long idle = 0;
             for (;;) {
-                // {seq, n, gain, stop}: one aligned 16-byte read, so the arguments arrive with their doorbell
+                // {seq, n, gain, stop}: one aligned 16-byte read, so the arguments arrive with their doorbell.
+                // TWO reads are kept in flight (a new one is issued while the older one is awaited), so the word is
+                // sampled every half PCIe round trip instead of once per round trip: ~0.3 us less from the host's
+                // store to the kernel's start.  One asm statement, because a register that is the destination of a
+                // load in flight must not be touched by compiler-generated moves; it leaves after kRtPollBurst
+                // polls at the latest (idle accounting and the sleep are done outside).
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 u32x4 w;
-                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                             : "=v"(w) : "v"(&mb->call_word[0]) : "memory");      // system scope: never served by a cache
+                unsigned sx, sw, budget = kRtPollBurst;
+                const unsigned last_s = (unsigned)__builtin_amdgcn_readfirstlane((int)last);
+                // (the two destinations are fixed registers, v[8:11] and v[12:15]: inline asm cannot name the
+                // components of a 128-bit operand)
+                asm volatile(
+                    "global_load_dwordx4 v[8:11], %[p], off sc0 sc1\n"
+                    "1:\n\t"
+                    "global_load_dwordx4 v[12:15], %[p], off sc0 sc1\n\t"
+                    "s_waitcnt vmcnt(1)\n\t"
+                    "v_readfirstlane_b32 %[sx], v8\n\t"
+                    "v_readfirstlane_b32 %[sw], v11\n\t"
+                    "s_nop 3\n\t"
+                    "s_cmp_lg_u32 %[sx], %[last]\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "s_cmp_lg_u32 %[sw], 0\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "global_load_dwordx4 v[8:11], %[p], off sc0 sc1\n\t"
+                    "s_waitcnt vmcnt(1)\n\t"
+                    "v_readfirstlane_b32 %[sx], v12\n\t"
+                    "v_readfirstlane_b32 %[sw], v15\n\t"
+                    "s_nop 3\n\t"
+                    "s_cmp_lg_u32 %[sx], %[last]\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_cmp_lg_u32 %[sw], 0\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_sub_u32 %[n], %[n], 1\n\t"
+                    "s_cmp_lg_u32 %[n], 0\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "s_waitcnt vmcnt(0)\n\t"          // budget spent: the younger read (v[8:11]) is complete now
+                    "s_branch 2f\n"
+                    "3:\n\t"                          // hit in v[12:15]: drain the other read, hand the hit over
+                    "s_waitcnt vmcnt(0)\n\t"
+                    "v_mov_b32 v8, v12\n\t"
+                    "v_mov_b32 v9, v13\n\t"
+                    "v_mov_b32 v10, v14\n\t"
+                    "v_mov_b32 v11, v15\n"
+                    "2:\n\t"                          // result in v[8:11]; nothing may stay in flight
+                    "s_waitcnt vmcnt(0)\n\t"
+                    "v_mov_b32 %[w0], v8\n\t"
+                    "v_mov_b32 %[w1], v9\n\t"
+                    "v_mov_b32 %[w2], v10\n\t"
+                    "v_mov_b32 %[w3], v11\n"
+                    : [w0] "=&v"(w.x), [w1] "=&v"(w.y), [w2] "=&v"(w.z), [w3] "=&v"(w.w), [sx] "=&s"(sx), [sw] "=&s"(sw),
+                      [n] "+s"(budget)
+                    : [p] "v"(&mb->call_word[0]), [last] "s"(last_s)
+                    : "memory", "scc", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
                 if (w.w) break;                                         // stop
                 if (w.x != last) {
                     last = w.x; cmd = 1;
@@ -596,7 +646,8 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
                     s_gain = __uint_as_float(w.z);
                     break;
                 }
-                if (++idle >= idle_limit) break;
+                idle += 2 * kRtPollBurst;
+                if (idle >= idle_limit) break;
                 for (unsigned k = 0; k < sleep_arg; ++k) __builtin_amdgcn_s_sleep(16);     // ~0.4 us each
             }
             s_cmd = cmd;

@@ -768,11 +768,11 @@ int rt_start(ohs_engine *e)
     std::atomic_thread_fence(std::memory_order_seq_cst);
     static const unsigned long long idle_limit = [] {
         const char *v = getenv("OHS_RT_IDLE_POLLS");        // polls without a doorbell before the kernel leaves (~2 s)
-        return v ? strtoull(v, nullptr, 10) : 1500000ull;
+        return v ? strtoull(v, nullptr, 10) : 3000000ull;      // two reads in flight: one poll per ~0.6 us
     }();
     static const unsigned sleep_arg = [] {
         const char *v = getenv("OHS_RT_POLL_SLEEP");
-        return v ? (unsigned)atoi(v) : 1u;
+        return v ? (unsigned)atoi(v) : 0u;      // no pause between poll bursts: 0.3 us less per call than one s_sleep(16)
     }();
     hipError_t err = launch_engine_resident(e->mb_dev, e->ctx->d_tw, e->rt_seq, idle_limit, sleep_arg, e->rt_st);
     if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(err));
