@@ -15,8 +15,11 @@ static void on_segv(int) { siglongjmp(jb, 1); }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // waits for *bell == seq (bell in device or host memory), copies n floats from src to dst, then writes seq to *done (host memory)
-__global__ void k_echo(volatile unsigned *bell, const float *src, float *dst, int n, volatile unsigned *done, int calls, volatile unsigned *stop)
+// (every call's frames carry the call number: a frame that still holds an older call's value was read stale)
+__global__ void k_echo(volatile unsigned *bell, const float *src, float *dst, int n, volatile unsigned *done, int calls, volatile unsigned *stop,
+                       unsigned *stale)
 {
+    unsigned my_stale = 0;
     for (unsigned seq = 1; seq <= (unsigned)calls; ++seq) {
         if (threadIdx.x == 0) {
             unsigned long long spins = 0;
@@ -27,7 +30,11 @@ __global__ void k_echo(volatile unsigned *bell, const float *src, float *dst, in
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         float acc = 0.f;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) acc += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v != (float)seq) ++my_stale;
+            acc += v;
+        }
         if (n) dst[threadIdx.x] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -35,24 +42,26 @@ __global__ void k_echo(volatile unsigned *bell, const float *src, float *dst, in
             __hip_atomic_store((unsigned *)done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    if (my_stale) atomicAdd(stale, my_stale);
 }
 
 static int run(const char *what, volatile unsigned *bell_host_view, unsigned *bell_dev, float *in_host_view, float *in_dev, int n)
 {
-    unsigned *done_h, *done_d, *stop_h, *stop_d; float *dst;
+    unsigned *done_h, *done_d, *stop_h, *stop_d, *stale_d; float *dst;
+    CK(hipMalloc((void **)&stale_d, 4)); CK(hipMemset(stale_d, 0, 4));
     CK(hipHostMalloc((void **)&done_h, 64, hipHostMallocMapped)); CK(hipHostGetDevicePointer((void **)&done_d, done_h, 0));
     CK(hipHostMalloc((void **)&stop_h, 64, hipHostMallocMapped)); CK(hipHostGetDevicePointer((void **)&stop_d, stop_h, 0));
     CK(hipMalloc((void **)&dst, 4096));
     *done_h = 0; *stop_h = 0; *bell_host_view = 0;
     const int calls = 3000;
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    hipLaunchKernelGGL(k_echo, dim3(1), dim3(512), 0, st, (volatile unsigned *)bell_dev, in_dev, dst, n, (volatile unsigned *)done_d, calls, (volatile unsigned *)stop_d);
+    hipLaunchKernelGGL(k_echo, dim3(1), dim3(512), 0, st, (volatile unsigned *)bell_dev, in_dev, dst, n, (volatile unsigned *)done_d, calls, (volatile unsigned *)stop_d, stale_d);
     double *t = (double *)malloc(sizeof(double) * calls);
     float *tmp = (float *)malloc(sizeof(float) * (n + 1));
-    for (int i = 0; i < n; ++i) tmp[i] = (float)i;
     int ok = 1;
     for (int c = 1; c <= calls && ok; ++c) {
         const double t0 = now_us();
+        for (int i = 0; i < n; ++i) tmp[i] = (float)c;
         if (n) memcpy(in_host_view, tmp, sizeof(float) * n);
         std::atomic_thread_fence(std::memory_order_release);
         *bell_host_view = (unsigned)c;
@@ -65,7 +74,10 @@ static int run(const char *what, volatile unsigned *bell_host_view, unsigned *be
     if (!ok) { printf("%-46s n=%5d: TIMEOUT\n", what, n); return 0; }
     // median
     for (int i = 0; i < calls; ++i) for (int j = i + 1; j < calls; ++j) if (t[j] < t[i]) { double x = t[i]; t[i] = t[j]; t[j] = x; }
-    printf("%-46s n=%5d floats: round trip median %.2f us, p99 %.2f, min %.2f\n", what, n, t[calls / 2], t[(int)(calls * 0.99)], t[0]);
+    unsigned stale = 0;
+    CK(hipMemcpy(&stale, stale_d, 4, hipMemcpyDeviceToHost));
+    printf("%-46s n=%5d floats: round trip median %.2f us, p99 %.2f, min %.2f; stale frames read: %u of %d\n", what, n, t[calls / 2],
+           t[(int)(calls * 0.99)], t[0], stale, n * calls);
     return 0;
 }
 
