@@ -264,7 +264,7 @@ int  ohs_batch_sync(ohs_batch *b, void *hip_stream);
  * its kernels with hipEvents on the caller's stream.  ohs_batch_profile_read waits for them,
  * returns the accumulated milliseconds per kernel, the number of ohs_batch_process calls and the
  * number of timed EQ / convolution launches since the last read, and clears the accumulators.
- * (With the EQ || convolution overlap a call issues 4 EQ launches and 4 convolution launches.) */
+ * (With the EQ || convolution overlap a call issues 6 EQ launches and 6 convolution launches.) */
 int  ohs_batch_set_profiling(ohs_batch *b, int enable);
 int  ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls,
                             uint64_t *eq_launches, uint64_t *conv_launches);

@@ -1535,10 +1535,12 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
     // The EQ is a serial recurrence (latency-bound, ~128 waves at 256 streams) and leaves most of the
     // chip idle, so the convolution of time chunk i runs on a second stream underneath the EQ of
     // chunk i+1.  Chunks touch disjoint frame ranges; state (EQ s1/s2, overlaps) chains per stream.
-    // Uneven chunks: only the LAST chunk's convolution is not hidden under an EQ launch, so it is short.
-    // OHS_OVERLAP_CUTS="0.3,0.6,0.9" overrides the interior cut points (tuning experiments).
+    // Uneven chunks: only the LAST chunk's convolution is not hidden under an EQ launch, so it is short
+    // (2 % of the frames; six chunks measure 6.00-6.02 ms per headline step, the four of {0.34, 0.66, 0.92} 6.05,
+    // seven 6.03-6.04: every extra EQ launch costs its ramp).
+    // OHS_OVERLAP_CUTS="0.3,0.6,0.9" overrides the interior cut points (tuning experiments, tools/ab_cuts.sh).
     static const std::vector<double> kCut = [] {
-        std::vector<double> c = {0.0, 0.34, 0.66, 0.92, 1.0};
+        std::vector<double> c = {0.0, 0.25, 0.5, 0.75, 0.92, 0.98, 1.0};
         if (const char *e = getenv("OHS_OVERLAP_CUTS")) {
             std::vector<double> v = {0.0};
             const char *p = e;
