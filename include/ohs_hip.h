@@ -93,11 +93,14 @@ int  ohs_engine_process_block(ohs_engine *e, const float *in_l, const float *in_
 int  ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out);
 /* Real-time mode (no reference counterpart -- the reference runs on the audio
  * thread's CPU).  enable != 0 starts a RESIDENT kernel (one workgroup) that serves ohs_engine_process_block --
- * and ohs_chain_process without EQ -- through a mailbox in pinned host memory: a call of n <= 8192 frames
- * launches nothing, allocates nothing and costs one doorbell round trip + one block's computation.  Results
- * are bit-identical to the launch-per-call path.  The kernel leaves the GPU when real-time mode is switched
- * off, on set_ir / clone / destroy / any call it cannot serve (it is restarted by the next call it can), and by
- * itself after ~2 s without a call.  Same threading rule as every handle: one thread at a time. */
+ * and ohs_chain_process with up to 12 enabled EQ bands -- through a mailbox in pinned host memory: a call that
+ * completes at most four 512-blocks (host blocks <= 2048 frames) launches nothing, allocates nothing and costs
+ * one doorbell round trip + one block's computation.  Results are bit-identical to the launch-per-call path,
+ * which serves every other call.  The kernel leaves the GPU when real-time mode is switched off, on set_ir /
+ * clone / destroy / any call it cannot serve (it is restarted by the next call it can), and by itself after
+ * ~2 s without a call.  It holds one CU while it lives: a device runs at most num_CUs / 4 of them
+ * (OHS_RT_MAX_RESIDENT), further engines in real-time mode are served launch per call until a slot frees up.
+ * Same threading rule as every handle: one thread at a time. */
 int  ohs_engine_set_realtime(ohs_engine *e, int enable);
 /* Delay the FIFO adapter of process_block adds for a constant host block size n (convolution.rs:163-181):
  * 0 when n is a multiple of 512; otherwise the frames answered with silence before the output FIFO can

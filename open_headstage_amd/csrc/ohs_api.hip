@@ -556,7 +556,7 @@ struct ohs_engine {
     size_t hcap = 0;
     uint64_t silent_frames = 0;                   // frames answered with the zero fill of convolution.rs:176-181
     // resident real-time kernel (ohs_engine_set_realtime): mailbox in pinned mapped memory, its own stream
-    bool rt_enabled = false, rt_running = false;
+    bool rt_enabled = false, rt_running = false, rt_slot = false;   // rt_slot: counted in the device's resident-kernel cap
     RtMailbox *mb = nullptr, *mb_dev = nullptr;
     hipStream_t rt_st = nullptr;
     unsigned rt_seq = 0;
@@ -722,12 +722,34 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
 }
 
 // ---- resident real-time kernel: host side of the mailbox protocol (k_engine_resident) --------------------
+// A resident kernel holds one CU (149 KiB of LDS) for as long as it lives, so their number per device is capped:
+// a quarter of the CUs by default (OHS_RT_MAX_RESIDENT).  Engines in real-time mode beyond the cap are served by
+// the launch-per-call path until a slot frees up -- same results, never a wait for a CU that is not coming.
+constexpr int kMaxDevices = 64;
+constexpr int OHS_RT_NO_SLOT = 1000;     // internal: rt_start found the device's cap reached (never crosses the C ABI)
+static std::atomic<int> g_rt_resident[kMaxDevices];
+static bool rt_slot_acquire(ohs_engine *e)
+{
+    if (e->rt_slot) return true;
+    static const int env_cap = [] { const char *v = getenv("OHS_RT_MAX_RESIDENT"); return v ? atoi(v) : -1; }();
+    const int cap = env_cap >= 0 ? env_cap : std::max(1, e->ctx->num_cus / 4);
+    std::atomic<int> &c = g_rt_resident[e->device % kMaxDevices];
+    if (c.fetch_add(1, std::memory_order_acq_rel) >= cap) { c.fetch_sub(1, std::memory_order_acq_rel); return false; }
+    e->rt_slot = true;
+    return true;
+}
+static void rt_mark_stopped(ohs_engine *e)
+{
+    e->rt_running = false;
+    if (e->rt_slot) { g_rt_resident[e->device % kMaxDevices].fetch_sub(1, std::memory_order_acq_rel); e->rt_slot = false; }
+}
+
 void rt_stop(ohs_engine *e)
 {
     if (!e->rt_running) return;
     __atomic_store_n(&e->mb->call_word[3], 1u, __ATOMIC_RELEASE);
     hipStreamSynchronize(e->rt_st);       // the kernel sees `stop` at its next poll (~1 us) and every wave leaves
-    e->rt_running = false;
+    rt_mark_stopped(e);
 }
 
 int rt_start(ohs_engine *e)
@@ -735,8 +757,9 @@ int rt_start(ohs_engine *e)
     if (e->rt_running) {
         if (__atomic_load_n(&e->mb->alive, __ATOMIC_ACQUIRE)) return OHS_OK;
         hipStreamSynchronize(e->rt_st);   // it left by its idle limit
-        e->rt_running = false;
+        rt_mark_stopped(e);
     }
+    if (!rt_slot_acquire(e)) return OHS_RT_NO_SLOT;
     if (!e->mb) {
         HIP_TRY(hipHostMalloc((void **)&e->mb, sizeof(RtMailbox), hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void **)&e->mb_dev, e->mb, 0));
@@ -775,7 +798,7 @@ int rt_start(ohs_engine *e)
         return v ? (unsigned)atoi(v) : 0u;      // no pause between poll bursts: 0.3 us less per call than one s_sleep(16)
     }();
     hipError_t err = launch_engine_resident(e->mb_dev, e->ctx->d_tw, e->rt_seq, idle_limit, sleep_arg, e->rt_st);
-    if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(err));
+    if (err != hipSuccess) { rt_mark_stopped(e); return fail(OHS_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(err)); }
     e->rt_running = true;
     return OHS_OK;
 }
@@ -830,7 +853,7 @@ int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r,
                 // the kernel left by its idle limit just as this call rang: start it again (from the state before
                 // this call -- the host's counters have not been advanced yet), it then serves `seq`
                 hipStreamSynchronize(e->rt_st);
-                e->rt_running = false;
+                e->rt_running = false;            // (the slot stays with this engine: it restarts at once)
                 --e->rt_seq;                      // rt_start arms the mailbox with the last SERVED sequence number
                 rc = rt_start(e);
                 if (rc) return rc;
@@ -872,13 +895,20 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     const bool rt_sized = (e->in.len + n) / BS <= 8 && n <= 8192 && e->in.len < (size_t)BS;
     // (the resident kernel gives every block of a call a pair of waves: up to kResidentMaxBlocks blocks)
     if (rt_sized && e->rt_enabled && (e->in.len + n) / BS <= (size_t)kResidentMaxBlocks) {
-        // the resident kernel serves the call unless the chain's EQ needs more than the ring form's 12 bands
-        if (!eq) return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0);
-        EqPassTable t;
-        const int nb_on = eq_single_pass_table(eq->eq, t);
-        if (nb_on == 0) return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0);
-        if (nb_on <= 12 && !eq->eq.exact_specials)
-            return engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, &eq->eq, &t, nb_on);
+        // the resident kernel serves the call unless the chain's EQ needs more than the ring form's 12 bands, or the
+        // device's cap of resident kernels is reached (OHS_RT_NO_SLOT: the launch-per-call path below serves it)
+        int rrc = OHS_RT_NO_SLOT;
+        bool tried = false;
+        if (!eq) { rrc = engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0); tried = true; }
+        else {
+            EqPassTable t;
+            const int nb_on = eq_single_pass_table(eq->eq, t);
+            if (nb_on == 0) { rrc = engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0); tried = true; }
+            else if (nb_on <= 12 && !eq->eq.exact_specials) {
+                rrc = engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, &eq->eq, &t, nb_on); tried = true;
+            }
+        }
+        if (tried && rrc != OHS_RT_NO_SLOT) return rrc;
     }
     rt_stop(e);         // the paths below launch kernels on the engine's state
     if (rt_sized) return engine_process_single_launch(e, in_l, in_r, out_l, out_r, n, eq, gain);
@@ -1017,6 +1047,7 @@ void ohs_engine_destroy(ohs_engine *e)
     if (!e) return;
     hipSetDevice(e->device);
     rt_stop(e);
+    rt_mark_stopped(e);     // (a slot taken by a start that then failed)
     if (e->rt_st) hipStreamDestroy(e->rt_st);
     if (e->mb) hipHostFree(e->mb);
     if (e->st) hipStreamSynchronize(e->st);
@@ -1117,7 +1148,8 @@ int ohs_engine_set_realtime(ohs_engine *e, int enable)
     if (rc == OHS_OK) rc = fifo_reserve(e->out, 8 * BS + 8192 + 1, e->st);
     if (rc == OHS_OK) rc = conv_grow_ring(e->conv, maxP + 7, e->st);
     if (rc) return rc;
-    return rt_start(e);
+    rc = rt_start(e);
+    return rc == OHS_RT_NO_SLOT ? OHS_OK : rc;      // over the cap: the mode is on, calls go launch per call until a slot frees
 }
 
 // diagnostics: device timestamps (100 MHz) of the last call served by the resident kernel

@@ -110,6 +110,57 @@ print("idle-exit ok")
     assert res.returncode == 0 and "idle-exit ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
 
 
+def test_resident_kernels_are_capped_per_device_and_the_rest_falls_back(ohs, synth):
+    """A resident kernel holds a CU for good, so their number per device is capped (OHS_RT_MAX_RESIDENT, read once per
+    process -> child process): engines beyond the cap run launch per call with the same bits, and get a resident kernel
+    once another engine leaves real-time mode."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r)
+import open_headstage_amd as ohs
+from open_headstage_amd import synth, _ffi
+irs = synth.hrir_set(512)
+rt = [ohs.ConvolutionEngine.new() for _ in range(4)]
+ref = [ohs.ConvolutionEngine.new() for _ in range(4)]
+for e in rt + ref:
+    for p in range(4):
+        e.set_ir(p, irs[p])
+for e in rt:
+    e.set_realtime(True)
+def resident(e):        # has a resident kernel ever served this engine?
+    st = (C.c_uint64 * 16)()
+    return _ffi.lib().ohs_engine_debug_rt_stamps(e._h, st) == 0
+x = synth.white_noise([21], 12 * 1024)[0]
+def step(i):
+    for k in range(4):
+        l, r = x[0, i*1024:(i+1)*1024].copy() * (k + 1) / 4, x[1, i*1024:(i+1)*1024].copy()
+        g = rt[k].process_block(l, r); w = ref[k].process_block(l, r)
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), (i, k)
+for i in range(4):
+    step(i)
+assert [resident(e) for e in rt] == [True, True, False, False], [resident(e) for e in rt]
+rt[0].set_realtime(False)            # frees a slot
+for i in range(4, 8):
+    step(i)
+assert resident(rt[2]) and not resident(rt[3]), [resident(e) for e in rt]
+del rt[1]; del ref[1]                # destroying an engine frees its slot too
+import gc; gc.collect()
+for i in range(8, 12):
+    for k in range(3):
+        l, r = x[0, i*1024:(i+1)*1024].copy(), x[1, i*1024:(i+1)*1024].copy()
+        g = rt[k].process_block(l, r); w = ref[k].process_block(l, r)
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), (i, k)
+assert resident(rt[2])               # the former rt[3]
+print("cap ok")
+""" % root
+    env = dict(os.environ, OHS_RT_MAX_RESIDENT="2")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "cap ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
+
+
 def test_latency_report_matches_the_fifo_rule(ohs, synth, oracle):
     e = ohs.ConvolutionEngine.new()
     assert e.latency_samples(512) == 0 and e.latency_samples(1024) == 0 and e.latency_samples(4096) == 0
