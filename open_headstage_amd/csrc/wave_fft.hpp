@@ -95,6 +95,11 @@ __device__ __forceinline__ void wave_lds_sync()
 #else
 #define OHS_TW_LD(p) lds_ld(p)
 #endif
+#ifdef OHS_TW_UNPINNED      // experiment: the table reads where hipcc puts them
+#define OHS_TW_PIN() do { } while (0)
+#else
+#define OHS_TW_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef OHS_LDS_MERGE
 // (accessed as one 64-bit integer, not as a <2 x float> vector: with a vector type in play hipcc packs the
 // following complex arithmetic into v_pk_* instructions and pays for it in register moves)
@@ -245,8 +250,16 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
                                                   int lane)
 {
     dft16<false, ZPAD>(v);                                  // over a -> p
+    {
+        // all 15 table reads in one burst, pinned there: left alone, hipcc issues each read right in front of its
+        // multiplication and waits for it -- eight exposed LDS round trips per twiddle stage
+        float2 tw[16];
 #pragma unroll
-    for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], OHS_TW_LD(&tab[kTabA + t1_index(p, lane)]));
+        for (int p = 1; p < 16; ++p) tw[p] = OHS_TW_LD(&tab[kTabA + t1_index(p, lane)]);
+        OHS_TW_PIN();
+#pragma unroll
+        for (int p = 1; p < 16; ++p) v[p] = cmul(v[p], tw[p]);
+    }
     const int pp = lane >> 2, c = lane & 3;
     const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
 #ifndef OHS_KO_T1       // timing experiment (wrong results): the transform without its T1 exchanges
@@ -258,8 +271,14 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
     wave_lds_sync();
 #endif
     dft16<false>(v);                                        // over b -> q
+    {
+        float2 tw[16];
 #pragma unroll
-    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], OHS_TW_LD(&tab[kTabB + 4 * q + (lane & 3)]));
+        for (int q = 1; q < 16; ++q) tw[q] = OHS_TW_LD(&tab[kTabB + 4 * q + (lane & 3)]);
+        OHS_TW_PIN();
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw[q]);
+    }
     const int p_lo = pp & 3, p_hi = pp >> 2;
     const int rrw = 4 * p_lo + c;
 #pragma unroll
@@ -350,8 +369,14 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     wave_lds_sync();
     dft16<true>(v);                                         // over q -> b
     const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
+    {
+        float2 tw[16];
 #pragma unroll
-    for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], OHS_TW_LD(&tab[kTabA + t1r + 4 * b]));   // w1024^((4b+c) p), conj
+        for (int b = 0; b < 16; ++b) tw[b] = OHS_TW_LD(&tab[kTabA + t1r + 4 * b]);
+        OHS_TW_PIN();
+#pragma unroll
+        for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], tw[b]);   // w1024^((4b+c) p), conj
+    }
 #ifndef OHS_KO_T1
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds_st(&lds[t1r + 4 * b], v[b]);    // T1'
