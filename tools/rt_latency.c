@@ -60,19 +60,33 @@ static void run(ohs_engine *e, size_t n, int calls, const char *what)
                    (st[13] - st[12]) * 0.01, (st[14] - st[13]) * 0.01);
     }
     qsort(t, (size_t)calls, sizeof(double), cmp);
+    if (calls >= 100000)
+        printf("{\"config\": \"%s\", \"frames\": %zu, \"calls\": %d, \"us_median\": %.1f, \"us_p99\": %.1f, \"us_p999\": %.1f, "
+               "\"us_p9999\": %.1f, \"us_max\": %.1f, \"us_min\": %.1f}\n", what, n, calls, t[calls / 2], t[(int)(calls * 0.99)],
+               t[(int)(calls * 0.999)], t[(int)(calls * 0.9999)], t[calls - 1], t[0]);
+    else
     printf("{\"config\": \"%s\", \"frames\": %zu, \"us_median\": %.1f, \"us_p99\": %.1f, \"us_max\": %.1f, \"us_min\": %.1f}\n", what, n,
            t[calls / 2], t[(int)(calls * 0.99)], t[calls - 1], t[0]);
     free(il); free(ir); free(ol); free(orr); free(t);
 }
 
-int main(void)
+int main(int argc, char **argv)
 {
     ohs_engine *e = NULL;
+    /* rt_latency soak N: N calls of the resident 1024-frame configuration only, with the tail of the distribution */
+    const int soak = (argc > 2 && !strcmp(argv[1], "soak")) ? atoi(argv[2]) : 0;
     if (ohs_engine_create(0, &e)) { printf("create: %s\n", ohs_last_error()); return 1; }
     float h[512];
     for (int p = 0; p < 4; ++p) {
         for (int i = 0; i < 512; ++i) h[i] = (i == 30 + 15 * (p == 1 || p == 2)) ? 1.0f : 0.3f * expf(-i / 85.0f) * ((i * 7919 % 13) - 6) / 60.0f;
         ohs_engine_set_ir(e, p, h, 512);
+    }
+    if (soak > 0) {
+        ohs_engine_set_realtime(e, 1);
+        run(e, 1024, soak, "c_host_engine_1024_resident_kernel_soak");
+        ohs_engine_set_realtime(e, 0);
+        ohs_engine_destroy(e);
+        return 0;
     }
     run(e, 1024, 2000, "c_host_engine_1024_launch_per_call");
     ohs_engine_set_realtime(e, 1);
