@@ -159,9 +159,10 @@ def cpu_baseline(frames: int, target_seconds: float = 10.0):
 
 
 def load_traffic(kernel: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/pmc_latest.json, written by
-    tools/pmc_summary.py from two separate --pmc passes with the gfx950 FETCH_SIZE x2 correction).  It is NOT
-    measured in this run -- `traffic_source` in the record says where it came from."""
+    """Fallback for roofline.traffic: HBM bytes per launch from the committed rocprofv3 PMC summary
+    (profiles/pmc_latest.json, written by tools/pmc_summary.py from two separate --pmc passes with the gfx950
+    FETCH_SIZE x2 correction).  The default run replaces it by measure_traffic_live(); `traffic_source` in the
+    record says which one it was."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(p) as f:
@@ -169,6 +170,52 @@ def load_traffic(kernel: str):
         return d.get(kernel, {}).get("hbm_bytes_per_launch"), "profiles/pmc_latest.json (" + str(d.get("_tag", "?")) + ")"
     except Exception:       # noqa: BLE001
         return None, None
+
+
+def measure_traffic_live(timeout_s: float = 240.0):
+    """HBM bytes per launch per kernel, measured NOW: two child runs of this script (2 steps, no extras) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes and no trace domain, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; both counters are KiB, and on gfx950 FETCH_SIZE reports half
+    of the bytes of a streaming read (x2).  Returns ({kernel: bytes}, source) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "rocprofv3 not on PATH"
+    work = tempfile.mkdtemp(prefix="ohs_pmc_", dir="/tmp")
+    per = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, ctr)
+            cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", sys.executable,
+                   os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "2", "--warmup", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr}: no counter file (exit {r.returncode})"
+            agg = collections.defaultdict(list)
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == ctr and "ohs::" in row.get("Kernel_Name", ""):
+                            name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("ohs::", "").split("<")[0]
+                            agg[name].append(float(row["Counter_Value"]))
+            for k, v in agg.items():
+                scale = 2048.0 if ctr == "FETCH_SIZE" else 1024.0
+                per.setdefault(k, 0.0)
+                per[k] += sum(v) / len(v) * scale
+    except Exception as e:      # noqa: BLE001 -- an extra must never break the contract line
+        return None, f"live PMC pass failed: {str(e)[:120]}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    if not per:
+        return None, "no ohs:: kernels in the counter files"
+    return {k: int(round(v)) for k, v in per.items()}, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of 2 steps"
 
 
 def make_processor(ohs, S, nb, irs, coeffs, enabled, device_index):
@@ -194,6 +241,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the saturation sweep and the PCIe-inclusive leg")
     ap.add_argument("--pipelined", action="store_true", help="pipeline consecutive steps (ohs_batch_process_deferred)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="take roofline.traffic from profiles/pmc_latest.json instead of measuring it in two rocprofv3 child runs")
     args = ap.parse_args()
 
     import torch
@@ -436,6 +485,19 @@ def main() -> int:
             del bp2, x2, y2
             torch.cuda.empty_cache()
         out["saturation"] = sat
+        # roofline.traffic measured now (two rocprofv3 --pmc child runs of this script); the committed summary
+        # stays the fallback and is named as such
+        if not args.no_live_pmc:
+            live, src = measure_traffic_live()
+            if live is not None and out is not None:
+                rf = out["roofline"]
+                if rf.get("kernel") in live:
+                    rf["traffic"] = live[rf["kernel"]]
+                    rf["traffic_source"] = src
+                if "conv" in rf and rf["conv"].get("kernel") in live:
+                    rf["conv"]["traffic"] = live[rf["conv"]["kernel"]]
+            elif out is not None:
+                out["roofline"]["traffic_live_error"] = src
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
