@@ -495,7 +495,11 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
 }
 
 // One launch = one call.
-__global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E)
+// `done` (pinned host memory, may be null): the call's sequence number is stored there once every wave's stores have
+// drained and been released -- the host spins on that word instead of querying the stream, whose completion signal
+// and hipStreamQuery round trip arrive several microseconds after the frames.
+__global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E, unsigned *done,
+                                                     unsigned seq)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
@@ -504,6 +508,14 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
     float2 *slabs = smem + kTabComplex;
     float2 *zx = slabs + n_waves * kWaveLdsComplex;
     engine_call_body<false, false>(A, E, tab, slabs, zx, zx + n_waves * kFft, wave, lane, n_waves);   // its first barrier also covers the table fill
+    if (done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // RESIDENT form ("persistent kernels + pinned-memory mailboxes"): one workgroup of 8
@@ -779,14 +791,14 @@ hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st)
+hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st, unsigned *done, unsigned seq)
 {
     if (a.n_blocks < 0 || a.n_blocks > 8) return hipErrorInvalidValue;
     // always the full workgroup: up to 4 blocks get a pair of waves each
     static std::atomic<unsigned long long> lds_ok{0};
     const hipError_t e2 = allow_large_lds(reinterpret_cast<const void *>(k_engine_call), kEngineLdsBytes, lds_ok);
     if (e2 != hipSuccess) return e2;
-    hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(512), kEngineLdsBytes, st, a, e);
+    hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(512), kEngineLdsBytes, st, a, e, done, seq);
     return hipGetLastError();
 }
 
@@ -1334,6 +1346,33 @@ hipError_t launch_scale_copy(const float *src, float *dst, long long n, float ga
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, gain);
+    return hipGetLastError();
+}
+
+// The same copy as the LAST kernel of a host call: the workgroup that finishes last stores `seq` into the call's
+// completion word in pinned host memory (see k_engine_call).  `counter` is a device word that is zero between calls.
+__global__ void k_scale_copy_done(const float *__restrict__ src, float *__restrict__ dst, long long n, float gain,
+                                  unsigned *counter, unsigned *done, unsigned seq)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] * gain;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // this workgroup's frames are out
+        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+hipError_t launch_scale_copy_done(const float *src, float *dst, long long n, float gain, unsigned *counter, unsigned *done,
+                                  unsigned seq, hipStream_t st)
+{
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_scale_copy_done, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, gain, counter,
+                       done, seq);
     return hipGetLastError();
 }
 

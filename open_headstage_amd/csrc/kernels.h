@@ -66,7 +66,9 @@ struct EngineCallArgs {
     int emit;                   // 1: out_len + 512 k >= n, the call pops n frames; 0: silence (host fills)
     float gain_pop;             // applied to popped frames only (lib.rs:1202-1207)
 };
-hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st);
+// done / seq: completion word in pinned host memory (nullptr: none), see k_engine_call
+hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e, hipStream_t st, unsigned *done = nullptr,
+                              unsigned seq = 0);
 
 // Mailbox of the resident real-time kernel, in pinned + mapped host memory (one per engine).
 // call_word = {seq, n, gain bits, stop}: the host writes n and gain, then seq (release); the device reads all
@@ -168,5 +170,7 @@ hipError_t launch_debug_fft(const float2 *in, float2 *out, int inverse, int batc
 
 // dst[i] = src[i] * gain  (n floats)
 hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st);
+hipError_t launch_scale_copy_done(const float *src, float *dst, long long n, float gain, unsigned *counter, unsigned *done,
+                                  unsigned seq, hipStream_t st);
 
 }  // namespace ohs

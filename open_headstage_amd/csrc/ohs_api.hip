@@ -553,6 +553,8 @@ struct ohs_engine {
     float *h_in = nullptr, *h_out = nullptr;      // host [2][hcap]
     float *dm_in = nullptr, *dm_out = nullptr;    // the same memory, device addresses
     float *d_eqbuf = nullptr;                     // device [2][hcap]
+    unsigned *h_done = nullptr, *dm_done = nullptr;   // completion word of the single-launch call (pinned; host / device address)
+    unsigned call_seq = 0;
     size_t hcap = 0;
     uint64_t silent_frames = 0;                   // frames answered with the zero fill of convolution.rs:176-181
     // resident real-time kernel (ohs_engine_set_realtime): mailbox in pinned mapped memory, its own stream
@@ -574,6 +576,8 @@ struct ohs_eq {
     float *h_pin = nullptr;     // [2][pin_cap] pinned + mapped host staging for real-time sized calls
     float *dm_pin = nullptr;    // its device address
     float *d_pinbuf = nullptr;  // [2][pin_cap] device side
+    unsigned *h_done = nullptr, *dm_done = nullptr, *d_counter = nullptr;   // completion word (pinned) + its workgroup counter
+    unsigned call_seq = 0;
     size_t pin_cap = 0;
 };
 
@@ -649,6 +653,11 @@ int engine_pinned_reserve(ohs_engine *e, size_t n)
     HIP_TRY(hipHostGetDevicePointer((void **)&e->dm_in, e->h_in, 0));
     HIP_TRY(hipHostGetDevicePointer((void **)&e->dm_out, e->h_out, 0));
     HIP_TRY(hipMalloc(&e->d_eqbuf, 2 * ncap * sizeof(float)));
+    if (!e->h_done) {
+        HIP_TRY(hipHostMalloc((void **)&e->h_done, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&e->dm_done, e->h_done, 0));
+        *e->h_done = 0;
+    }
     e->hcap = ncap;
     return OHS_OK;
 }
@@ -703,13 +712,24 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
     g.src_l = src_l; g.src_r = src_r;
     g.host_l = e->dm_out; g.host_r = e->dm_out + e->hcap;
     g.n = (int)n; g.emit = emit ? 1 : 0; g.gain_pop = gain;
-    hipError_t err = launch_engine_call(a, g, st);
+    const unsigned seq = ++e->call_seq;
+    hipError_t err = launch_engine_call(a, g, st, e->dm_done, seq);
     if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("engine call launch: ") + hipGetErrorString(err));
     c.cnt += k;
     for (int p = 0; p < 4; ++p) c.since[p] += (long long)k;
     e->in.len = e->in.len + n - k * BS;
     e->out.len = emit ? e->out.len + k * BS - n : e->out.len + k * BS;
-    HIP_TRY(sync_spin(st));
+    {   // the kernel's own completion word (it is stored behind a system-scope release of the frames); the stream
+        // query is the fallback -- and the error path: a kernel that died never writes the word
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(e->h_done, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+                HIP_TRY(hipStreamSynchronize(st));
+                break;
+            }
+        }
+    }
     if (emit) {
         std::memcpy(out_l, e->h_out, n * sizeof(float));
         std::memcpy(out_r, e->h_out + e->hcap, n * sizeof(float));
@@ -1059,6 +1079,7 @@ void ohs_engine_destroy(ohs_engine *e)
     if (e->h_in) hipHostFree(e->h_in);
     if (e->h_out) hipHostFree(e->h_out);
     if (e->d_eqbuf) hipFree(e->d_eqbuf);
+    if (e->h_done) hipHostFree(e->h_done);
     if (e->st) hipStreamDestroy(e->st);
     delete e;
 }
@@ -1231,6 +1252,8 @@ void ohs_eq_destroy(ohs_eq *q)
     if (q->d_buf) hipFree(q->d_buf);
     if (q->h_pin) hipHostFree(q->h_pin);
     if (q->d_pinbuf) hipFree(q->d_pinbuf);
+    if (q->h_done) hipHostFree(q->h_done);
+    if (q->d_counter) hipFree(q->d_counter);
     if (q->st) hipStreamDestroy(q->st);
     delete q;
 }
@@ -1296,8 +1319,25 @@ int ohs_eq_process_block(ohs_eq *q, float *left, float *right, size_t n)
         HIP_TRY(launch_scale_copy(q->dm_pin, q->d_pinbuf, (long long)(q->pin_cap + n), 1.0f, q->st));
         int rc = eq_launch(q->eq, q->d_pinbuf, q->d_pinbuf, 0, (long long)q->pin_cap, (long long)n, q->st);
         if (rc) return rc;
-        HIP_TRY(launch_scale_copy(q->d_pinbuf, q->dm_pin, (long long)(q->pin_cap + n), 1.0f, q->st));
-        HIP_TRY(sync_spin(q->st));
+        if (!q->h_done) {
+            HIP_TRY(hipHostMalloc((void **)&q->h_done, 64, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void **)&q->dm_done, q->h_done, 0));
+            *q->h_done = 0;
+            HIP_TRY(hipMalloc((void **)&q->d_counter, sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(q->d_counter, 0, sizeof(unsigned), q->st));
+        }
+        const unsigned seq = ++q->call_seq;
+        HIP_TRY(launch_scale_copy_done(q->d_pinbuf, q->dm_pin, (long long)(q->pin_cap + n), 1.0f, q->d_counter, q->dm_done, seq, q->st));
+        {   // the copy-out kernel's completion word; the stream is the fallback and the error path
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (__atomic_load_n(q->h_done, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+                    HIP_TRY(hipStreamSynchronize(q->st));
+                    break;
+                }
+            }
+        }
         std::memcpy(left, q->h_pin, n * sizeof(float));
         std::memcpy(right, q->h_pin + q->pin_cap, n * sizeof(float));
         return OHS_OK;
