@@ -43,7 +43,7 @@ PROTOTYPES = {
     "ohs_engine_clone": (C.c_int, [vp, vpp]),
     "ohs_engine_destroy": (None, [vp]),
     "ohs_engine_set_ir": (C.c_int, [vp, C.c_int, fp, C.c_size_t]),
-    "ohs_engine_process_block": (C.c_int, [vp, fp, fp, fp, fp, C.c_size_t]),
+    "ohs_engine_process_block": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t]),     # audio pointers as plain addresses (hot call)
     "ohs_engine_num_partitions": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
     "ohs_engine_set_realtime": (C.c_int, [vp, C.c_int]),
     "ohs_engine_latency_samples": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -56,7 +56,7 @@ PROTOTYPES = {
                                      C.c_float, C.c_int]),
     "ohs_eq_set_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.c_int]),
     "ohs_eq_get_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.POINTER(C.c_int)]),
-    "ohs_eq_process_block": (C.c_int, [vp, fp, fp, C.c_size_t]),
+    "ohs_eq_process_block": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ohs_eq_reset": (C.c_int, [vp]),
     "ohs_eq_set_exact_specials": (C.c_int, [vp, C.c_int]),
     "ohs_batch_set_eq_exact_specials": (C.c_int, [vp, C.c_int]),
@@ -80,7 +80,7 @@ PROTOTYPES = {
     "ohs_sofa_get_hrtf_irs": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, fp, fp, C.c_size_t, fp, fp]),
     "ohs_sofa_resample_ir": (C.c_int, [fp, C.c_size_t, C.c_float, C.c_float, fp, C.c_size_t,
                                        C.POINTER(C.c_size_t)]),
-    "ohs_chain_process": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, fp, fp, C.c_size_t]),
+    "ohs_chain_process": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, C.c_size_t]),
     "ohs_batch_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, vpp]),
     "ohs_batch_destroy": (None, [vp]),
     "ohs_batch_set_ir": (C.c_int, [vp, C.c_int, fp, C.c_size_t]),
