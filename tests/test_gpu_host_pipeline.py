@@ -112,3 +112,37 @@ def test_host_pipeline_irregular_strides_and_errors():
     with pytest.raises(OhsError):
         check(lib().ohs_batch_process_host(bp2._h, C.c_void_p(big_in.ctypes.data), C.c_void_p(big_out.ctypes.data),
                                            n_blocks, ss, frames - 1, 0))
+
+
+def test_host_pipeline_stage_trace_diagnostic_runs():
+    """OHS_HOST_PIPE_TRACE=1 (read once per process -> child process): the per-chunk stage table is printed and the
+    results are unchanged."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import open_headstage_amd as ohs
+from open_headstage_amd import synth
+S, nb = 3, 96
+x = synth.white_noise(range(S), nb * 512)
+def make():
+    bp = ohs.BatchProcessor(S, num_bands=10)
+    irs = synth.hrir_set(512)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i, b in enumerate(synth.eq_table()):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(True)
+    return bp
+a = make().process_host(x.copy(), chunk_blocks=32)
+b = make().process_host(x.copy(), chunk_blocks=32)
+assert np.array_equal(a, b)
+print("trace ok")
+""" % root
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OHS_HOST_PIPE_TRACE="1"),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "trace ok" in res.stdout, (res.stdout[-300:], res.stderr[-1500:])
+    assert "[ohs host pipeline] 3 chunks of 32 blocks" in res.stderr, res.stderr[-1500:]
