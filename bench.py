@@ -442,6 +442,34 @@ def main() -> int:
 
     # ---- extras, N = 1 only, after the timed region ----
     if world == 1 and not args.no_extras and not strong:
+        # The convolution by itself (BASELINE config 3 without the EQ): 8 steps back to back.  In the headline step
+        # it runs in six slices underneath the EQ and `roofline.conv` shows what it gets there; this is the kernel
+        # with the chip to itself, against HBM by its design bytes.
+        try:
+            bp.set_eq_enabled(False)
+            # 40 untimed steps first: after the EQ phase (7/8 of the chip idle) the first full-chip steps run 25 %
+            # slower than the steady state -- 0.78 ms with 2 warm-up steps, 0.64 with 40 or 200 (clock / power ramp)
+            for _ in range(40):
+                bp.process(x, out=y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                 # (EQ off: the step's two kernels are launched on this very stream)
+            for _ in range(16):
+                bp.process(x, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            dt = e0.elapsed_time(e1) * 1e-3 / 16
+            _, cb_alone = bp.kernel_bytes(n_blocks)
+            out["roofline"]["conv_alone"] = {
+                "what": "the same batch with the EQ off, 16 steps back to back after 40 warm-up steps (pre-pass + main kernel per step, HIP events)",
+                "ms_per_step": round(dt * 1e3, 4), "Msamples_s": round(args.streams * frames / dt / 1e6, 1),
+                "design_bytes_per_step": int(cb_alone),
+                "achieved": round(cb_alone / dt / 1e9, 1), "unit": "GB/s",
+                "frac": round(cb_alone / dt / 1e9 / HBM_PEAK_GBS, 5)}
+            bp.set_eq_enabled(True)
+            bp.reset()
+        except Exception as e:      # noqa: BLE001
+            out["roofline"]["conv_alone"] = {"error": str(e)[:200]}
         # PCIe-inclusive: the same step from / to pinned host memory, H2D || kernels || D2H over time chunks
         S = args.streams
         try:
