@@ -186,6 +186,10 @@ def measure_traffic_live(timeout_s: float = 240.0):
     rp = shutil.which("rocprofv3")
     if not rp:
         return None, "rocprofv3 not on PATH"
+    # never nest: if this very process is being profiled, the children would inherit the tool's preload
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or \
+            "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "running under a profiler: no nested rocprofv3 runs"
     work = tempfile.mkdtemp(prefix="ohs_pmc_", dir="/tmp")
     per = {}
     try:
