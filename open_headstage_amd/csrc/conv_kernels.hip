@@ -848,9 +848,13 @@ hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2,
 // Round 1 added the chunk-boundary tails afterwards with a read-modify-write pass over `out` (k_conv_p1_fixup);
 // recomputing 1 block in ~34 instead costs less than that pass and its traffic.
 #ifndef OHS_P1_WAVES
-#define OHS_P1_WAVES 15
+#define OHS_P1_WAVES 16
 #endif
-constexpr int kP1Waves = OHS_P1_WAVES;   // waves per workgroup = per CU (LDS: 25 KiB of tables + 8.5 KiB per wave = 152.5 KiB)
+// waves per workgroup = per CU, four per SIMD.  LDS: 8.5 KiB of twiddle tables + 16 KiB of C / D + 16 slabs of 8672 B
+// = 163 840 B, every byte of the CU's 160 KiB (the w64 table hides in the padding of the w1024 table's rows,
+// wave_fft.hpp, and a slab ends where its last image does).
+constexpr int kP1Waves = OHS_P1_WAVES;
+static_assert((kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2) <= 160 * 1024, "k_conv_p1: LDS plan");
 
 // W = Z C + conj(Zm) D for the 16 registers of a lane, written over the mirror values (cd: LDS, [2][16][64])
 __device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float2 (&w)[16], const float2 *cd, int lane)
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 }
 
 // pre-pass: wave (s, e) as described above; same workgroup shape as the main kernel, so that the 25 KiB of
-// tables are fetched once per 15 waves and all waves of the pass are resident in two rounds
+// tables are fetched once per 16 waves and all waves of the pass are resident in two rounds
 __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Args A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -1141,12 +1145,12 @@ hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float
     return hipGetLastError();
 }
 
-// F: one wave per (stream, block).  kTpWaves waves per workgroup (one workgroup per CU): the 9 KiB of twiddle
+// F: one wave per (stream, block).  kTpWaves waves per workgroup (one workgroup per CU): the 8.5 KiB of twiddle
 // tables are fetched once per 16 waves instead of once per 4, and a CU holds 16 waves instead of 12.
 #ifndef OHS_TP_WAVES
 #define OHS_TP_WAVES 16
 #endif
-constexpr int kTpWaves = OHS_TP_WAVES;      // LDS: 9 KiB + 16 x 8.5 KiB = 145 KiB
+constexpr int kTpWaves = OHS_TP_WAVES;      // LDS: 8.5 KiB + 16 x 8672 B = 144 KiB
 __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_forward(const ConvTpArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];

@@ -82,7 +82,7 @@ int get_ctx(int device, DeviceCtx **out)
         const double ang = -2.0 * 3.14159265358979323846264338327950288 * (double)k / (double)NF;
         tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
     }
-    // every kernel receives the EXPANDED, lane-ordered tables (9 KiB) and copies them to LDS
+    // every kernel receives the EXPANDED, lane-ordered tables (8.5 KiB) and copies them to LDS
     std::vector<float2> expanded(kTabComplex);
     expand_twiddle_tables(tw.data(), expanded.data());
     if (hipMalloc(&c->d_tw, kTabComplex * sizeof(float2)) != hipSuccess) {

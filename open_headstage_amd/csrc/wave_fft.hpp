@@ -1,5 +1,5 @@
 // wave_fft.hpp -- one wavefront (64 lanes x 16 complex registers) computes one
-// complex FFT-1024 entirely in registers + a private 8.5 KiB LDS slab.
+// complex FFT-1024 entirely in registers + a private LDS slab of 8672 bytes.
 //
 // This is the transform behind rustfft's `Fft::process` call sites in the
 // reference (src/dsp/convolution.rs:129,255,276): unnormalised, forward =
@@ -33,14 +33,18 @@ namespace ohs {
 
 constexpr int kBlock = 512;
 constexpr int kFft = 1024;
-constexpr int kWaveLdsComplex = 16 * 68;   // per-wave LDS slab, in float2 units (8704 B)
+constexpr int kWaveLdsComplex = 15 * 68 + 64;   // per-wave LDS slab, in float2 units (8672 B): the last T1 row needs no padding,
+                                                // the T2 image ends at 65 * 15 + 63
 
-// twiddle tables kept in LDS per workgroup (float2 units), 9 KiB
+// twiddle tables kept in LDS per workgroup (float2 units), 8.5 KiB
 constexpr int kTabA = 0;              // [16][68]  w1024^(m p) at t1_index(p, m): rows for the forward transform,
                                       //           columns (conjugated) for the inverse
-constexpr int kTabB = 16 * 68;        // [16][4]   w64^(c q)   index 4q + c: only 64 distinct values (LDS broadcast);
-                                      //           forward: lane c = lane & 3, reg q; inverse: lane q = lane >> 2, reg c
-constexpr int kTabComplex = 16 * 68 + 64;  // 1152 float2 = 9 KiB
+// w64^(c q), 64 values, live in the four padding slots at the end of row q of that table (tabB_index): no bytes of
+// their own -- which is what lets a 16th wave's slab fit into the CU's 160 KiB next to the P = 1 kernel's tables.
+// forward: lane c = lane & 3, reg q (4 addresses per read: broadcast); inverse: lane q = lane >> 2, reg c (per
+// 32 lanes 8 addresses in 8 different bank pairs)
+constexpr int kTabComplex = 16 * 68;  // 1088 float2 = 8.5 KiB
+__host__ __device__ __forceinline__ constexpr int tabB_index(int q, int c) { return 68 * q + 64 + c; }
 
 // T1 image / twiddle table position of element (p, m), m = 4b + c
 __host__ __device__ __forceinline__ constexpr int t1_index(int p, int m) { return 68 * p + m; }
@@ -208,7 +212,7 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
     t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
-// The 9 KiB of per-workgroup twiddle tables are expanded ONCE per device on the host
+// The 8.5 KiB of per-workgroup twiddle tables are expanded ONCE per device on the host
 // (expand_twiddle_tables, from exp(-2 pi i e / 1024) computed in f64 and rounded to f32, as rustfft
 // does); a kernel only copies them into LDS with 16-byte loads.
 __device__ __forceinline__ void fill_twiddle_tables(float2 *tab, const float2 *__restrict__ gtab,
@@ -227,7 +231,7 @@ inline void expand_twiddle_tables(const float2 *tw, float2 *expanded)
     for (int p = 0; p < 16; ++p)
         for (int m = 0; m < 64; ++m) expanded[kTabA + t1_index(p, m)] = tw[(m * p) & 1023];   // w1024^(m p)
     for (int q = 0; q < 16; ++q)
-        for (int c = 0; c < 4; ++c) expanded[kTabB + 4 * q + c] = tw[(16 * c * q) & 1023];    // w64^(c q)
+        for (int c = 0; c < 4; ++c) expanded[tabB_index(q, c)] = tw[(16 * c * q) & 1023];     // w64^(c q)
 }
 
 __host__ __device__ __forceinline__ constexpr int t2_sigma(int q, int p_hi)
@@ -274,7 +278,7 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
     {
         float2 tw[16];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) tw[q] = OHS_TW_LD(&tab[kTabB + 4 * q + (lane & 3)]);
+        for (int q = 1; q < 16; ++q) tw[q] = OHS_TW_LD(&tab[tabB_index(q, lane & 3)]);
         OHS_TW_PIN();
 #pragma unroll
         for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw[q]);
@@ -353,7 +357,7 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
-        const float2 w = OHS_TW_LD(&tab[kTabB + 4 * (lane >> 2) + c]);
+        const float2 w = OHS_TW_LD(&tab[tabB_index(lane >> 2, c)]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
     }

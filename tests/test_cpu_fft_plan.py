@@ -18,3 +18,4 @@ def test_wave_fft_index_plan_and_bank_census():
     assert "T1 fwd write 1 read 1" in out and "T2 fwd write 1 read 1" in out and "T1 inv write 1 read 1" in out
     assert "T2 inv write 2 read 1" in out                      # the one documented 2-way conflict
     assert "T2 mirror reads 1 1" in out and "twiddle table rows / columns 1 1" in out
+    assert "w64 table in the row padding, forward / inverse 1 1" in out and "slab 1084 entries: OK" in out

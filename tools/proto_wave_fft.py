@@ -166,6 +166,27 @@ if __name__ == "__main__":
           worst(halves, lambda L, g: addr2(0, g & 3, ((64 - L) & 63) >> 2, ((64 - L) & 63) & 3), 32))
     print("twiddle table rows / columns", worst(halves, lambda m, p: addr1(p, m), 32),
           worst(halves, lambda L, b: addr1(L >> 2, 4 * b + (L & 3)), 32))
+    # w64^(c q) lives in the four padding slots of row q of that table (tabB_index): distinct ADDRESSES per bank pair
+    # (lanes that read the same address are one broadcast access)
+    def worst_distinct(groups, f, nb):
+        wv = 0
+        for g in groups:
+            for reg in range(16):
+                per = {}
+                for lane in g:
+                    a = f(lane, reg)
+                    per.setdefault(a % nb, set()).add(a)
+                wv = max(wv, max(len(v) for v in per.values()))
+        return wv
+    tab_b = lambda q, c: 68 * q + 64 + c
+    assert all(tab_b(q, c) < 16 * 68 and tab_b(q, c) % 68 >= 64 for q in range(16) for c in range(4))
+    print("w64 table in the row padding, forward / inverse", worst_distinct(halves, lambda L, q: tab_b(q, L & 3), 32),
+          worst_distinct(halves, lambda L, c: tab_b(L >> 2, c & 3), 32))
+    # a wave's slab: 15 * 68 + 64 entries hold both images
+    slab = 15 * 68 + 64
+    assert max(addr1(p, m) for p in range(16) for m in range(64)) < slab
+    assert max(addr2(a, b, c, d) for a in range(4) for b in range(4) for c in range(16) for d in range(4)) < slab
+    print("slab", slab, "entries: OK")
     # the mirror trick itself: DFT4 over c of the T2-image groups of the mirror lanes gives Z[N - k]
     def t2_image(z):
         regs = np.zeros((64, 16), complex)

@@ -27,7 +27,7 @@ bp.set_eq_enabled(False)
 x = synth.white_noise_torch(0, S, frames, dev)
 y = torch.empty_like(x)
 settings = [dict(OHS_P1_TARGET_WAVES=str(tw), OHS_P1_STAGGER=str(sg))
-            for tw, sg in itertools.product((3840, 5760, 7680, 11520), (0, 8))]
+            for tw, sg in itertools.product((3840, 4096, 7680, 8192, 11520, 12288), (0,))]
 res = {i: [] for i in range(len(settings))}
 for rnd in range(6):
     for i, st in enumerate(settings):
