@@ -29,6 +29,10 @@ EXTRA_DEFS = os.environ.get("OHS_EXTRA_DEFS", "").split()
 OBJ = os.path.join(HERE, "build", TAG) if TAG else os.path.join(HERE, "build")
 LIB = os.path.join(HERE, f"libohs_hip_{TAG}.so" if TAG else "libohs_hip.so")
 STAMP = os.path.join(HERE, f"libohs_hip_{TAG}.stamp" if TAG else "libohs_hip.stamp")
+# per-kernel register / scratch / LDS figures as hipcc reports them (-Rpass-analysis=kernel-resource-usage), written
+# next to the library at build time: DESIGN.md quotes them and tests/test_cpu_host_logic.py holds k_eq_ring to its
+# 32-VGPR budget with them
+RESOURCES = os.path.join(HERE, f"libohs_hip_{TAG}.resources.json" if TAG else "libohs_hip.resources.json")
 ARCH = "gfx950"
 
 
@@ -111,19 +115,80 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or _read_obj_hash(obj) != want[src]:
-            cmd = [hipcc, *COMMON, *extra, *EXTRA_DEFS, "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc, *COMMON, *extra, *EXTRA_DEFS, "-Rpass-analysis=kernel-resource-usage", "-c",
+                   os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            remarks = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
+            rest = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l]
+            if rest:
+                sys.stderr.write("\n".join(rest) + "\n")
+            if r.returncode != 0:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            with open(obj + ".resources.json", "w") as f:
+                json.dump(_parse_resource_remarks(remarks), f, indent=1, sort_keys=True)
             with open(obj + ".hash", "w") as f:
                 f.write(want[src])
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    res = {}
+    for obj in objs:
+        try:
+            with open(obj + ".resources.json") as f:
+                res.update(json.load(f))
+        except Exception:       # noqa: BLE001 -- an object built before this file recorded them
+            pass
+    with open(RESOURCES, "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
     with open(STAMP, "w") as f:
         json.dump(want, f, indent=1)
     return LIB
+
+
+def _parse_resource_remarks(lines: list[str]) -> dict:
+    """{kernel (demangled base name, template arguments kept): {vgprs, agprs, sgprs, scratch_bytes_per_lane,
+    lds_bytes, occupancy_waves_per_simd}} from hipcc's kernel-resource-usage remarks."""
+    import re
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+            "LDS Size [bytes/block]": "lds_bytes", "Occupancy [waves/SIMD]": "occupancy_waves_per_simd"}
+    for l in lines:
+        m = re.search(r"remark:\s+Function Name: (\S+)", l)
+        if m:
+            name = m.group(1)
+            name = _kernel_base_name(name)
+            cur = out.setdefault(name, {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", l)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def _kernel_base_name(mangled: str) -> str:
+    """_ZN3ohs9k_conv_p1ENS_10ConvP1ArgsE -> k_conv_p1; _ZN3ohs9k_eq_passILi6EEEv... -> k_eq_pass<6> (Itanium
+    nested-name <length><identifier> pairs; no demangler is needed for the kernels of this library)"""
+    import re
+    m = re.match(r"_ZN3ohs(\d+)", mangled)
+    if not m:
+        return mangled
+    n = int(m.group(1))
+    start = m.end()
+    name = mangled[start:start + n]
+    t = re.match(r"ILi(\d+)E", mangled[start + n:])
+    return f"{name}<{t.group(1)}>" if t else name
+
+
+def resources() -> dict:
+    """the figures recorded by the last build (empty if the library was built before they were recorded)"""
+    try:
+        with open(RESOURCES) as f:
+            return json.load(f)
+    except Exception:           # noqa: BLE001
+        return {}
 
 
 def _read_obj_hash(obj: str) -> str:

@@ -1436,8 +1436,20 @@ int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch *
         return fail(OHS_ERR_HIP, "hipStreamCreate failed");
     }
     {
-        const char *e = getenv("OHS_NO_OVERLAP");
-        b->overlap = !(e && e[0] == '1');
+        // EQ || convolution overlap policy.  An EQ wave saturates the vector unit of its SIMD (every instruction of
+        // the ring form is a 4-cycle DPP / packed operation: two EQ waves on one SIMD take 1.82x the time of one,
+        // four 3.47x -- profiles/r03_eq_share.txt), so the convolution only makes progress on CUs that host no EQ
+        // wave; from one EQ wave per SIMD on (almost) every CU upwards the two kernels merely get in each other's
+        // way (2048 streams: 13.7-16.1 ms overlapped, 11.5 ms one after the other).  Overlap while at least an
+        // eighth of the CUs stays free of EQ waves, serialise beyond.  OHS_NO_OVERLAP=1 / OHS_FORCE_OVERLAP=1 override.
+        const char *e = getenv("OHS_NO_OVERLAP"), *f = getenv("OHS_FORCE_OVERLAP");
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        const size_t eq_waves = (2 * n_streams + 3) / 4;            // 4 chains per wave
+        const size_t eq_cus = (eq_waves + 3) / 4;                   // one wave per SIMD once there is a wave per CU
+        b->overlap = eq_cus * 8 <= (size_t)cus * 7;
+        if (e && e[0] == '1') b->overlap = false;
+        if (f && f[0] == '1') b->overlap = true;
     }
     rc = conv_init(b->conv, n_streams, b->st);
     if (rc == OHS_OK) rc = eq_init(b->eq, num_bands, 2 * n_streams, 48000.0f, b->st);

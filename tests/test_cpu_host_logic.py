@@ -189,3 +189,31 @@ def test_header_is_plain_c_and_the_c_host_links(tmp_path):
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), "-o",
                     str(tmp_path / "host_chain"), os.path.join(root, "examples", "host_chain.c"),
                     "-L" + libdir, "-lohs_hip", "-lm", "-Wl,-rpath," + libdir], check=True)
+
+
+def test_kernel_register_budgets(lib):
+    """Figures hipcc reported when the library was built (open_headstage_amd/libohs_hip.resources.json).
+    k_eq_ring must fit beside four k_conv_p1 waves on a SIMD: 4 x alloc(k_conv_p1) + alloc(k_eq_ring) <= 512
+    registers per lane at the hardware's granule of 8, and neither may spill."""
+    from open_headstage_amd import build
+    res = build.resources()
+    if not res:
+        pytest.skip("library built before resource figures were recorded")
+
+    def alloc(k):
+        return -(-(res[k]["vgprs"] + res[k]["agprs"]) // 8) * 8
+
+    assert res["k_eq_ring"]["scratch_bytes_per_lane"] == 0
+    assert res["k_conv_p1"]["scratch_bytes_per_lane"] == 0
+    assert alloc("k_eq_ring") <= 32, res["k_eq_ring"]
+    assert 4 * alloc("k_conv_p1") + alloc("k_eq_ring") <= 512, (res["k_conv_p1"], res["k_eq_ring"])
+    # the generated asm bodies must be the generator's current output
+    import importlib.util
+    gen_path = os.path.join(ROOT, "tools", "gen_eq_ring2_asm.py")
+    spec = importlib.util.spec_from_file_location("gen_eq_ring2_asm", gen_path)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    inc = open(os.path.join(ROOT, "open_headstage_amd", "csrc", "eq_ring2_asm.inc")).read()
+    for macro, lines in (("EQ_RING2_MAIN", gen.gen_main()), ("EQ_RING2_HEAD_NOLOAD", gen.gen(first_step=16, loads=False))):
+        body = f"#define {macro} \\\n" + " \\\n".join('    "' + l + '\\n"' for l in lines) + "\n"
+        assert body in inc, f"{macro}: eq_ring2_asm.inc is not what tools/gen_eq_ring2_asm.py writes"
