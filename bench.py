@@ -12,10 +12,15 @@
              contiguous id range, no data-path collective; the shared HRIR set + EQ table is broadcast
              once from rank 0 (RCCL over xGMI via torch.distributed "nccl").
 
-Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+Launch:  python bench.py [--gpus N] [--steps K] [--warmup W]
+             N > 1 without WORLD_SIZE in the environment: this process never touches the GPU -- it starts N child
+             ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays
+             rank 0's line and exits with the worst child status
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line.  Beside the contract's fields it carries, at N = 1:
+Rank 0 prints ONE JSON line.  At N > 1 it carries `ranks` (per rank: device index, PCI bus id / UUID, streams, ms per
+step -- gathered with all_gather_object), `rccl_world_size`, `distinct_devices`, and in strong mode
+`expected_strong_scaling`.  Beside the contract's fields it carries, at N = 1:
   roofline      the dominant kernel (HIP-event time inside the timed region) against HBM and, when it is the
                 EQ's serial recurrence, against its instruction-issue floor; `conv` = the convolution kernel
                 against HBM by the bytes it really moves
@@ -172,7 +177,7 @@ def load_traffic(kernel: str):
         return None, None
 
 
-def measure_traffic_live(timeout_s: float = 240.0):
+def measure_traffic_live(frames: int, streams: int, timeout_s: float = 240.0):
     """HBM bytes per launch per kernel, measured NOW: two child runs of this script (2 steps, no extras) under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes and no trace domain, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; both counters are KiB, and on gfx950 FETCH_SIZE reports half
@@ -195,13 +200,26 @@ def measure_traffic_live(timeout_s: float = 240.0):
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, ctr)
+            # the SAME workload as this run (frames / streams forwarded); a fresh child process, never a re-exec of
+            # this GPU-initialised one; its own session, so that a timeout ends the profiled grandchild as well
             cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", sys.executable,
-                   os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "2", "--warmup", "1"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                   os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "2", "--warmup", "1",
+                   "--frames", str(frames), "--streams", str(streams)]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc_child = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)     # the session this Popen created: rocprofv3 + its child
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                return None, f"rocprofv3 --pmc {ctr}: timed out after {timeout_s:.0f} s (process group ended)"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not files:
-                return None, f"rocprofv3 --pmc {ctr}: no counter file (exit {r.returncode})"
+                return None, f"rocprofv3 --pmc {ctr}: no counter file (exit {rc_child})"
             agg = collections.defaultdict(list)
             for f in files:
                 with open(f) as fh:
@@ -233,6 +251,58 @@ def make_processor(ohs, S, nb, irs, coeffs, enabled, device_index):
     return bp
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N child ranks of this script -- fresh
+    processes, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would -- relay
+    rank 0's single JSON line (its stdout IS this process's stdout; the other ranks' stdout goes to stderr) and exit
+    with the worst child status.  This parent imports no torch and never initialises the GPU; nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OHS_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst, failed_at = 0, None
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = max(worst, rc if rc > 0 else 128 - rc)
+                if failed_at is None:
+                    failed_at = time.monotonic()
+                    print(f"bench.py: rank {r} exited with status {rc}; giving the other ranks 30 s", file=sys.stderr)
+        if failed_at is not None and pending and time.monotonic() - failed_at > 30.0:
+            for r in sorted(pending):           # exactly the processes started above, nothing by pattern
+                procs[r].kill()
+        time.sleep(0.05)
+    return worst
+
+
+# one MI355X, ms per headline step by streams per GPU (profiles/r03_eq_share.txt, run 4): what strong scaling of a
+# 2048-stream job must look like, whatever the fabric does -- the step time is one EQ chain's serial time up to ~1000
+# streams per GPU, so fewer streams per GPU do not make a step shorter
+STEP_MS_BY_STREAMS = {256: 6.07, 512: 5.96, 1024: 7.37, 1536: 9.14, 2048: 11.39, 4096: 23.33}
+
+
+def expected_step_ms(streams: int) -> float:
+    pts = sorted(STEP_MS_BY_STREAMS.items())
+    if streams <= pts[0][0]:
+        return pts[0][1]
+    for (s0, t0), (s1, t1) in zip(pts, pts[1:]):
+        if streams <= s1:
+            return t0 + (t1 - t0) * (streams - s0) / (s1 - s0)
+    return pts[-1][1] * streams / pts[-1][0]
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,17 +319,33 @@ def main() -> int:
                     help="take roofline.traffic from profiles/pmc_latest.json instead of measuring it in two rocprofv3 child runs")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args.gpus)           # (before torch is imported: the parent never touches the GPU)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    # every rank checks the sharding BEFORE the process group exists, so that a bad job size fails on all ranks
+    # together instead of leaving the others in a barrier
+    if args.total_streams > 0 and args.total_streams < world:
+        if rank == 0:
+            print(f"bench.py: --total-streams {args.total_streams} < {world} ranks: a rank would have no stream",
                   file=sys.stderr)
         return 2
+    if args.total_streams <= 0 and args.streams < 1:
+        if rank == 0:
+            print("bench.py: --streams must be >= 1", file=sys.stderr)
+        return 2
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         return 2
@@ -293,9 +379,7 @@ def main() -> int:
     total_streams = args.total_streams if strong else args.streams * world
     ids = sharding.shard_range(total_streams, rank, world)       # this rank's contiguous stream ids
     S = len(ids)
-    if S == 0:
-        print(f"bench.py: rank {rank} has no streams ({total_streams} streams over {world} ranks)", file=sys.stderr)
-        return 2
+    assert S > 0        # (checked above, before the process group was created)
     bands = synth.eq_table()
     nb = len(bands)
 
@@ -338,7 +422,19 @@ def main() -> int:
     eq_ms, conv_ms, n_calls, eq_launches, conv_launches = bp.profile_read()
     bp.set_profiling(False)
 
+    rank_records = None
     if distributed:
+        # proof of placement: what THIS rank ran on, gathered from every rank (the driver's scaling run must show N
+        # distinct devices, not N ranks on one)
+        props = torch.cuda.get_device_properties(dev_index)
+        bus = getattr(props, "pci_bus_id", None)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": props.name,
+                "pci_bus_id": None if bus is None else f"{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:"
+                                                       f"{getattr(props, 'pci_device_id', 0):02x}",
+                "uuid": str(getattr(props, "uuid", "")) or None, "streams": S, "stream_ids": [ids.start, ids.stop],
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "pid": os.getpid()}
+        rank_records = [None] * world
+        dist.all_gather_object(rank_records, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device=bcast_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -443,6 +539,20 @@ def main() -> int:
             },
             "finite": ok,
         }
+        if rank_records is not None:
+            out["launcher"] = os.environ.get("OHS_BENCH_LAUNCHER", "torch.distributed.run or equivalent")
+            out["dist_backend"] = backend + (" (= RCCL on ROCm)" if backend == "nccl" else " (rehearsal: ranks may share a GPU)")
+            out["rccl_world_size"] = dist.get_world_size()
+            out["ranks"] = rank_records
+            out["distinct_devices"] = len({r["uuid"] or r["pci_bus_id"] or (r["device_index"],) for r in rank_records})
+        if strong:
+            t1, tn = expected_step_ms(total_streams), expected_step_ms(S)
+            out["expected_strong_scaling"] = {
+                "x_vs_one_gpu": round(t1 / tn, 2), "expected_ms_per_step": round(tn, 2), "one_gpu_ms_per_step": round(t1, 2),
+                "why": "per-GPU step time is one EQ chain's serial recurrence (~6 ms) up to ~1000 streams per GPU, so "
+                       f"{total_streams} streams on {world} GPU(s) = {S} per GPU cannot beat that floor: a property of "
+                       "the IIR, not of the fabric (the data path has no collective); table: one-GPU measurements, "
+                       "profiles/r03_eq_share.txt"}
 
     # ---- extras, N = 1 only, after the timed region ----
     if world == 1 and not args.no_extras and not strong:
@@ -521,7 +631,7 @@ def main() -> int:
         # roofline.traffic measured now (two rocprofv3 --pmc child runs of this script); the committed summary
         # stays the fallback and is named as such
         if not args.no_live_pmc:
-            live, src = measure_traffic_live()
+            live, src = measure_traffic_live(frames, args.streams)
             if live is not None and out is not None:
                 rf = out["roofline"]
                 if rf.get("kernel") in live:

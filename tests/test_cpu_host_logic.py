@@ -217,3 +217,22 @@ def test_kernel_register_budgets(lib):
     for macro, lines in (("EQ_RING2_MAIN", gen.gen_main()), ("EQ_RING2_HEAD_NOLOAD", gen.gen(first_step=16, loads=False))):
         body = f"#define {macro} \\\n" + " \\\n".join('    "' + l + '\\n"' for l in lines) + "\n"
         assert body in inc, f"{macro}: eq_ring2_asm.inc is not what tools/gen_eq_ring2_asm.py writes"
+
+
+def test_bench_self_launch_plumbing_without_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts two ranks of itself and returns the worst
+    child status.  Without a GPU every rank refuses (exit 2, no CPU fallback) -- which exercises the launcher, the
+    environment it builds and the status relay here; the GPU rehearsal is tests/test_gpu_bench_rehearsal.py."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here: covered by the GPU rehearsal")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-2000:])
+    assert r.stderr.count("no GPU visible") == 2, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a job with fewer streams than ranks fails on every rank before any process group exists
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-streams", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "a rank would have no stream" in r.stderr

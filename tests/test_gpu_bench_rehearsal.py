@@ -1,6 +1,8 @@
 """Rehearsal of the driver's multi-rank bench run on a ONE-GPU box: bench.py itself (not a helper) is launched
-with torch.distributed.run at world size 2, OHS_BENCH_DIST_BACKEND=gloo (table broadcast and barriers over
-gloo, both ranks on cuda:0), in weak and in strong (--total-streams) mode.  Checks the argument / environment /
+at world size 2 -- through torch.distributed.run AND through its own launcher (`python bench.py --gpus 2` with no
+WORLD_SIZE in the environment: the parent starts the ranks itself and never touches the GPU) --,
+OHS_BENCH_DIST_BACKEND=gloo (table broadcast and barriers over gloo, both ranks on cuda:0), in weak and in strong
+(--total-streams) mode.  Checks the argument / environment /
 barrier plumbing, that the rank shards are disjoint and cover the job, and that every rank's outputs equal the
 single-rank run of the same stream ids bit for bit (streams share only read-only tables: SURVEY section 8e)."""
 import json
@@ -16,11 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--steps", "2", "--warmup", "1", "--frames", "20480", "--no-cpu-baseline", "--no-extras"]
 
 
-def _run(tmp_path, tag, world, extra, port):
+def _run(tmp_path, tag, world, extra, port, launcher="torchrun"):
     dump = str(tmp_path / tag)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OHS_BENCH_DIST_BACKEND="gloo", OHS_BENCH_DUMP=dump)
-    if world == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *COMMON, *extra]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "OHS_BENCH_LAUNCHER"):
+        env.pop(k, None)
+    if world == 1 or launcher == "self":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), *COMMON, *extra]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
@@ -37,14 +41,21 @@ def _run(tmp_path, tag, world, extra, port):
     return rec, shards
 
 
-@pytest.mark.parametrize("mode", ["weak", "strong"])
-def test_bench_two_ranks_on_one_gpu_matches_single_rank(tmp_path, mode):
+@pytest.mark.parametrize("launcher,mode", [("torchrun", "weak"), ("torchrun", "strong"), ("self", "weak"), ("self", "strong")])
+def test_bench_two_ranks_on_one_gpu_matches_single_rank(tmp_path, launcher, mode):
     if mode == "weak":
         two, one = ["--streams", "6"], ["--streams", "12"]
     else:
         two, one = ["--total-streams", "12"], ["--total-streams", "12"]
-    rec2, sh2 = _run(tmp_path, "w2" + mode, 2, two, 29541 if mode == "weak" else 29543)
+    rec2, sh2 = _run(tmp_path, "w2" + mode, 2, two, 29541 if mode == "weak" else 29543, launcher)
     rec1, sh1 = _run(tmp_path, "w1" + mode, 1, one, 0)
+    # placement evidence gathered from every rank (here both ranks share cuda:0: ONE distinct device)
+    assert rec2["rccl_world_size"] == 2 and len(rec2["ranks"]) == 2 and rec2["distinct_devices"] == 1
+    assert [r["rank"] for r in rec2["ranks"]] == [0, 1] and [r["streams"] for r in rec2["ranks"]] == [6, 6]
+    assert rec2["ranks"][0]["pid"] != rec2["ranks"][1]["pid"]
+    assert (rec2["launcher"] == "self") == (launcher == "self")
+    assert ("expected_strong_scaling" in rec2) == (mode == "strong")
+    assert "ranks" not in rec1
     assert rec2["n_gpus"] == 2 and rec1["n_gpus"] == 1
     assert rec2["scaling"] == mode and rec2["config"]["total_streams"] == 12
     assert rec2["config"]["streams_per_gpu"] == 6 and rec2["finite"] and rec2["value"] > 0
