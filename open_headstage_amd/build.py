@@ -115,7 +115,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or _read_obj_hash(obj) != want[src]:
-            cmd = [hipcc, *COMMON, *extra, *EXTRA_DEFS, "-Rpass-analysis=kernel-resource-usage", "-c",
+            cmd = [hipcc, *COMMON, *extra, *EXTRA_DEFS, "-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics", "-c",
                    os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))

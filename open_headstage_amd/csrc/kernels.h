@@ -113,6 +113,8 @@ struct ConvP1Args {
     const float2 *tw;
     float gain;
     int stagger;                // wave w of a workgroup starts its block loop w * stagger * 64 cycles late (0 = off)
+    int prio_mode;              // issue priority of the waves: 0 = hardware default (oldest first), 1 = rotating per block
+    int weights[4];             // relative length of a chunk by the age rank of the wave that runs it (conv_kernels.hip: p1_chunk_begin)
 };
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
 int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)

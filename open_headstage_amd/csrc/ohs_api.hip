@@ -10,6 +10,7 @@
 #include "host_internal.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cctype>
 #include <cmath>
@@ -275,7 +276,7 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
             if (eff >= 0.97) break;
         }
     }
-    if (K > n_blocks - 1) K = n_blocks - 1;                        // the last block belongs to the pre-pass
+    if (K > n_blocks) K = n_blocks;
     if (K < 1) K = 1;
     return K;
 }
@@ -317,6 +318,24 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         a.tw = ctx->d_tw; a.gain = gain;
         const char *env_sg = getenv("OHS_P1_STAGGER");          // tuning experiments
         a.stagger = env_sg ? atoi(env_sg) : 0;
+        const char *env_pr = getenv("OHS_P1_PRIO");             // tuning experiments: 1 = rotate the issue priority per block
+        a.prio_mode = env_pr ? atoi(env_pr) : 0;
+        // chunk lengths by age rank of the wave (p1_chunk_begin); equal lengths when chunks are short
+        static const std::array<int, 4> kWeights = [] {
+            std::array<int, 4> w = {1425, 1128, 825, 622};
+            if (const char *e = getenv("OHS_P1_WEIGHTS")) {     // tuning experiments: "w0,w1,w2,w3"
+                int v[4];
+                if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 &&
+                    v[3] > 0 && v[0] < 100000 && v[1] < 100000 && v[2] < 100000 && v[3] < 100000)
+                    w = {v[0], v[1], v[2], v[3]};
+            }
+            return w;
+        }();
+        const int wmin = std::min(std::min(kWeights[0], kWeights[1]), std::min(kWeights[2], kWeights[3]));
+        const int wsum = kWeights[0] + kWeights[1] + kWeights[2] + kWeights[3];
+        // every chunk must keep >= 2 blocks: mean length x (smallest weight / mean weight) >= 2
+        const bool weighted = (long long)n_blocks * 4 * wmin >= 2ll * K * wsum;
+        for (int g = 0; g < 4; ++g) a.weights[g] = weighted ? kWeights[(size_t)g] : 1;
         hipError_t e = launch_conv_p1(a, st);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
         std::swap(c.d_tails, c.d_tails_alt);
