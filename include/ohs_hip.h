@@ -119,17 +119,26 @@ int  ohs_engine_silent_frames(const ohs_engine *e, uint64_t *frames);
 typedef struct ohs_eq ohs_eq;
 
 /* biquad::Coefficients::<f32>::from_params as called at parametric_eq.rs:64-70,105-111;
- * out = {b0,b1,b2,a1,a2} normalised by a0.  gain_db is used by Peak/LowShelf/HighShelf only. */
+ * out = {b0,b1,b2,a1,a2} normalised by a0.  gain_db is used by Peak/LowShelf/HighShelf only.
+ * A CONVENIENCE, NOT A PARITY PATH: the formulas are the crate's, and sinf / cosf / powf are a restatement of the
+ * `libm` crate 0.1.4 the reference links (a port of musl's routines; csrc/libm_musl.h) rather than the host's libm,
+ * so the result is the same on every host -- but whether it equals the crate's last bit cannot be checked here
+ * (parity unpinned), and ONE ulp in ONE coefficient moves the EQ's output by up to 2e-4 relative RMS.  A host that
+ * must match the reference to 1e-6 computes the coefficients with the `biquad` crate and passes them to
+ * ohs_eq_set_band_coeffs / ohs_batch_set_eq_band_coeffs. */
 int  ohs_biquad_coeffs(int filter_type, float fs, float fc, float q, float gain_db, float out[5]);
 /* StereoParametricEQ::new(num_bands, fs)  parametric_eq.rs:132-142: every band
  * PeakingEQ 0 dB @ 20 Hz Q 0.707, disabled (:63-76). */
 int  ohs_eq_create(int device, size_t num_bands, float fs, ohs_eq **out);
 void ohs_eq_destroy(ohs_eq *eq);
 /* update_band_coeffs(band_idx, sample_rate, &BandConfig)  parametric_eq.rs:144-164.
- * band >= num_bands is ignored (returns OHS_OK).  State (s1,s2) is kept (:112). */
+ * band >= num_bands is ignored (returns OHS_OK).  State (s1,s2) is kept (:112).
+ * Coefficients by ohs_biquad_coeffs: convenience, NOT within 1e-6 of the reference unless that restatement agrees
+ * with the `biquad` crate bit for bit (unpinned) -- see ohs_biquad_coeffs; the parity path is ohs_eq_set_band_coeffs. */
 int  ohs_eq_update_band(ohs_eq *eq, size_t band, float fs, int filter_type, float fc, float q,
                         float gain_db, int enabled);
-/* Same, but the host supplies biquad-crate coefficients so the bits are its own. */
+/* The parity path: the host supplies the coefficients (the `biquad` crate's, in the reference's shim), so the bits
+ * are the reference's own; the kernel is bit-exact given them. */
 int  ohs_eq_set_band_coeffs(ohs_eq *eq, size_t band, const float coeffs[5], int enabled);
 int  ohs_eq_get_band_coeffs(const ohs_eq *eq, size_t band, float coeffs[5], int *enabled);
 /* process_block(&mut [f32], &mut [f32]) in place  parametric_eq.rs:166-179.  Same products and sums
@@ -232,6 +241,7 @@ void ohs_batch_destroy(ohs_batch *b);
 /* set_ir semantics of convolution.rs:111-139 applied to every stream. `ir` is a HOST pointer. */
 int  ohs_batch_set_ir(ohs_batch *b, int path, const float *ir, size_t len);
 int  ohs_batch_set_eq_band_coeffs(ohs_batch *b, size_t band, const float coeffs[5], int enabled);
+/* convenience (coefficients by ohs_biquad_coeffs: not a parity path, see there) */
 int  ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_type, float fc,
                               float q, float gain_db, int enabled);
 /* eq_enable / output gain of lib.rs:1179,1202 */

@@ -49,7 +49,9 @@ def _units():
         ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
         ("sofa_conditioning.cpp", ["-x", "hip"]),   # host-only C++ (libmysofa-style loudness / interpolation)
         ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
-        ("biquad_coeffs.cpp", ["-x", "hip"]),   # host-only C++ (RBJ coefficient formulas)
+        # host-only C++ (RBJ coefficient formulas + the musl restatement of sinf / cosf / powf: every operation rounds
+        # by itself)
+        ("biquad_coeffs.cpp", ["-x", "hip", "-ffp-contract=off"]),
     ]
 
 

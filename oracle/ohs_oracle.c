@@ -8,6 +8,7 @@
  * bit-for-bit with every product and sum rounded separately.
  */
 #include "ohs_oracle.h"
+#include "libm_musl.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -282,8 +283,9 @@ void ohs_or_engine_process_block(ohs_or_engine *e, const float *in_l, const floa
 /* biquad 0.4.2 Coefficients::<f32>::from_params (call sites                  */
 /* parametric_eq.rs:64-70,105-111), restated from the published crate.        */
 /* All arithmetic is f32, evaluated left to right as the crate writes it.     */
-/* libm 0.1.4's sinf/cosf/powf are restated by this platform's libm           */
-/* (parity unpinned at the last-ulp level, see header).                       */
+/* libm 0.1.4's sinf/cosf/powf (a port of musl's) are restated in             */
+/* oracle/libm_musl.h, not taken from this platform's libm (parity unpinned   */
+/* at the last-ulp level all the same: the crate is not on this machine).     */
 /* ------------------------------------------------------------------------- */
 int ohs_or_biquad_coeffs(int filter_type, float fs, float fc, float q, float gain_db, float out[5])
 {
@@ -292,8 +294,8 @@ int ohs_or_biquad_coeffs(int filter_type, float fs, float fc, float q, float gai
 
     const float pi = 3.14159265358979323846264338327950288f;
     const float omega = 2.0f * pi * fc / fs;
-    const float omega_s = sinf(omega);
-    const float omega_c = cosf(omega);
+    const float omega_s = ohs_musl_sinf(omega);
+    const float omega_c = ohs_musl_cosf(omega);
     const float alpha = omega_s / (2.0f * q);
     float b0, b1, b2, a0, a1, a2;
 
@@ -319,7 +321,7 @@ int ohs_or_biquad_coeffs(int filter_type, float fs, float fc, float q, float gai
         a0 = 1.0f + alpha; a1 = -2.0f * omega_c; a2 = 1.0f - alpha;
         break;
     case OHS_OR_LOWSHELF: {
-        const float a = powf(10.0f, gain_db / 40.0f);
+        const float a = ohs_musl_powf(10.0f, gain_db / 40.0f);
         const float sa = sqrtf(a);
         b0 = a * ((a + 1.0f) - (a - 1.0f) * omega_c + 2.0f * alpha * sa);
         b1 = 2.0f * a * ((a - 1.0f) - (a + 1.0f) * omega_c);
@@ -329,7 +331,7 @@ int ohs_or_biquad_coeffs(int filter_type, float fs, float fc, float q, float gai
         a2 = (a + 1.0f) + (a - 1.0f) * omega_c - 2.0f * alpha * sa;
         break; }
     case OHS_OR_HIGHSHELF: {
-        const float a = powf(10.0f, gain_db / 40.0f);
+        const float a = ohs_musl_powf(10.0f, gain_db / 40.0f);
         const float sa = sqrtf(a);
         b0 = a * ((a + 1.0f) + (a - 1.0f) * omega_c + 2.0f * alpha * sa);
         b1 = -2.0f * a * ((a - 1.0f) + (a + 1.0f) * omega_c);
@@ -340,7 +342,7 @@ int ohs_or_biquad_coeffs(int filter_type, float fs, float fc, float q, float gai
         break; }
     case OHS_OR_PEAK:
     default: {
-        const float a = powf(10.0f, gain_db / 40.0f);
+        const float a = ohs_musl_powf(10.0f, gain_db / 40.0f);
         b0 = 1.0f + alpha * a; b1 = -2.0f * omega_c; b2 = 1.0f - alpha * a;
         a0 = 1.0f + alpha / a; a1 = -2.0f * omega_c; a2 = 1.0f - alpha / a;
         break; }

@@ -27,8 +27,9 @@ def build(force: bool = False) -> str:
     """Compile oracle/ohs_oracle.c -> libohs_oracle.so (gcc, -ffp-contract=off)."""
     src = os.path.join(_HERE, "ohs_oracle.c")
     hdr = os.path.join(_HERE, "ohs_oracle.h")
+    libm = os.path.join(_HERE, "libm_musl.h")
     stale = (not os.path.exists(_SO)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr)
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr, libm)
     )
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B", "libohs_oracle.so"], check=True,
@@ -43,7 +44,8 @@ def build_native() -> str:
     only the vectorisation differs."""
     out = os.path.join(_HERE, "libohs_oracle_native.so")
     src = os.path.join(_HERE, "ohs_oracle.c")
-    if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+    libm = os.path.join(_HERE, "libm_musl.h")
+    if not os.path.exists(out) or max(os.path.getmtime(src), os.path.getmtime(libm)) > os.path.getmtime(out):
         subprocess.run(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11",
                         "-shared", "-o", out, src, "-lm"], check=True)
     return out

@@ -244,6 +244,43 @@ def test_eq_coefficients_match_oracle_restatement(ohs, synth, oracle):
         biquad_coefficients(FilterType.Peak, 48000.0, 1000.0, -1.0, 0.0)
 
 
+def test_eq_one_ulp_in_one_coefficient_moves_the_output_beyond_1e_6(ohs, synth, oracle):
+    """Why the EQ's coefficients must be the reference's BITS: with the bench's 10-band table, one coefficient of one
+    band changed by one ulp moves 96 000 output samples by far more than the 1e-6 parity bar (the low-frequency
+    sections have poles at 1 - 1e-3 ... 1 - 1e-2: coefficient noise is amplified by 1 / (1 + a1 + a2)).  This is what
+    INTEGRATION.md section 4 rests on: a host that needs the reference's output hands ohs_eq_set_band_coeffs the
+    `biquad` crate's own coefficients; ohs_eq_update_band (this library's restatement of the crate's libm) is a
+    convenience whose parity with the crate is unpinned."""
+    bands = synth.eq_table()
+    n = 96000
+    x = synth.white_noise([11], n)[0]
+
+    def run(perturb):
+        eq = ohs.StereoParametricEQ.new(len(bands), 48000.0)
+        for i, b in enumerate(bands):
+            eq.update_band_coeffs(i, 48000.0, b)
+        if perturb is not None:
+            band, k = perturb
+            c, en = eq.get_band_coeffs(band)
+            c = c.copy()
+            c[k] = np.nextafter(c[k], np.float32(np.inf), dtype=np.float32)
+            eq.set_band_coeffs(band, c, en)
+        l, r = x[0].copy(), x[1].copy()
+        eq.process_block(l, r)
+        return np.stack([l, r]).astype(np.float64)
+
+    ref = run(None)
+    assert np.array_equal(run(None), ref)                       # the experiment itself is deterministic
+    rms = float(np.sqrt(np.mean(ref ** 2)))
+    moved = {}
+    for name, perturb in (("band 0 a1", (0, 3)), ("band 0 b0", (0, 0)), ("band 1 a1", (1, 3)), ("band 5 a1", (5, 3))):
+        d = run(perturb) - ref
+        moved[name] = float(np.sqrt(np.mean(d ** 2))) / rms
+    print("relative RMS change per one-ulp coefficient change:", {k: f"{v:.2e}" for k, v in moved.items()})
+    assert moved["band 0 a1"] > 1e-5 and moved["band 0 b0"] > 1e-5 and moved["band 1 a1"] > 1e-5, moved
+    assert all(v > 1e-6 for v in moved.values()), moved
+
+
 def test_eq_frequency_response(ohs, synth, oracle):
     eg, eo = _mk_eqs(ohs, oracle, synth.eq_table())
     f = np.geomspace(20.0, 20000.0, 64).astype(np.float32)
