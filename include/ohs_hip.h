@@ -44,7 +44,8 @@ enum {
     OHS_ERR_NEGATIVE_Q = 5,       /* biquad::Errors::NegativeQ */
     OHS_ERR_ALLOC = 6,
     OHS_ERR_IO = 7,               /* a file could not be opened / read */
-    OHS_ERR_PARSE = 8             /* malformed CSV / unsupported filter type; see ohs_last_error() */
+    OHS_ERR_PARSE = 8,            /* malformed CSV / unsupported filter type; see ohs_last_error() */
+    OHS_ERR_RCCL = 9              /* librccl.so could not be loaded, or an RCCL call failed; see ohs_last_error() */
 };
 
 /* ConvolutionPath discriminants -- src/dsp/convolution.rs:28-33.
@@ -288,6 +289,45 @@ int  ohs_batch_algorithmic_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *
  * call (P = 1: 16 B per frame + chunk-boundary tails + state; it writes no history and keeps overlaps in
  * registers) -- the numerator of a kernel's own HBM fraction, next to rocprofv3's measured bytes */
 int  ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_bytes, uint64_t *conv_bytes);
+
+/* ---- the batch mode over the GPUs of one node (north_star: 2048 streams over 8 MI355X) ----- */
+/* One process, n_devices GPUs.  The job's streams_total independent stereo streams are cut into contiguous,
+ * balanced id ranges (the first streams_total % n_devices devices get one more -- what every rank of bench.py
+ * computes for itself), one ohs_batch per device.  The data path has NO collective: all mutable state is per stream
+ * (convolution.rs:36-42,76-79; parametric_eq.rs:125-129).  The only exchange is the shared tables: they are uploaded
+ * to the first device and reach the others by ONE ncclBroadcast over xGMI (RCCL, loaded from librccl.so when the
+ * first node batch is created -- hosts that stay on one GPU never load it; communicators from ncclCommInitAll).
+ * `devices` lists the HIP device indices (NULL = 0 .. n_devices - 1).  Same threading rule as every handle. */
+typedef struct ohs_node_batch ohs_node_batch;
+int  ohs_node_batch_create(int n_devices, const int *devices, size_t streams_total, size_t num_bands,
+                           ohs_node_batch **out);
+void ohs_node_batch_destroy(ohs_node_batch *nb);
+/* the shard of device slot `slot` (0 .. n_devices - 1): HIP device index, first stream id, number of streams */
+int  ohs_node_batch_shard(const ohs_node_batch *nb, int slot, int *device, size_t *first_stream, size_t *n_streams);
+/* the per-device handle, for callers that keep their audio in device memory: ohs_batch_process(handle, ...) on that
+ * device with that shard's streams.  Owned by the node batch. */
+int  ohs_node_batch_device_batch(ohs_node_batch *nb, int slot, ohs_batch **out);
+/* All shared tables at once: four impulse responses (HOST pointers, lens[p] == 0 => that path is muted) and the EQ
+ * table (coeffs: num_bands x {b0,b1,b2,a1,a2}, enabled: num_bands ints; both may be NULL = leave the EQ table as
+ * it is).  Packed, copied to the first device, ONE ncclBroadcast, unpacked on every device: set_ir semantics of
+ * convolution.rs:111-139 for all four paths of every stream, ohs_batch_set_eq_band_coeffs for every band. */
+int  ohs_node_batch_set_tables(ohs_node_batch *nb, const float *const irs[4], const size_t lens[4],
+                               const float *eq_coeffs, const int *eq_enabled);
+/* one path in mid-stream (one broadcast of that impulse response) */
+int  ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t len);
+/* host-side settings, applied to every device's handle (no device traffic: kernel arguments) */
+int  ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const float coeffs[5], int enabled);
+int  ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable);
+int  ohs_node_batch_set_gain(ohs_node_batch *nb, float gain);
+int  ohs_node_batch_reset(ohs_node_batch *nb);
+/* ohs_batch_process_host for the whole job: h_in / h_out hold ALL streams_total streams (same planar layout and
+ * strides); every device runs the three-stage host pipeline on its shard from a thread of its own.  Blocking.
+ * Pinned host memory must be visible to every device (hipHostMallocPortable).  Results are bit-identical to
+ * ohs_batch_process_host on one device with the same chunk_blocks: streams do not interact. */
+int  ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h_out, size_t n_blocks,
+                                 size_t stream_stride, size_t channel_stride, size_t chunk_blocks);
+/* what RCCL reports for the communicators in use: ncclCommCount of slot 0's, and 1 if librccl.so is loaded */
+int  ohs_node_batch_rccl_info(const ohs_node_batch *nb, int *comm_size, int *rccl_loaded);
 
 #ifdef __cplusplus
 }

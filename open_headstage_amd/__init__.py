@@ -8,11 +8,11 @@ contains no CPU compute path.
 """
 from .dsp import (BLOCK_SIZE, FFT_SIZE, NUM_EQ_BANDS, BandConfig, ConvolutionEngine, ConvolutionPath,
                   FilterType, StereoParametricEQ, biquad_coefficients, process_chain)
-from .batch import BatchProcessor
+from .batch import BatchProcessor, NodeBatchProcessor
 from .autoeq import BandSetting, apply_bands, parse_autoeq_csv, parse_autoeq_csv_text
 from ._ffi import OhsError
 
 __all__ = ["BLOCK_SIZE", "FFT_SIZE", "NUM_EQ_BANDS", "BandConfig", "ConvolutionEngine",
            "ConvolutionPath", "FilterType", "StereoParametricEQ", "biquad_coefficients",
-           "process_chain", "BatchProcessor", "OhsError", "BandSetting", "apply_bands",
+           "process_chain", "BatchProcessor", "NodeBatchProcessor", "OhsError", "BandSetting", "apply_bands",
            "parse_autoeq_csv", "parse_autoeq_csv_text"]

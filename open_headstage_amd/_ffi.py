@@ -21,6 +21,7 @@ OHS_ERR_NEGATIVE_Q = 5
 OHS_ERR_ALLOC = 6
 OHS_ERR_IO = 7
 OHS_ERR_PARSE = 8
+OHS_ERR_RCCL = 9
 
 class BandSettingC(C.Structure):
     """ohs_band_setting (include/ohs_hip.h) = BandSetting, autoeq_parser.rs:34-41"""
@@ -101,6 +102,18 @@ PROTOTYPES = {
                                          C.POINTER(C.c_uint64)]),
     "ohs_batch_algorithmic_bytes": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_uint64)]),
     "ohs_batch_kernel_bytes": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ohs_node_batch_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_size_t, C.c_size_t, vpp]),
+    "ohs_node_batch_destroy": (None, [vp]),
+    "ohs_node_batch_shard": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ohs_node_batch_device_batch": (C.c_int, [vp, C.c_int, vpp]),
+    "ohs_node_batch_set_tables": (C.c_int, [vp, C.POINTER(fp), C.POINTER(C.c_size_t), fp, C.POINTER(C.c_int)]),
+    "ohs_node_batch_set_ir": (C.c_int, [vp, C.c_int, fp, C.c_size_t]),
+    "ohs_node_batch_set_eq_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.c_int]),
+    "ohs_node_batch_set_eq_enabled": (C.c_int, [vp, C.c_int]),
+    "ohs_node_batch_set_gain": (C.c_int, [vp, C.c_float]),
+    "ohs_node_batch_reset": (C.c_int, [vp]),
+    "ohs_node_batch_process_host": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "ohs_node_batch_rccl_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 

@@ -143,3 +143,104 @@ class BatchProcessor:
                 lib().ohs_batch_destroy(h)
             except Exception:
                 pass
+
+
+class NodeBatchProcessor:
+    """The batch mode over the GPUs of one node in ONE process (ohs_node_batch_*, include/ohs_hip.h): contiguous
+    stream-id shards, one per-device batch each, the shared tables carried from the first device to the others by one
+    RCCL broadcast inside the library.  Host mirror of what a Rust host binds."""
+
+    def __init__(self, streams_total: int, num_bands: int = 10, devices=None, n_devices: int | None = None):
+        if devices is None:
+            if n_devices is None:
+                raise ValueError("give devices=[...] or n_devices=N")
+            arr, n = None, int(n_devices)
+        else:
+            devices = [int(d) for d in devices]
+            n = len(devices)
+            arr = (C.c_int * n)(*devices)
+        self.streams_total = int(streams_total)
+        self.num_bands = int(num_bands)
+        self.n_devices = n
+        h = C.c_void_p()
+        check(lib().ohs_node_batch_create(n, arr, self.streams_total, self.num_bands, C.byref(h)))
+        self._h = h
+
+    def shard(self, slot: int):
+        """(HIP device index, first stream id, number of streams) of device slot `slot`"""
+        d, f, c = C.c_int(), C.c_size_t(), C.c_size_t()
+        check(lib().ohs_node_batch_shard(self._h, int(slot), C.byref(d), C.byref(f), C.byref(c)))
+        return int(d.value), int(f.value), int(c.value)
+
+    def set_tables(self, irs, eq_coeffs=None, eq_enabled=None) -> None:
+        """irs: four impulse responses (an empty one mutes its path); eq_coeffs [num_bands, 5] + eq_enabled [num_bands]
+        or both None.  One broadcast carries everything."""
+        arrs = [np.ascontiguousarray(h, dtype=np.float32).ravel() for h in irs]
+        if len(arrs) != 4:
+            raise ValueError("need four impulse responses")
+        ptrs = (fp * 4)(*[a.ctypes.data_as(fp) if a.size else None for a in arrs])
+        lens = (C.c_size_t * 4)(*[a.size for a in arrs])
+        if eq_coeffs is None:
+            check(lib().ohs_node_batch_set_tables(self._h, ptrs, lens, None, None))
+            return
+        c = np.ascontiguousarray(eq_coeffs, dtype=np.float32).reshape(self.num_bands, 5)
+        en = np.ascontiguousarray(np.asarray(eq_enabled).astype(np.int32)).reshape(self.num_bands)
+        check(lib().ohs_node_batch_set_tables(self._h, ptrs, lens, c.ctypes.data_as(fp),
+                                              en.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def set_ir(self, path, ir_data) -> None:
+        ir = np.ascontiguousarray(ir_data, dtype=np.float32).ravel()
+        check(lib().ohs_node_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp) if ir.size else None, ir.size))
+
+    def set_band_coeffs(self, band_idx: int, coeffs, enabled: bool) -> None:
+        c = np.ascontiguousarray(coeffs, dtype=np.float32).ravel()
+        if c.size != 5:
+            raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
+        check(lib().ohs_node_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp), int(bool(enabled))))
+
+    def set_eq_enabled(self, eq_enable: bool) -> None:
+        check(lib().ohs_node_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
+
+    def set_gain(self, gain: float) -> None:
+        check(lib().ohs_node_batch_set_gain(self._h, float(gain)))
+
+    def reset(self) -> None:
+        check(lib().ohs_node_batch_reset(self._h))
+
+    def rccl_info(self):
+        """(size of the RCCL communicator, librccl.so loaded)"""
+        n, ok = C.c_int(), C.c_int()
+        check(lib().ohs_node_batch_rccl_info(self._h, C.byref(n), C.byref(ok)))
+        return int(n.value), bool(ok.value)
+
+    def process_host(self, x, out=None, chunk_blocks: int = 0):
+        """x, out: contiguous float32 HOST buffers [streams_total, 2, frames] (numpy, or torch tensors -- pinned ones
+        must be portable across devices); every device runs its shard from a thread of its own.  Blocking."""
+        is_np = isinstance(x, np.ndarray)
+        if out is None:
+            out = np.empty_like(x) if is_np else x.new_empty(x.shape)
+        S, ch, frames = x.shape
+        if S != self.streams_total or ch != 2 or frames % BLOCK_SIZE:
+            raise ValueError(f"expected [{self.streams_total}, 2, k*{BLOCK_SIZE}], got {tuple(x.shape)}")
+        if tuple(out.shape) != tuple(x.shape):
+            raise ValueError("out must match x")
+        if is_np:
+            if x.dtype != np.float32 or not x.flags.c_contiguous or out.dtype != np.float32 or not out.flags.c_contiguous:
+                raise TypeError("numpy buffers must be contiguous float32")
+            pi, po = x.ctypes.data, out.ctypes.data
+        else:
+            import torch
+            if x.is_cuda or out.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or not out.is_contiguous():
+                raise TypeError("x / out must be contiguous float32 HOST tensors")
+            pi, po = x.data_ptr(), out.data_ptr()
+        check(lib().ohs_node_batch_process_host(self._h, C.c_void_p(pi), C.c_void_p(po), frames // BLOCK_SIZE,
+                                                2 * frames, frames, int(chunk_blocks)))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().ohs_node_batch_destroy(h)
+            except Exception:
+                pass

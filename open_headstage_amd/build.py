@@ -49,6 +49,7 @@ def _units():
         ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
         ("sofa_conditioning.cpp", ["-x", "hip"]),   # host-only C++ (libmysofa-style loudness / interpolation)
         ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
+        ("node_batch.cpp", ["-x", "hip"]),      # host-only C++ (batch mode over the GPUs of a node; RCCL by dlopen)
         # host-only C++ (RBJ coefficient formulas + the musl restatement of sinf / cosf / powf: every operation rounds
         # by itself)
         ("biquad_coeffs.cpp", ["-x", "hip", "-ffp-contract=off"]),
@@ -132,7 +133,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 json.dump(_parse_resource_remarks(remarks), f, indent=1, sort_keys=True)
             with open(obj + ".hash", "w") as f:
                 f.write(want[src])
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz"]
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz", "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,0 +1,326 @@
+// node_batch.cpp -- the offline many-stream batch mode over the GPUs of ONE node, behind the C ABI
+// (BASELINE.json north_star: "shards independent stereo streams across the 8 GPUs of one node with RCCL broadcast of
+// the shared HRIR set over xGMI").  Host-only C++ on top of the public single-device batch API.
+//
+// One process, one ohs_batch per device, contiguous stream-id shards, NO data-path collective (all mutable state is
+// per stream: convolution.rs:36-42,76-79; parametric_eq.rs:125-129).  The one exchange -- the shared tables -- is a
+// real RCCL broadcast: the packed tables are copied to the first device and ncclBroadcast (grouped over the
+// communicators ncclCommInitAll returns) carries them to every other device over xGMI; each device then builds its
+// spectra from its own copy.  librccl.so is loaded with dlopen when the first node batch is created, so the core
+// library has no RCCL dependency and a single-GPU host never loads it.
+#include "../../include/ohs_hip.h"
+#include "host_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and enums only; the functions are looked up in the loaded library
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+int fail(int code, const std::string &m) { ohs_internal_set_error(m.c_str()); return code; }
+
+struct Rccl {
+    void *so = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) {
+            r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.so) break;
+        }
+        if (!r.so) { r.error = std::string("librccl.so could not be loaded: ") + dlerror(); return; }
+        auto sym = [&](const char *n) -> void * {
+            void *p = dlsym(r.so, n);
+            if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n;
+            return p;
+        };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r;
+}
+
+#define NB_HIP(x)                                                                                      \
+    do {                                                                                               \
+        hipError_t e_ = (x);                                                                           \
+        if (e_ != hipSuccess) return fail(OHS_ERR_HIP, std::string(#x ": ") + hipGetErrorString(e_)); \
+    } while (0)
+#define NB_NCCL(x)                                                                                         \
+    do {                                                                                                   \
+        ncclResult_t r_ = (x);                                                                             \
+        if (r_ != ncclSuccess) return fail(OHS_ERR_RCCL, std::string(#x ": ") + rccl().GetErrorString(r_)); \
+    } while (0)
+
+}  // namespace
+
+struct ohs_node_batch {
+    int n = 0;
+    size_t streams_total = 0, num_bands = 0;
+    std::vector<int> dev;
+    std::vector<size_t> first, count;
+    std::vector<ohs_batch *> b;
+    std::vector<ncclComm_t> comm;
+    std::vector<hipStream_t> st;        // one per device, for the broadcasts
+    std::vector<float *> d_tab;         // broadcast buffer per device
+    size_t tab_cap = 0;                 // floats
+};
+
+namespace {
+
+// contiguous, balanced ranges; the first (total % n) shards get one more (open_headstage_amd/sharding.py)
+void shard_range(size_t total, int slot, int n, size_t *first, size_t *count)
+{
+    const size_t q = total / (size_t)n, r = total % (size_t)n;
+    *first = (size_t)slot * q + std::min<size_t>((size_t)slot, r);
+    *count = q + ((size_t)slot < r ? 1 : 0);
+}
+
+int grow_tables(ohs_node_batch *nb, size_t floats)
+{
+    if (floats <= nb->tab_cap) return OHS_OK;
+    size_t cap = nb->tab_cap ? nb->tab_cap : 4096;
+    while (cap < floats) cap *= 2;
+    for (int i = 0; i < nb->n; ++i) {
+        NB_HIP(hipSetDevice(nb->dev[(size_t)i]));
+        NB_HIP(hipStreamSynchronize(nb->st[(size_t)i]));
+        if (nb->d_tab[(size_t)i]) NB_HIP(hipFree(nb->d_tab[(size_t)i]));
+        nb->d_tab[(size_t)i] = nullptr;
+        NB_HIP(hipMalloc(&nb->d_tab[(size_t)i], cap * sizeof(float)));
+    }
+    nb->tab_cap = cap;
+    return OHS_OK;
+}
+
+// host -> first device -> ONE grouped ncclBroadcast -> every device; returns with the data in place everywhere
+int broadcast_from_host(ohs_node_batch *nb, const float *host, size_t floats)
+{
+    if (floats == 0) return OHS_OK;
+    int rc = grow_tables(nb, floats);
+    if (rc) return rc;
+    NB_HIP(hipSetDevice(nb->dev[0]));
+    NB_HIP(hipMemcpyAsync(nb->d_tab[0], host, floats * sizeof(float), hipMemcpyHostToDevice, nb->st[0]));
+    Rccl &R = rccl();
+    NB_NCCL(R.GroupStart());
+    for (int i = 0; i < nb->n; ++i) {
+        const ncclResult_t r = R.Broadcast(nb->d_tab[0], nb->d_tab[(size_t)i], floats, ncclFloat, 0, nb->comm[(size_t)i],
+                                           nb->st[(size_t)i]);
+        if (r != ncclSuccess) { R.GroupEnd(); return fail(OHS_ERR_RCCL, std::string("ncclBroadcast: ") + R.GetErrorString(r)); }
+    }
+    NB_NCCL(R.GroupEnd());
+    for (int i = 0; i < nb->n; ++i) {
+        NB_HIP(hipSetDevice(nb->dev[(size_t)i]));
+        NB_HIP(hipStreamSynchronize(nb->st[(size_t)i]));
+    }
+    return OHS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ohs_node_batch_create(int n_devices, const int *devices, size_t streams_total, size_t num_bands, ohs_node_batch **out)
+{
+    if (!out) return fail(OHS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) return fail(OHS_ERR_INVALID_ARG, "n_devices must be 1..64");
+    if (streams_total < (size_t)n_devices) return fail(OHS_ERR_INVALID_ARG, "fewer streams than devices: a device would have no stream");
+    int have = 0;
+    int rc = ohs_device_count(&have);
+    if (rc) return fail(rc, std::string(ohs_last_error()) + " -- the library has no CPU fallback");
+    std::vector<int> dev((size_t)n_devices);
+    for (int i = 0; i < n_devices; ++i) {
+        dev[(size_t)i] = devices ? devices[i] : i;
+        if (dev[(size_t)i] < 0 || dev[(size_t)i] >= have) return fail(OHS_ERR_INVALID_ARG, "device index out of range");
+        for (int k = 0; k < i; ++k)
+            if (dev[(size_t)k] == dev[(size_t)i]) return fail(OHS_ERR_INVALID_ARG, "a device is listed twice");
+    }
+    Rccl &R = rccl();
+    if (!R.error.empty()) return fail(OHS_ERR_RCCL, R.error);
+    ohs_node_batch *nb = new (std::nothrow) ohs_node_batch;
+    if (!nb) return fail(OHS_ERR_ALLOC, "out of host memory");
+    nb->n = n_devices; nb->streams_total = streams_total; nb->num_bands = num_bands; nb->dev = dev;
+    nb->first.resize((size_t)n_devices); nb->count.resize((size_t)n_devices);
+    nb->b.assign((size_t)n_devices, nullptr); nb->comm.assign((size_t)n_devices, nullptr);
+    nb->st.assign((size_t)n_devices, nullptr); nb->d_tab.assign((size_t)n_devices, nullptr);
+    auto body = [&]() -> int {
+        for (int i = 0; i < n_devices; ++i) {
+            shard_range(streams_total, i, n_devices, &nb->first[(size_t)i], &nb->count[(size_t)i]);
+            int r = ohs_batch_create(dev[(size_t)i], nb->count[(size_t)i], num_bands, &nb->b[(size_t)i]);
+            if (r) return r;
+            NB_HIP(hipSetDevice(dev[(size_t)i]));
+            NB_HIP(hipStreamCreateWithFlags(&nb->st[(size_t)i], hipStreamNonBlocking));
+        }
+        NB_NCCL(R.CommInitAll(nb->comm.data(), n_devices, dev.data()));
+        return OHS_OK;
+    };
+    rc = body();
+    if (rc) { ohs_node_batch_destroy(nb); return rc; }
+    *out = nb;
+    return OHS_OK;
+}
+
+void ohs_node_batch_destroy(ohs_node_batch *nb)
+{
+    if (!nb) return;
+    Rccl &R = rccl();
+    for (int i = 0; i < nb->n; ++i) {
+        hipSetDevice(nb->dev[(size_t)i]);
+        if (nb->st[(size_t)i]) hipStreamSynchronize(nb->st[(size_t)i]);
+        if (nb->comm[(size_t)i] && R.CommDestroy) R.CommDestroy(nb->comm[(size_t)i]);
+        if (nb->d_tab[(size_t)i]) hipFree(nb->d_tab[(size_t)i]);
+        if (nb->st[(size_t)i]) hipStreamDestroy(nb->st[(size_t)i]);
+        if (nb->b[(size_t)i]) ohs_batch_destroy(nb->b[(size_t)i]);
+    }
+    delete nb;
+}
+
+int ohs_node_batch_shard(const ohs_node_batch *nb, int slot, int *device, size_t *first_stream, size_t *n_streams)
+{
+    if (!nb || slot < 0 || slot >= nb->n) return fail(OHS_ERR_INVALID_ARG, "bad node batch / slot");
+    if (device) *device = nb->dev[(size_t)slot];
+    if (first_stream) *first_stream = nb->first[(size_t)slot];
+    if (n_streams) *n_streams = nb->count[(size_t)slot];
+    return OHS_OK;
+}
+
+int ohs_node_batch_device_batch(ohs_node_batch *nb, int slot, ohs_batch **out)
+{
+    if (!nb || !out || slot < 0 || slot >= nb->n) return fail(OHS_ERR_INVALID_ARG, "bad node batch / slot");
+    *out = nb->b[(size_t)slot];
+    return OHS_OK;
+}
+
+int ohs_node_batch_set_tables(ohs_node_batch *nb, const float *const irs[4], const size_t lens[4],
+                              const float *eq_coeffs, const int *eq_enabled)
+{
+    if (!nb || !irs || !lens) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if ((eq_coeffs == nullptr) != (eq_enabled == nullptr)) return fail(OHS_ERR_INVALID_ARG, "eq_coeffs and eq_enabled go together");
+    size_t off[5] = {0, 0, 0, 0, 0};
+    for (int p = 0; p < 4; ++p) {
+        if (lens[p] && !irs[p]) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
+        if (lens[p] > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
+        off[p + 1] = off[p] + lens[p];
+    }
+    const size_t eq_floats = eq_coeffs ? nb->num_bands * 6 : 0;         // 5 coefficients + the enable flag per band
+    std::vector<float> pack(off[4] + eq_floats);
+    for (int p = 0; p < 4; ++p)
+        if (lens[p]) std::memcpy(pack.data() + off[p], irs[p], lens[p] * sizeof(float));
+    for (size_t i = 0; i < (eq_coeffs ? nb->num_bands : 0); ++i) {
+        std::memcpy(pack.data() + off[4] + 6 * i, eq_coeffs + 5 * i, 5 * sizeof(float));
+        pack[off[4] + 6 * i + 5] = eq_enabled[i] ? 1.0f : 0.0f;
+    }
+    int rc = broadcast_from_host(nb, pack.data(), pack.size());
+    if (rc) return rc;
+    std::vector<float> eq_back(eq_floats);
+    for (int i = 0; i < nb->n; ++i) {
+        for (int p = 0; p < 4; ++p) {
+            rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], p, nb->d_tab[(size_t)i] + off[p], lens[p]);
+            if (rc) return rc;
+        }
+        if (eq_floats) {
+            // the EQ table is host-side state of a handle (kernel arguments): every device's handle gets the bits its
+            // OWN device received
+            NB_HIP(hipSetDevice(nb->dev[(size_t)i]));
+            NB_HIP(hipMemcpy(eq_back.data(), nb->d_tab[(size_t)i] + off[4], eq_floats * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < nb->num_bands; ++k) {
+                rc = ohs_batch_set_eq_band_coeffs(nb->b[(size_t)i], k, eq_back.data() + 6 * k, eq_back[6 * k + 5] != 0.0f);
+                if (rc) return rc;
+            }
+        }
+    }
+    return OHS_OK;
+}
+
+int ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t len)
+{
+    if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");
+    if (path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "path must be 0..3");
+    if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
+    if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
+    int rc = broadcast_from_host(nb, ir, len);
+    if (rc) return rc;
+    for (int i = 0; i < nb->n; ++i) {
+        rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], path, nb->d_tab[(size_t)i], len);
+        if (rc) return rc;
+    }
+    return OHS_OK;
+}
+
+#define NB_FOR_EACH(call)                                                         \
+    if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");              \
+    for (int i = 0; i < nb->n; ++i) {                                             \
+        ohs_batch *h = nb->b[(size_t)i];                                          \
+        const int rc = (call);                                                    \
+        if (rc) return rc;                                                        \
+    }                                                                             \
+    return OHS_OK;
+
+int ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const float coeffs[5], int enabled)
+{
+    NB_FOR_EACH(ohs_batch_set_eq_band_coeffs(h, band, coeffs, enabled))
+}
+int ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable) { NB_FOR_EACH(ohs_batch_set_eq_enabled(h, eq_enable)) }
+int ohs_node_batch_set_gain(ohs_node_batch *nb, float gain) { NB_FOR_EACH(ohs_batch_set_gain(h, gain)) }
+int ohs_node_batch_reset(ohs_node_batch *nb) { NB_FOR_EACH(ohs_batch_reset(h)) }
+
+int ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h_out, size_t n_blocks,
+                                size_t stream_stride, size_t channel_stride, size_t chunk_blocks)
+{
+    if (!nb || !h_in || !h_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    std::vector<int> rc((size_t)nb->n, OHS_OK);
+    std::vector<std::string> err((size_t)nb->n);
+    auto work = [&](int i) {
+        const size_t o = nb->first[(size_t)i] * stream_stride;
+        rc[(size_t)i] = ohs_batch_process_host(nb->b[(size_t)i], h_in + o, h_out + o, n_blocks, stream_stride,
+                                               channel_stride, chunk_blocks);
+        if (rc[(size_t)i]) err[(size_t)i] = ohs_last_error();       // (thread-local: carried back to the caller below)
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nb->n; ++i) th.emplace_back(work, i);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < nb->n; ++i)
+        if (rc[(size_t)i]) return fail(rc[(size_t)i], "device slot " + std::to_string(i) + ": " + err[(size_t)i]);
+    return OHS_OK;
+}
+
+int ohs_node_batch_rccl_info(const ohs_node_batch *nb, int *comm_size, int *rccl_loaded)
+{
+    if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");
+    Rccl &R = rccl();
+    if (rccl_loaded) *rccl_loaded = R.so != nullptr && R.error.empty();
+    if (comm_size) {
+        int n = 0;
+        NB_NCCL(R.CommCount(nb->comm[0], &n));
+        *comm_size = n;
+    }
+    return OHS_OK;
+}
+
+}  // extern "C"

@@ -207,8 +207,10 @@ int conv_grow_ring(ConvState &c, int need, hipStream_t st)
     return OHS_OK;
 }
 
-// set_ir (convolution.rs:111-139) for one path; `ir` is a host pointer
-int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st)
+// set_ir (convolution.rs:111-139) for one path; `ir` is a host pointer, or a device pointer on the state's
+// device when ir_on_device (the node-level batch hands over what RCCL has just broadcast)
+int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st,
+                bool ir_on_device = false)
 {
     if (path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "path must be 0..3");
     if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
@@ -223,9 +225,13 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
         if (len == 0) {
             HIP_TRY(hipMemsetAsync(nH, 0, NF * sizeof(float2), st));   // :114-118 mute
         } else {
-            HIP_TRY(hipMalloc(&d_ir, len * sizeof(float)));
-            HIP_TRY(hipMemcpyAsync(d_ir, ir, len * sizeof(float), hipMemcpyHostToDevice, st));
-            HIP_TRY(launch_ir_spectrum(d_ir, (int)len, P, nH, ctx->d_tw, st));
+            const float *src = ir;
+            if (!ir_on_device) {
+                HIP_TRY(hipMalloc(&d_ir, len * sizeof(float)));
+                HIP_TRY(hipMemcpyAsync(d_ir, ir, len * sizeof(float), hipMemcpyHostToDevice, st));
+                src = d_ir;
+            }
+            HIP_TRY(launch_ir_spectrum(src, (int)len, P, nH, ctx->d_tw, st));
         }
         int rc = conv_grow_ring(c, P, st);
         if (rc) return rc;
@@ -1019,6 +1025,7 @@ const char *ohs_status_string(int s)
     case OHS_ERR_ALLOC: return "OHS_ERR_ALLOC";
     case OHS_ERR_IO: return "OHS_ERR_IO";
     case OHS_ERR_PARSE: return "OHS_ERR_PARSE";
+    case OHS_ERR_RCCL: return "OHS_ERR_RCCL";
     default: return "OHS_ERR_UNKNOWN";
     }
 }
@@ -1509,6 +1516,15 @@ int ohs_batch_set_ir(ohs_batch *b, int path, const float *ir, size_t len)
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipDeviceSynchronize());
     return conv_set_ir(b->conv, b->ctx, path, ir, len, b->st);
+}
+
+// node_batch.cpp: the same with the IR already on the batch's device (a broadcast buffer)
+extern "C" int ohs_internal_batch_set_ir_device(ohs_batch *b, int path, const float *d_ir, size_t len)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return conv_set_ir(b->conv, b->ctx, path, d_ir, len, b->st, true);
 }
 
 int ohs_batch_set_eq_band_coeffs(ohs_batch *b, size_t band, const float coeffs[5], int enabled)

@@ -45,7 +45,7 @@ def test_no_cpu_fallback_without_device(lib):
     assert rc == _ffi.OHS_ERR_NO_DEVICE
     import open_headstage_amd as ohs
     for ctor in (lambda: ohs.ConvolutionEngine.new(), lambda: ohs.StereoParametricEQ.new(10, 48000.0),
-                 lambda: ohs.BatchProcessor(4)):
+                 lambda: ohs.BatchProcessor(4), lambda: ohs.NodeBatchProcessor(16, n_devices=2)):
         with pytest.raises(ohs.OhsError) as ei:
             ctor()
         assert ei.value.status == _ffi.OHS_ERR_NO_DEVICE

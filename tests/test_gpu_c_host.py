@@ -50,3 +50,40 @@ def test_c_host_chain_matches_oracle(tmp_path, oracle):
         oracle.chain_process(eng, eq, l, rr, eq_enable=True, gain=0.8912509)
         ref[0, pos:pos + 1024], ref[1, pos:pos + 1024] = l, rr
     assert_parity(y, ref, "C host chain")
+
+
+def test_c_host_node_batch_matches_oracle(tmp_path, oracle):
+    """examples/host_node_batch.c: the node-level batch API (RCCL communicator of the box's one GPU) from a compiled C
+    host, against the oracle."""
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    libdir = os.path.join(ROOT, "open_headstage_amd")
+    exe = str(tmp_path / "host_node_batch")
+    subprocess.run([gcc, "-O2", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "examples", "host_node_batch.c"), "-L" + libdir, "-lohs_hip", "-lm",
+                    "-Wl,-rpath," + libdir], check=True)
+    taps, frames, S = 512, 512 * 40, 5
+    irs = synth.hrir_set(taps)
+    x = synth.white_noise(range(300, 300 + S), frames)
+    np.stack(irs).astype(np.float32).tofile(tmp_path / "irs.f32")
+    x.astype(np.float32).tofile(tmp_path / "in.f32")
+    r = subprocess.run([exe, "1", str(S), str(tmp_path / "irs.f32"), str(taps), str(tmp_path / "in.f32"),
+                        str(tmp_path / "out.f32"), str(frames)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL communicator of 1 rank(s)" in r.stderr and "streams [0, 5)" in r.stderr
+    y = np.fromfile(tmp_path / "out.f32", np.float32).reshape(S, 2, frames)
+    bands = synth.eq_table()
+    for s in range(S):
+        eng = oracle.ConvolutionEngine()
+        for p in range(4):
+            eng.set_ir(p, irs[p])
+        eq = oracle.StereoParametricEQ(len(bands), synth.FS)
+        for i, b in enumerate(bands):
+            eq.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+        l, rr = x[s, 0].copy(), x[s, 1].copy()
+        oracle.chain_process(eng, eq, l, rr, eq_enable=True, gain=0.8912509)
+        assert_parity(y[s], np.stack([l, rr]), f"C node-batch host, stream {s}")
