@@ -115,6 +115,17 @@ int  ohs_engine_latency_samples(const ohs_engine *e, size_t n, size_t *latency);
 int  ohs_engine_debug_rt_stamps(const ohs_engine *e, uint64_t out[16]);
 /* Frames this engine has answered with that silence so far = its current delay in frames. */
 int  ohs_engine_silent_frames(const ohs_engine *e, uint64_t *frames);
+/* Denormal handling of every kernel this handle launches: the reference's unit tests run
+ * with IEEE denormals, but the shipped plugin's Plugin::process (src/lib.rs:1156) runs inside nih-plug's
+ * flush-to-zero scope.  mode 0 (default): IEEE, what the parity tests compare.  mode 1: results that would be
+ * denormal are flushed to signed zero, denormal inputs are still read (x86 MXCSR.FTZ, what nih-plug sets).  mode 2:
+ * denormal inputs are read as zero as well (FTZ | DAZ, what many hosts set on their audio threads).  Set through the
+ * MODE register of each kernel.  In modes 1 and 2 the EQ stays bit-exact against the reference arithmetic run in the
+ * same mode (tests/test_gpu_ftz.py) up to the default (ring) kernel's documented corners, which flushing makes
+ * reachable: a result flushed to -0.0 comes out as +0.0, and a denormal INPUT sample is read as zero also in mode 1
+ * (ohs_eq_set_exact_specials selects the kernel without either).
+ * Also available as ohs_eq_set_flush_denormals and ohs_batch_set_flush_denormals; clones inherit the mode. */
+int  ohs_engine_set_flush_denormals(ohs_engine *e, int mode);
 
 /* ---- StereoParametricEQ  (src/dsp/parametric_eq.rs:125-210) ------------------ */
 typedef struct ohs_eq ohs_eq;
@@ -153,6 +164,7 @@ int  ohs_eq_process_block(ohs_eq *eq, float *left, float *right, size_t n);
  * time of the default kernel.  Audio hosts do not produce such samples; offline jobs that must be bit-exact on
  * arbitrary data switch it on. */
 int  ohs_eq_set_exact_specials(ohs_eq *eq, int enable);
+int  ohs_eq_set_flush_denormals(ohs_eq *eq, int mode);              /* see ohs_engine_set_flush_denormals */
 /* reset_all_bands_state  parametric_eq.rs:181-188 (also Plugin::reset, lib.rs:1152-1154). */
 int  ohs_eq_reset(ohs_eq *eq);
 /* calculate_frequency_response(fs, &[f32]) -> Vec<f32>  parametric_eq.rs:190-209
@@ -248,6 +260,7 @@ int  ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_ty
 /* eq_enable / output gain of lib.rs:1179,1202 */
 int  ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable);
 int  ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable);    /* see ohs_eq_set_exact_specials */
+int  ohs_batch_set_flush_denormals(ohs_batch *b, int mode);         /* see ohs_engine_set_flush_denormals (EQ and convolution) */
 int  ohs_batch_set_gain(ohs_batch *b, float gain);
 /* zero every stream's EQ state, history and overlap (IRs and EQ table kept) */
 int  ohs_batch_reset(ohs_batch *b);

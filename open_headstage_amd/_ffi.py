@@ -60,6 +60,9 @@ PROTOTYPES = {
     "ohs_eq_process_block": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ohs_eq_reset": (C.c_int, [vp]),
     "ohs_eq_set_exact_specials": (C.c_int, [vp, C.c_int]),
+    "ohs_eq_set_flush_denormals": (C.c_int, [vp, C.c_int]),
+    "ohs_engine_set_flush_denormals": (C.c_int, [vp, C.c_int]),
+    "ohs_batch_set_flush_denormals": (C.c_int, [vp, C.c_int]),
     "ohs_batch_set_eq_exact_specials": (C.c_int, [vp, C.c_int]),
     "ohs_eq_frequency_response": (C.c_int, [vp, C.c_float, fp, C.c_size_t, fp]),
     "ohs_autoeq_parse_csv": (C.c_int, [C.c_char_p, C.POINTER(BandSettingC), C.c_size_t,

@@ -48,6 +48,10 @@ class BatchProcessor:
     def set_eq_exact_specials(self, enable: bool) -> None:
         check(lib().ohs_batch_set_eq_exact_specials(self._h, int(bool(enable))))
 
+    def set_flush_denormals(self, mode: int) -> None:
+        """0 = IEEE (default), 1 = FTZ, 2 = FTZ | DAZ for the EQ and the convolution (ohs_batch_set_flush_denormals)"""
+        check(lib().ohs_batch_set_flush_denormals(self._h, int(mode)))
+
     def set_gain(self, gain: float) -> None:
         check(lib().ohs_batch_set_gain(self._h, float(gain)))
 

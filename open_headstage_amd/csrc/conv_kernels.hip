@@ -314,6 +314,7 @@ __device__ __forceinline__ void conv_general_body(const ConvGeneralArgs &A, cons
 
 __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     float2 *lds = smem + kTabComplex;
@@ -501,6 +502,7 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
 __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, const EngineCallArgs E, unsigned *done,
                                                      unsigned seq)
 {
+    ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     __syncthreads();
     ConvGeneralArgs &A = *reinterpret_cast<ConvGeneralArgs *>(s_args);
     EngineCallArgs &E = *reinterpret_cast<EngineCallArgs *>(reinterpret_cast<char *>(s_args) + sizeof(ConvGeneralArgs));
+    ohs_set_fp_mode(A.fp_mode);             // for the kernel's whole life (a change of mode stops it first), its EQ included
     if (threadIdx.x == 0) s_eq_version = 0xffffffffu;       // no EQ block held yet (the host counts from 1)
     // what the kernel keeps in LDS for as long as it lives (anything that changes it on the host side -- set_ir, a
     // launch-per-call block, clone -- stops the kernel first): the engine's overlaps and partition 0 of every path
@@ -918,6 +921,7 @@ extern "C" int ohs_debug_p1_clk(unsigned long long *out, size_t n_waves)
 #endif
 __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 {
+    ohs_set_fp_mode(A.fp_mode);
 #ifdef OHS_P1_STAMPS
     const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1071,6 +1075,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 constexpr int kP1StateWaves = 4;
 __global__ __launch_bounds__(64 * kP1StateWaves) void k_conv_p1_state(const ConvP1Args A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kP1StateWaves);
@@ -1111,6 +1116,7 @@ __global__ __launch_bounds__(64 * kP1StateWaves) void k_conv_p1_state(const Conv
 
 __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Args A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     float2 *cd = smem + kTabComplex;
@@ -1228,6 +1234,7 @@ hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float
 constexpr int kTpWaves = OHS_TP_WAVES;      // LDS: 8.5 KiB + 16 x 8672 B = 144 KiB
 __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_forward(const ConvTpArgs A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kTpWaves);
@@ -1266,6 +1273,7 @@ hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st)
 // I: one wave per (stream, block < n_mac)
 __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_inverse(const ConvTpArgs A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kTpWaves);
@@ -1311,6 +1319,7 @@ __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_inverse(const ConvTpA
 // new state: overlaps of the segment's last block, (lsl + j lsr) from W1 and (rsl + j rsr) from W - W1
 __global__ __launch_bounds__(256) void k_conv_tp_tails(const ConvTpArgs A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
@@ -1416,23 +1425,25 @@ hipError_t launch_zero_tail_component(float2 *tails, long long n_streams, int wh
     return hipGetLastError();
 }
 
-__global__ void k_scale_copy(const float *__restrict__ src, float *__restrict__ dst, long long n, float gain)
+__global__ void k_scale_copy(const float *__restrict__ src, float *__restrict__ dst, long long n, float gain, int fp_mode)
 {
+    ohs_set_fp_mode(fp_mode);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i] * gain;
 }
-hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st)
+hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st, int fp_mode)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, gain);
+    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, gain, fp_mode);
     return hipGetLastError();
 }
 
 // The same copy as the LAST kernel of a host call: the workgroup that finishes last stores `seq` into the call's
 // completion word in pinned host memory (see k_engine_call).  `counter` is a device word that is zero between calls.
 __global__ void k_scale_copy_done(const float *__restrict__ src, float *__restrict__ dst, long long n, float gain,
-                                  unsigned *counter, unsigned *done, unsigned seq)
+                                  unsigned *counter, unsigned *done, unsigned seq, int fp_mode)
 {
+    ohs_set_fp_mode(fp_mode);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i] * gain;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1447,11 +1458,11 @@ __global__ void k_scale_copy_done(const float *__restrict__ src, float *__restri
     }
 }
 hipError_t launch_scale_copy_done(const float *src, float *dst, long long n, float gain, unsigned *counter, unsigned *done,
-                                  unsigned seq, hipStream_t st)
+                                  unsigned seq, hipStream_t st, int fp_mode)
 {
     if (n <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_scale_copy_done, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, gain, counter,
-                       done, seq);
+                       done, seq, fp_mode);
     return hipGetLastError();
 }
 

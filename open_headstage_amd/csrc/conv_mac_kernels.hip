@@ -55,6 +55,7 @@ constexpr int kTB = OHS_MAC_TB;     // output blocks per register tile
 constexpr int kPI = OHS_MAC_PI;     // partitions per register window (Ppad is a multiple of 16, so 8 or 16)
 __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     // XCD-aware mapping.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own
     // 4 MiB L2; all workgroups of one stream re-read that stream's history ring (P + n_mac spectra,
     // 2.3 MiB on config 4), so a stream's workgroups are given ids that are congruent mod 8: its ring
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 // main MAC loop carries no per-iteration test for it (that test cost the main kernel 55 %).
 __global__ __launch_bounds__(256) void k_conv_tp_w1(const ConvTpArgs A)
 {
+    ohs_set_fp_mode(A.fp_mode);
     const int pi = blockIdx.x * 256 + threadIdx.x;
     if (pi >= A.n_pairs) return;
     const int b = A.pairs[pi];

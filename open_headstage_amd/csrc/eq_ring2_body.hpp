@@ -89,29 +89,22 @@ __device__ __forceinline__ void ring2_chunk(int q, int n, int j, bool band, cons
 #define EQ_RING2_CONSTS [b2] "{v1}"(c.b2), [pb01] "{v[12:13]}"(pb01), [a12] "{v[14:15]}"(a12)
 #define EQ_RING2_CLOBBERS "v6", "v8", "v9", "memory"
 
-// The launch's full groups, n_full >= 2 of them, in ONE statement: chunks 1..7 of group 0 (chunk 0 ran in the gated
+// The launch's full groups, n_full >= 1 of them, in ONE statement: chunks 1..7 of group 0 (chunk 0 ran in the gated
 // form; the block requests chunks 2..7 itself, so that the gated code runs with two input registers alive, not
 // eight), n_full - 2 interior groups, the last full group.  x1 = chunk 1's inputs, xnext = chunk 0 of the group
 // behind the last full one.
-__device__ __forceinline__ void eq_ring2_main(const RingLane &c, RingRegs &r, float x1, float xnext, unsigned lane_off,
-                                              const float *src, float *dst, unsigned interior_groups)
+__device__ __forceinline__ void eq_ring2_full_groups(const RingLane &c, RingRegs &r, float x1, float xnext, unsigned lane_off,
+                                                     const float *src, float *dst, int n_full)
 {
     const v2f pb01 = {c.pb0, c.pb1}, a12 = {c.a1, c.a2};
     unsigned k512 = 512;
+    // (wave-uniform by construction; readfirstlane tells hipcc so -- it had put the selects into VGPRs)
+    unsigned only = (unsigned)__builtin_amdgcn_readfirstlane(n_full == 1 ? 1 : 0);
+    unsigned interior_groups = (unsigned)__builtin_amdgcn_readfirstlane(n_full >= 2 ? n_full - 2 : 0);
     asm volatile(EQ_RING2_MAIN
                  : EQ_RING2_STATE, [x1] "+{v17}"(x1), [voff] "+{v0}"(lane_off), [cnt] "+s"(interior_groups)
-                 : EQ_RING2_CONSTS, [xn] "{v24}"(xnext), [src] "s"(src), [dst] "s"(dst), [k512] "s"(k512)
+                 : EQ_RING2_CONSTS, [xn] "{v24}"(xnext), [src] "s"(src), [dst] "s"(dst), [k512] "s"(k512), [only] "s"(only)
                  : EQ_RING2_CLOBBERS, "v16", "v18", "v19", "v20", "v21", "v22", "v23", "scc");
-}
-// the same for a launch with exactly one full group
-__device__ __forceinline__ void eq_ring2_head_only(const RingLane &c, RingRegs &r, float x1, float xnext, unsigned lane_off,
-                                                   const float *src, float *dst)
-{
-    const v2f pb01 = {c.pb0, c.pb1}, a12 = {c.a1, c.a2};
-    asm volatile(EQ_RING2_HEAD_NOLOAD
-                 : EQ_RING2_STATE
-                 : EQ_RING2_CONSTS, [x1] "{v17}"(x1), [xn] "{v24}"(xnext), [voff] "{v0}"(lane_off), [src] "s"(src), [dst] "s"(dst)
-                 : EQ_RING2_CLOBBERS, "v18", "v19", "v20", "v21", "v22", "v23");
 }
 
 // the strides the ring form's 32-bit lane offsets can address (host side, launch_eq_pass)
@@ -201,8 +194,7 @@ __device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long 
             ring2_pm(r, c);
             // group 0: chunk 0 gated (band j wakes up at step j + 1); the rest of the full groups as asm
             ring2_chunk(0, n32, d.j, d.band, c, r, x0, x1, dst0, d.lane_off);
-            if (n_full >= 2) eq_ring2_main(c, r, x1, xq, d.lane_off, src0, dst0, (unsigned)(n_full - 2));
-            else eq_ring2_head_only(c, r, x1, xq, d.lane_off, src0, dst0);
+            eq_ring2_full_groups(c, r, x1, xq, d.lane_off, src0, dst0, n_full);
             q = n_full * G;
         } else {
             ring2_pre<0>(r, c, xq);

@@ -10,6 +10,22 @@ namespace ohs {
 // Only ENABLED bands are handed to the kernel (a disabled band is the identity and keeps its state,
 // parametric_eq.rs:118-120), so lane j of a row is the j-th enabled band of this pass and `slot[j]` is
 // that band's index in the per-chain state array.
+// Denormal handling of the caller: nih-plug runs Plugin::process with the CPU's flush-to-zero bit set
+// (ScopedFtz: MXCSR.FTZ -- results that would be denormal become signed zeros; denormal INPUTS are still read), the
+// reference's unit tests run with IEEE denormals.  fp_mode of a launch: 0 = IEEE (the default, what the parity tests
+// and the unit tests compare), 1 = flush denormal results (FTZ), 2 = flush results and read denormal inputs as zero
+// (FTZ | DAZ, what many audio hosts set themselves).  MODE.FP_DENORM bits [5:4] govern f32: 3 = keep both, 1 = keep
+// inputs / flush results, 0 = flush both.  The kernels contain no f32 division or square root (their expansions
+// switch the mode and restore the compile-time default), so a mode set at kernel entry holds to the end.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void ohs_set_fp_mode(int fp_mode)
+{
+    // hwreg(HW_REG_MODE = 1, offset 4, size 2): id | offset << 6 | (size - 1) << 11
+    if (fp_mode == 1) __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 1);
+    else if (fp_mode == 2) __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 0);
+}
+#endif
+
 struct EqPassTable {
     float b0[16], b1[16], b2[16], a1[16], a2[16];
     int slot[16];
@@ -23,7 +39,7 @@ constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
 // pass-on lanes run 1*x + 0).
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
                           long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
-                          hipStream_t st, bool exact_specials = false);
+                          hipStream_t st, bool exact_specials = false, int fp_mode = 0);
 
 // |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
 hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,
@@ -50,6 +66,7 @@ struct ConvGeneralArgs {
     int zero_tails_in;          // start from zero overlap instead of `tails`
     const float2 *tw;           // master twiddle table, 1024 entries
     float gain;
+    int fp_mode;                // denormal handling, see ohs_set_fp_mode
 };
 hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st);
 
@@ -115,6 +132,7 @@ struct ConvP1Args {
     int stagger;                // wave w of a workgroup starts its block loop w * stagger * 64 cycles late (0 = off)
     int prio_mode;              // issue priority of the waves: 0 = hardware default (oldest first), 1 = rotating per block
     int weights[4];             // relative length of a chunk by the age rank of the wave that runs it (conv_kernels.hip: p1_chunk_begin)
+    int fp_mode;                // denormal handling, see ohs_set_fp_mode
 };
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
 int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)
@@ -148,6 +166,7 @@ struct ConvTpArgs {
     float2 *tails_out;          // state out: the last block's four overlaps, general-kernel format
     const float2 *tw;
     float gain;
+    int fp_mode;                // denormal handling, see ohs_set_fp_mode
 };
 hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st);
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st);
@@ -171,8 +190,8 @@ hipError_t launch_debug_fft(const float2 *in, float2 *out, int inverse, int batc
                             hipStream_t st);
 
 // dst[i] = src[i] * gain  (n floats)
-hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st);
+hipError_t launch_scale_copy(const float *src, float *dst, long long n, float gain, hipStream_t st, int fp_mode = 0);
 hipError_t launch_scale_copy_done(const float *src, float *dst, long long n, float gain, unsigned *counter, unsigned *done,
-                                  unsigned seq, hipStream_t st);
+                                  unsigned seq, hipStream_t st, int fp_mode = 0);
 
 }  // namespace ohs

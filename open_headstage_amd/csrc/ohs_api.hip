@@ -143,6 +143,7 @@ struct ConvState {
     float2 *d_W = nullptr;          // [S][w_blocks][1024] MAC output scratch
     size_t w_blocks = 0;
     float2 *d_W1 = nullptr;         // [S][1024]
+    int fp_mode = 0;                // denormal handling of every launch on this state (kernels.h: ohs_set_fp_mode)
 };
 
 void conv_free(ConvState &c)
@@ -321,7 +322,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         a.CD = c.d_cd;
         for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
         a.tails = c.d_tails; a.tails_out = c.d_tails_alt; a.chunk_tails = c.d_chunk_tails;
-        a.tw = ctx->d_tw; a.gain = gain;
+        a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
         const char *env_sg = getenv("OHS_P1_STAGGER");          // tuning experiments
         a.stagger = env_sg ? atoi(env_sg) : 0;
         const char *env_pr = getenv("OHS_P1_PRIO");             // tuning experiments: 1 = rotate the issue priority per block
@@ -366,7 +367,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             a.hist = c.d_hist; a.cap = c.cap; a.cnt = cnt;
             a.tails = c.d_tails; a.tails_out = tails_out;
             a.skip_store = skip_store; a.zero_tails_in = zero_in;
-            a.tw = ctx->d_tw; a.gain = gain;
+            a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
             hipError_t e = launch_conv_general(a, (int)c.S, st);
             if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(e));
             return OHS_OK;
@@ -411,7 +412,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 a.CD = c.d_cdm; a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt + (unsigned long long)done;
                 a.W = c.d_W; a.W1 = c.d_W1; a.tails = c.d_tails; a.tails_out = c.d_tails_alt;
                 a.pairs = ctx->d_pairs; a.n_pairs = ctx->n_pairs;
-                a.tw = ctx->d_tw; a.gain = gain;
+                a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
                 hipError_t e = launch_conv_tp_forward(a, st);
                 if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
                 if (e == hipSuccess) e = launch_conv_tp_inverse(a, st);   // block 0 reads the OLD state
@@ -435,6 +436,7 @@ struct EqState {
     std::vector<int> en;         // nb
     float *d_state = nullptr;    // [chains][kEqStateSlots][2], indexed by band
     bool exact_specials = false; // ohs_*_set_eq_exact_specials: conveyor kernel, exact for -0.0 / around non-finite input
+    int fp_mode = 0;             // denormal handling (kernels.h: ohs_set_fp_mode)
 };
 
 using ohs_host::rbj;
@@ -505,7 +507,7 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
                 t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
             }
         }
-        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials);
+        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials, e.fp_mode);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
         did = true;
@@ -730,7 +732,7 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
     for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
     a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
     a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
-    a.tw = e->ctx->d_tw; a.gain = 1.0f;
+    a.tw = e->ctx->d_tw; a.gain = 1.0f; a.fp_mode = e->conv.fp_mode;
     EngineCallArgs g;
     g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
     g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
@@ -824,7 +826,7 @@ int rt_start(ohs_engine *e)
     for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p]; }
     a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
     a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
-    a.tw = e->ctx->d_tw; a.gain = 1.0f;
+    a.tw = e->ctx->d_tw; a.gain = 1.0f; a.fp_mode = e->conv.fp_mode;
     EngineCallArgs &g = mb->call;
     g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
     g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
@@ -949,7 +951,7 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
             EqPassTable t;
             const int nb_on = eq_single_pass_table(eq->eq, t);
             if (nb_on == 0) { rrc = engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, nullptr, nullptr, 0); tried = true; }
-            else if (nb_on <= 12 && !eq->eq.exact_specials) {
+            else if (nb_on <= 12 && !eq->eq.exact_specials && eq->eq.fp_mode == e->conv.fp_mode) {     // (the resident kernel runs in the engine's mode)
                 rrc = engine_process_resident(e, in_l, in_r, out_l, out_r, n, gain, &eq->eq, &t, nb_on); tried = true;
             }
         }
@@ -985,8 +987,8 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     if (e->out.len >= n) {
         rc = engine_stage_reserve(e, n);
         if (rc) return rc;
-        HIP_TRY(launch_scale_copy(e->out.d, e->d_stage, (long long)n, gain, st));
-        HIP_TRY(launch_scale_copy(e->out.d + e->out.cap, e->d_stage + e->stage_cap, (long long)n, gain, st));
+        HIP_TRY(launch_scale_copy(e->out.d, e->d_stage, (long long)n, gain, st, e->conv.fp_mode));
+        HIP_TRY(launch_scale_copy(e->out.d + e->out.cap, e->d_stage + e->stage_cap, (long long)n, gain, st, e->conv.fp_mode));
         HIP_TRY(hipMemcpyAsync(out_l, e->d_stage, n * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(out_r, e->d_stage + e->stage_cap, n * sizeof(float), hipMemcpyDeviceToHost, st));
         rc = fifo_drop_front(e->out, n, e->scratch, st);
@@ -1123,6 +1125,7 @@ int ohs_engine_clone(const ohs_engine *src, ohs_engine **out)
     rt_stop(const_cast<ohs_engine *>(src));      // state at rest (the clone itself starts outside real-time mode)
     hipStreamSynchronize(src->st);
     e->silent_frames = src->silent_frames;
+    d.fp_mode = s.fp_mode;
     for (int p = 0; p < 4; ++p) {
         hipFree(d.d_H[p]); d.d_H[p] = nullptr;
         if (hipMalloc(&d.d_H[p], (size_t)s.P[p] * NF * sizeof(float2)) != hipSuccess) return bail(fail(OHS_ERR_HIP, "hipMalloc"));
@@ -1177,6 +1180,18 @@ int ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out)
 {
     if (!e || !out || path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "bad argument");
     *out = (size_t)e->conv.P[path];
+    return OHS_OK;
+}
+
+int ohs_engine_set_flush_denormals(ohs_engine *e, int mode)
+{
+    if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
+    if (mode < 0 || mode > 2) return fail(OHS_ERR_INVALID_ARG, "mode must be 0 (IEEE), 1 (FTZ) or 2 (FTZ | DAZ)");
+    if (mode != e->conv.fp_mode) {
+        HIP_TRY(hipSetDevice(e->device));
+        rt_stop(e);         // the resident kernel set its mode when it started; the next call restarts it
+        e->conv.fp_mode = mode;
+    }
     return OHS_OK;
 }
 
@@ -1386,6 +1401,14 @@ int ohs_eq_process_block(ohs_eq *q, float *left, float *right, size_t n)
     return OHS_OK;
 }
 
+int ohs_eq_set_flush_denormals(ohs_eq *q, int mode)
+{
+    if (!q) return fail(OHS_ERR_INVALID_ARG, "eq is NULL");
+    if (mode < 0 || mode > 2) return fail(OHS_ERR_INVALID_ARG, "mode must be 0 (IEEE), 1 (FTZ) or 2 (FTZ | DAZ)");
+    q->eq.fp_mode = mode;
+    return OHS_OK;
+}
+
 int ohs_eq_set_exact_specials(ohs_eq *q, int enable)
 {
     if (!q) return fail(OHS_ERR_INVALID_ARG, "eq is NULL");
@@ -1553,6 +1576,15 @@ int ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     b->eq_enable = eq_enable != 0;
+    return OHS_OK;
+}
+
+int ohs_batch_set_flush_denormals(ohs_batch *b, int mode)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    if (mode < 0 || mode > 2) return fail(OHS_ERR_INVALID_ARG, "mode must be 0 (IEEE), 1 (FTZ) or 2 (FTZ | DAZ)");
+    b->conv.fp_mode = mode;
+    b->eq.fp_mode = mode;
     return OHS_OK;
 }
 

@@ -114,6 +114,11 @@ class ConvolutionEngine:
         """Resident-kernel mode for real-time sized calls (ohs_engine_set_realtime)."""
         check(lib().ohs_engine_set_realtime(self._h, int(bool(enable))))
 
+    def set_flush_denormals(self, mode: int) -> None:
+        """0 = IEEE denormals (default), 1 = flush denormal results (nih-plug's FTZ scope around Plugin::process,
+        src/lib.rs:1156), 2 = also read denormal inputs as zero (FTZ | DAZ).  ohs_engine_set_flush_denormals."""
+        check(lib().ohs_engine_set_flush_denormals(self._h, int(mode)))
+
     def latency_samples(self, n: int) -> int:
         """Delay of the FIFO adapter for a constant host block size n (convolution.rs:163-181)."""
         v = C.c_size_t()
@@ -192,6 +197,10 @@ class StereoParametricEQ:
     def set_exact_specials(self, enable: bool) -> None:
         """Opt into bit-exact handling of -0.0 and of samples around a non-finite input (ohs_eq_set_exact_specials)."""
         check(lib().ohs_eq_set_exact_specials(self._h, int(bool(enable))))
+
+    def set_flush_denormals(self, mode: int) -> None:
+        """see ConvolutionEngine.set_flush_denormals (ohs_eq_set_flush_denormals)"""
+        check(lib().ohs_eq_set_flush_denormals(self._h, int(mode)))
 
     def reset_all_bands_state(self) -> None:
         check(lib().ohs_eq_reset(self._h))

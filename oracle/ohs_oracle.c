@@ -10,6 +10,10 @@
 #include "ohs_oracle.h"
 #include "libm_musl.h"
 
+#if defined(__x86_64__) || defined(__i386__)
+#include <xmmintrin.h>
+#endif
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -540,4 +544,28 @@ void ohs_or_eq_f64(const float *coeffs, const int *enabled, size_t nb,
         }
         y[i] = s;
     }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Denormal handling of the CALLING THREAD, as the shipped plugin runs:       */
+/* nih-plug wraps Plugin::process (src/lib.rs:1156) in a flush-to-zero scope  */
+/* (MXCSR.FTZ: denormal RESULTS become signed zeros; denormal inputs are      */
+/* still read).  mode 0 = IEEE (what the reference's unit tests run with),    */
+/* 1 = FTZ, 2 = FTZ | DAZ.  Returns the previous mode.  The arithmetic of     */
+/* this file is scalar / vector SSE, which MXCSR governs.                     */
+/* ------------------------------------------------------------------------- */
+int ohs_or_set_flush_denormals(int mode)
+{
+#if defined(__x86_64__) || defined(__i386__)
+    const unsigned csr = _mm_getcsr();
+    const int prev = (csr & 0x8000u) ? ((csr & 0x0040u) ? 2 : 1) : 0;
+    unsigned next = csr & ~(0x8000u | 0x0040u);
+    if (mode >= 1) next |= 0x8000u;     /* FTZ */
+    if (mode >= 2) next |= 0x0040u;     /* DAZ */
+    _mm_setcsr(next);
+    return prev;
+#else
+    (void)mode;
+    return -1;
+#endif
 }

@@ -101,6 +101,9 @@ void ohs_or_binaural_f64(const double *x_l, const double *x_r, size_t n,
 void ohs_or_eq_f64(const float *coeffs /* nb*5 */, const int *enabled, size_t nb,
                    const float *x, size_t n, double *state, double *y);
 
+/* flush-to-zero mode of the calling thread (0 = IEEE, 1 = FTZ, 2 = FTZ | DAZ); returns the previous mode, -1 where unsupported */
+int ohs_or_set_flush_denormals(int mode);
+
 #ifdef __cplusplus
 }
 #endif

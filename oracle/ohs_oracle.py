@@ -96,6 +96,8 @@ def lib() -> C.CDLL:
     L.ohs_or_eq_frequency_response.argtypes = [C.c_void_p, C.c_float, fp, C.c_size_t, fp]
     L.ohs_or_chain_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, fp, fp,
                                        C.c_size_t]
+    L.ohs_or_set_flush_denormals.restype = C.c_int
+    L.ohs_or_set_flush_denormals.argtypes = [C.c_int]
     L.ohs_or_direct_conv_f64.argtypes = [fp, C.c_size_t, fp, C.c_size_t, dp]
     L.ohs_or_binaural_f64.argtypes = [dp, dp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, fp,
                                       C.c_size_t, fp, C.c_size_t, dp, dp]
@@ -155,6 +157,25 @@ class ConvolutionEngine:
         if getattr(self, "_h", None):
             lib().ohs_or_engine_free(self._h)
             self._h = None
+
+
+class flush_denormals:
+    """Context manager: run the oracle calls inside with the calling thread's MXCSR set as the shipped plugin runs
+    (mode 1 = FTZ, nih-plug's scope around Plugin::process, src/lib.rs:1156; 2 = FTZ | DAZ), restored on exit.
+    numpy arithmetic on this thread is affected too while the mode is set: keep the block to oracle calls."""
+
+    def __init__(self, mode: int):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = lib().ohs_or_set_flush_denormals(self.mode)
+        if self.prev < 0:
+            raise RuntimeError("no flush-to-zero control on this CPU")
+        return self
+
+    def __exit__(self, *exc):
+        lib().ohs_or_set_flush_denormals(self.prev)
+        return False
 
 
 def biquad_coeffs(filter_type: int, fs: float, fc: float, q: float, gain_db: float):

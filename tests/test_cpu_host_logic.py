@@ -214,7 +214,7 @@ def test_kernel_register_budgets(lib):
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     inc = open(os.path.join(ROOT, "open_headstage_amd", "csrc", "eq_ring2_asm.inc")).read()
-    for macro, lines in (("EQ_RING2_MAIN", gen.gen_main()), ("EQ_RING2_HEAD_NOLOAD", gen.gen(first_step=16, loads=False))):
+    for macro, lines in (("EQ_RING2_MAIN", gen.gen_main()),):
         body = f"#define {macro} \\\n" + " \\\n".join('    "' + l + '\\n"' for l in lines) + "\n"
         assert body in inc, f"{macro}: eq_ring2_asm.inc is not what tools/gen_eq_ring2_asm.py writes"
 

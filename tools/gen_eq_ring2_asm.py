@@ -36,8 +36,8 @@ Blocks (first_step, loads, loop):
     LOOP         0, yes, yes   interior groups: everything in bounds
     NOLOAD       0, no,  no    a full group whose successor is not full (the caller loaded v24)
     HEAD_NOLOAD 16, no,  no
-Macros: EQ_RING2_MAIN = HEAD_LOADS + LOOP (%[cnt] >= 0 times) + NOLOAD in one statement, for launches of >= 2 full
-groups; EQ_RING2_HEAD_NOLOAD for launches of one.
+Macro: EQ_RING2_MAIN = all of a launch's full groups in one statement -- HEAD_NOLOAD when there is one (%[only]),
+else HEAD_LOADS + LOOP (%[cnt] >= 0 times) + NOLOAD.
 Lane 4b+i of an input / store register holds sample 16q + 4b + 3 - i (the offsets carry j ^ 3).
 """
 import os
@@ -60,9 +60,9 @@ def ror(n):
 
 
 def size_of(line):
-    if line.startswith((".p2align", "1:", "2:")):
+    if line.startswith((".p2align", "1:", "2:", "3:", "4:")):
         return 0
-    if line.startswith(("s_nop", "s_waitcnt", "s_sub_u32", "s_cmp", "s_cbranch", "v_add_u32_e32")):
+    if line.startswith(("s_nop", "s_waitcnt", "s_sub_u32", "s_cmp", "s_cbranch", "s_branch", "v_add_u32_e32")):
         return 4
     return 8
 
@@ -173,9 +173,15 @@ def check_alignment(lines):
 
 
 def gen_main():
-    """The launch's full groups in ONE statement (>= 2 of them): HEAD_LOADS, the interior loop %[cnt] times (possibly
-    zero), NOLOAD.  v0 enters as the lane's offset of group 0 and is advanced to the last full group's."""
-    out = gen(first_step=16)
+    """The launch's full groups, all of them, in ONE statement (one statement: two in an if / else made hipcc keep
+    copies of the pinned state for the path not taken, beyond the kernel's 32 registers):
+        %[only] != 0 (one full group):   HEAD_NOLOAD
+        else (%[cnt] + 2 full groups):   HEAD_LOADS, the interior loop %[cnt] >= 0 times, NOLOAD
+    v0 enters as the lane's offset of group 0 and leaves as that of the last full group."""
+    out = [".p2align 5",
+           "s_cmp_lg_u32 %[only], 0",
+           "s_cbranch_scc1 3f"]
+    out += gen(first_step=16)
     out += ["v_add_u32_e32 v0, %[k512], v0",       # group 1's offset: what the loop / the closing group expects
             "s_cmp_eq_u32 %[cnt], 0",
             "s_cbranch_scc1 2f",
@@ -183,6 +189,9 @@ def gen_main():
     out += gen(loop=True)
     out += ["2:"]
     out += gen(loads=False)
+    out += ["s_branch 4f", "s_nop 0", "3:"]
+    out += gen(first_step=16, loads=False)
+    out += ["4:"]
     check_alignment(out)
     return out
 
@@ -192,8 +201,7 @@ if __name__ == "__main__":
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_eq_ring2_asm.py -- do not edit.  EQ ring group bodies on pinned low registers "
                 "(see eq_ring2_body.hpp).\n")
-        for macro, lines in (("EQ_RING2_MAIN", gen_main()),
-                             ("EQ_RING2_HEAD_NOLOAD", gen(first_step=16, loads=False))):
+        for macro, lines in (("EQ_RING2_MAIN", gen_main()),):
             f.write(f"#define {macro} \\\n")
             f.write(" \\\n".join('    "' + l + '\\n"' for l in lines))
             f.write("\n\n")
