@@ -101,6 +101,10 @@ int  ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out);
  * clone / destroy / any call it cannot serve (it is restarted by the next call it can), and by itself after
  * ~2 s without a call.  It holds one CU while it lives: a device runs at most num_CUs / 4 of them
  * (OHS_RT_MAX_RESIDENT), further engines in real-time mode are served launch per call until a slot frees up.
+ * Whenever ANY handle of this library on the same device is about to free device memory or wait for the whole
+ * device (set_ir, destroy, reset, buffer growth), it asks the device's resident kernels to leave first and holds new
+ * ones off until it is done -- a resident kernel would otherwise stall such a wait for as long as it lives; a call
+ * arriving meanwhile is served launch per call, the next one restarts the kernel.
  * Same threading rule as every handle: one thread at a time. */
 int  ohs_engine_set_realtime(ohs_engine *e, int enable);
 /* Delay the FIFO adapter of process_block adds for a constant host block size n (convolution.rs:163-181):
@@ -282,7 +286,10 @@ int  ohs_batch_join(ohs_batch *b, void *hip_stream);
  * chunk i + 1, the kernels of chunk i and copy-out of chunk i - 1 run concurrently on three internal
  * streams.  Blocking: h_out is complete on return.  h_in may equal h_out.  Pinned (page-locked) host memory
  * is needed for the copies to overlap at link speed; pageable memory works but serialises.  Results are
- * bit-identical to the sequence of ohs_batch_process calls with the same chunk sizes on device buffers. */
+ * bit-identical to the sequence of ohs_batch_process calls with the same chunk sizes on device buffers.
+ * The call runs on internal streams: work queued earlier on this handle through ohs_batch_process /
+ * _process_deferred on a stream of the caller's must have completed (ohs_batch_sync) -- it advances the same
+ * per-stream state; a pending deferred call is joined by the library itself. */
 int  ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t n_blocks,
                             size_t stream_stride, size_t channel_stride, size_t chunk_blocks);
 /* waits (host side) for everything queued on `hip_stream` and for a pending deferred call */

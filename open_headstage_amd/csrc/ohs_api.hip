@@ -21,6 +21,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace ohs;
@@ -121,6 +122,43 @@ int next_pow2(int v)
 }
 
 // ---- convolution state shared by the engine (1 stream) and batch (S streams) ----
+// ---- resident real-time kernels vs. device-wide waits ------------------------------------------------------
+// hipFree, hipDeviceSynchronize and hipHostFree wait for EVERY kernel on the device -- a resident real-time kernel
+// (k_engine_resident) of some other engine included, which only leaves when its owner stops it or after ~2 s without
+// a call.  Library code that is about to make such a wait opens a DeviceWideSection: it asks every resident kernel of
+// the device to leave (the `stop` word of its mailbox; the kernel is gone a microsecond later, and its owner restarts
+// it on its next call exactly as after an idle exit) and keeps new ones from starting until the section ends (rt_start
+// answers OHS_RT_NO_SLOT meanwhile: that call is served launch per call, like an engine beyond the device's cap).
+// Only the mailbox word of a foreign engine is touched, under the registry's mutex, which an engine's destruction
+// takes before its mailbox is freed.
+constexpr int kMaxDevices = 64;
+struct RtRegistry {
+    std::mutex mu;
+    std::vector<ohs_engine *> running;     // engines whose resident kernel has been launched and not yet reaped
+    int hold = 0;                           // open DeviceWideSections
+};
+static RtRegistry g_rt_reg[kMaxDevices];
+void rt_request_stop_locked(ohs_engine *e);      // (defined with the mailbox protocol below)
+struct DeviceWideSection {
+    int dev = 0;
+    DeviceWideSection()
+    {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        RtRegistry &r = g_rt_reg[dev % kMaxDevices];
+        std::lock_guard<std::mutex> lk(r.mu);
+        ++r.hold;
+        for (ohs_engine *e : r.running) rt_request_stop_locked(e);
+    }
+    ~DeviceWideSection()
+    {
+        RtRegistry &r = g_rt_reg[dev % kMaxDevices];
+        std::lock_guard<std::mutex> lk(r.mu);
+        --r.hold;
+    }
+    DeviceWideSection(const DeviceWideSection &) = delete;
+    DeviceWideSection &operator=(const DeviceWideSection &) = delete;
+};
+
 struct ConvState {
     size_t S = 1;
     float2 *d_H[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -148,6 +186,7 @@ struct ConvState {
 
 void conv_free(ConvState &c)
 {
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
     for (int p = 0; p < 4; ++p) { if (c.d_H[p]) hipFree(c.d_H[p]); c.d_H[p] = nullptr; }
     if (c.d_hist) hipFree(c.d_hist);
     if (c.d_tails) hipFree(c.d_tails);
@@ -187,6 +226,7 @@ int conv_init(ConvState &c, size_t S, hipStream_t st)
 int conv_grow_ring(ConvState &c, int need, hipStream_t st)
 {
     if (need <= c.cap) return OHS_OK;
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
     const int ncap = next_pow2(need);
     float2 *nh = nullptr;
     HIP_TRY(hipMalloc(&nh, c.S * (size_t)ncap * NF * sizeof(float2)));
@@ -217,6 +257,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
     // every failure path below frees what it allocated: a HIP_TRY inside the lambda returns from the
     // lambda only, the buffers are released after it
     float2 *nH = nullptr;
@@ -308,6 +349,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         const long long target_override = env_tw ? atoll(env_tw) : 0LL;
         const long long K = conv_p1_chunks(ctx, c.S, n_blocks, target_override);
         if ((size_t)K > c.chunk_tails_cap) {
+            DeviceWideSection dws;
             HIP_TRY(hipStreamSynchronize(st));
             if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
             c.d_chunk_tails = nullptr; c.chunk_tails_cap = 0;
@@ -384,6 +426,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             if (rc) return rc;
             const int Ppad = Ppad_for_ring(Pmax);
             if (!c.cdm_valid || c.cdm_ppad != Ppad) {
+                DeviceWideSection dws;
                 HIP_TRY(hipStreamSynchronize(st));
                 if (c.d_cdm) hipFree(c.d_cdm);
                 c.d_cdm = nullptr;
@@ -394,6 +437,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 c.cdm_ppad = Ppad; c.cdm_valid = true;
             }
             if ((size_t)seg_max > c.w_blocks) {
+                DeviceWideSection dws;
                 HIP_TRY(hipStreamSynchronize(st));
                 if (c.d_W) hipFree(c.d_W);
                 c.d_W = nullptr; c.w_blocks = 0;
@@ -525,6 +569,7 @@ struct DevFifo {
 int fifo_reserve(DevFifo &f, size_t need, hipStream_t st)
 {
     if (need <= f.cap) return OHS_OK;
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
     size_t ncap = f.cap ? f.cap : 4 * BS;
     while (ncap < need) ncap *= 2;
     float *nd = nullptr;
@@ -645,6 +690,7 @@ namespace {
 int engine_stage_reserve(ohs_engine *e, size_t n)
 {
     if (n <= e->stage_cap) return OHS_OK;
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
     size_t ncap = e->stage_cap ? e->stage_cap : 4 * BS;
     while (ncap < n) ncap *= 2;
     if (e->d_stage) hipFree(e->d_stage);
@@ -669,6 +715,7 @@ hipError_t sync_spin(hipStream_t st)
 int engine_pinned_reserve(ohs_engine *e, size_t n)
 {
     if (n <= e->hcap) return OHS_OK;
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
     size_t ncap = e->hcap ? e->hcap : 2048;
     while (ncap < n) ncap *= 2;
     if (e->h_in) hipHostFree(e->h_in);
@@ -772,7 +819,6 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
 // A resident kernel holds one CU (149 KiB of LDS) for as long as it lives, so their number per device is capped:
 // a quarter of the CUs by default (OHS_RT_MAX_RESIDENT).  Engines in real-time mode beyond the cap are served by
 // the launch-per-call path until a slot frees up -- same results, never a wait for a CU that is not coming.
-constexpr int kMaxDevices = 64;
 constexpr int OHS_RT_NO_SLOT = 1000;     // internal: rt_start found the device's cap reached (never crosses the C ABI)
 static std::atomic<int> g_rt_resident[kMaxDevices];
 static bool rt_slot_acquire(ohs_engine *e)
@@ -788,14 +834,41 @@ static bool rt_slot_acquire(ohs_engine *e)
 static void rt_mark_stopped(ohs_engine *e)
 {
     e->rt_running = false;
+    {
+        RtRegistry &r = g_rt_reg[e->device % kMaxDevices];
+        std::lock_guard<std::mutex> lk(r.mu);
+        r.running.erase(std::remove(r.running.begin(), r.running.end(), e), r.running.end());
+    }
     if (e->rt_slot) { g_rt_resident[e->device % kMaxDevices].fetch_sub(1, std::memory_order_acq_rel); e->rt_slot = false; }
+}
+static void rt_mark_stopped_unregistered(ohs_engine *e)     // registry mutex held by the caller, e not in the list
+{
+    e->rt_running = false;
+    if (e->rt_slot) { g_rt_resident[e->device % kMaxDevices].fetch_sub(1, std::memory_order_acq_rel); e->rt_slot = false; }
+}
+void rt_request_stop_locked(ohs_engine *e)       // registry mutex held: e->mb is alive
+{
+    if (e->mb) __atomic_store_n(&e->mb->call_word[3], 1u, __ATOMIC_RELEASE);
 }
 
 void rt_stop(ohs_engine *e)
 {
     if (!e->rt_running) return;
     __atomic_store_n(&e->mb->call_word[3], 1u, __ATOMIC_RELEASE);
-    hipStreamSynchronize(e->rt_st);       // the kernel sees `stop` at its next poll (~1 us) and every wave leaves
+    // the kernel sees `stop` at its next poll (~1 us) and every wave leaves.  Bounded: a kernel that does not leave
+    // within 5 s is wedged, and an unbounded wait here would hang the audio thread with it -- the engine is taken out
+    // of real-time mode and carries on launch per call (whatever the device still does for it)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(e->rt_st);
+        if (q != hipErrorNotReady) break;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            e->rt_enabled = false;
+            ohs_internal_set_error("resident kernel did not leave within 5 s of its stop request; real-time mode switched off for this engine");
+            break;
+        }
+        std::this_thread::yield();
+    }
     rt_mark_stopped(e);
 }
 
@@ -844,8 +917,19 @@ int rt_start(ohs_engine *e)
         const char *v = getenv("OHS_RT_POLL_SLEEP");
         return v ? (unsigned)atoi(v) : 0u;      // no pause between poll bursts: 0.3 us less per call than one s_sleep(16)
     }();
-    hipError_t err = launch_engine_resident(e->mb_dev, e->ctx->d_tw, e->rt_seq, idle_limit, sleep_arg, e->rt_st);
-    if (err != hipSuccess) { rt_mark_stopped(e); return fail(OHS_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(err)); }
+    {
+        // launch and registration are one step under the registry's mutex: a DeviceWideSection either finds this
+        // kernel in the list (and asks it to leave) or has raised `hold` before (and no kernel is started)
+        RtRegistry &r = g_rt_reg[e->device % kMaxDevices];
+        std::lock_guard<std::mutex> lk(r.mu);
+        if (r.hold > 0) { rt_mark_stopped_unregistered(e); return OHS_RT_NO_SLOT; }
+        hipError_t err = launch_engine_resident(e->mb_dev, e->ctx->d_tw, e->rt_seq, idle_limit, sleep_arg, e->rt_st);
+        if (err != hipSuccess) {
+            rt_mark_stopped_unregistered(e);
+            return fail(OHS_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(err));
+        }
+        r.running.push_back(e);
+    }
     e->rt_running = true;
     return OHS_OK;
 }
@@ -908,8 +992,12 @@ int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r,
                 ring();
             }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-                rt_stop(e);
-                return fail(OHS_ERR_HIP, "resident kernel did not answer within 5 s");
+                // (the host's counters have not been advanced: the call did not happen as far as the engine's
+                // state on this side goes; rt_seq goes back to the last sequence number served)
+                --e->rt_seq;
+                e->rt_enabled = false;      // later calls: launch per call
+                rt_stop(e);                 // bounded
+                return fail(OHS_ERR_HIP, "resident kernel did not answer within 5 s; real-time mode switched off for this engine");
             }
         }
     }
@@ -1095,7 +1183,8 @@ void ohs_engine_destroy(ohs_engine *e)
     if (!e) return;
     hipSetDevice(e->device);
     rt_stop(e);
-    rt_mark_stopped(e);     // (a slot taken by a start that then failed)
+    rt_mark_stopped(e);     // (a slot taken by a start that then failed; also takes the engine off the registry)
+    DeviceWideSection dws;  // (frees below: no resident kernel of another engine may be in their way)
     if (e->rt_st) hipStreamDestroy(e->rt_st);
     if (e->mb) hipHostFree(e->mb);
     if (e->st) hipStreamSynchronize(e->st);
@@ -1123,6 +1212,7 @@ int ohs_engine_clone(const ohs_engine *src, ohs_engine **out)
     const ConvState &s = src->conv;
     ConvState &d = e->conv;
     rt_stop(const_cast<ohs_engine *>(src));      // state at rest (the clone itself starts outside real-time mode)
+    DeviceWideSection dws;
     hipStreamSynchronize(src->st);
     e->silent_frames = src->silent_frames;
     d.fp_mode = s.fp_mode;
@@ -1288,6 +1378,7 @@ void ohs_eq_destroy(ohs_eq *q)
 {
     if (!q) return;
     hipSetDevice(q->device);
+    DeviceWideSection dws;
     if (q->st) hipStreamSynchronize(q->st);
     if (q->eq.d_state) hipFree(q->eq.d_state);
     if (q->d_buf) hipFree(q->d_buf);
@@ -1342,6 +1433,7 @@ int ohs_eq_process_block(ohs_eq *q, float *left, float *right, size_t n)
         // ahead, less than a PCIe read, and its 64-byte stores are a poor fit for the bus.)
         // 1024 frames: 47 us per call (was 260 us with four hipMemcpyAsync of pageable memory).
         if (n > q->pin_cap) {
+            DeviceWideSection dws;
             size_t ncap = q->pin_cap ? q->pin_cap : 2048;
             while (ncap < n) ncap *= 2;
             if (q->h_pin) hipHostFree(q->h_pin);
@@ -1384,6 +1476,7 @@ int ohs_eq_process_block(ohs_eq *q, float *left, float *right, size_t n)
         return OHS_OK;
     }
     if (n > q->buf_cap) {
+        DeviceWideSection dws;
         size_t ncap = q->buf_cap ? q->buf_cap : 4 * BS;
         while (ncap < n) ncap *= 2;
         if (q->d_buf) hipFree(q->d_buf);
@@ -1446,7 +1539,7 @@ int ohs_eq_frequency_response(const ohs_eq *q, float fs, const float *freqs, siz
     if (e == hipSuccess) e = launch_eq_freq_response(d_c, d_en, (int)nb, fs, d_f, (int)n, d_o, q->st);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, n * sizeof(float), hipMemcpyDeviceToHost, q->st);
     if (e == hipSuccess) e = hipStreamSynchronize(q->st);
-    hipFree(d);
+    { DeviceWideSection dws; hipFree(d); }
     if (e != hipSuccess) return fail(OHS_ERR_HIP, hipGetErrorString(e));
     return OHS_OK;
 }
@@ -1512,6 +1605,7 @@ void ohs_batch_destroy(ohs_batch *b)
 {
     if (!b) return;
     hipSetDevice(b->device);
+    DeviceWideSection dws;
     hipDeviceSynchronize();
     conv_free(b->conv);
     if (b->eq.d_state) hipFree(b->eq.d_state);
@@ -1537,6 +1631,7 @@ int ohs_batch_set_ir(ohs_batch *b, int path, const float *ir, size_t len)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
+    DeviceWideSection dws;
     HIP_TRY(hipDeviceSynchronize());
     return conv_set_ir(b->conv, b->ctx, path, ir, len, b->st);
 }
@@ -1546,6 +1641,7 @@ extern "C" int ohs_internal_batch_set_ir_device(ohs_batch *b, int path, const fl
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
+    DeviceWideSection dws;
     HIP_TRY(hipDeviceSynchronize());
     return conv_set_ir(b->conv, b->ctx, path, d_ir, len, b->st, true);
 }
@@ -1606,6 +1702,7 @@ int ohs_batch_reset(ohs_batch *b)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
+    DeviceWideSection dws;
     HIP_TRY(hipDeviceSynchronize());
     ConvState &c = b->conv;
     HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), b->st));
@@ -1834,6 +1931,7 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
         }
     }
     if (cf > b->slot_frames) {
+        DeviceWideSection dws;
         HIP_TRY(hipDeviceSynchronize());
         for (int k = 0; k < ohs_batch::kHostSlots; ++k) {
             if (b->d_slot[k]) hipFree(b->d_slot[k]);
@@ -1868,6 +1966,13 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
     };
     const size_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
     int rc = OHS_OK;
+    // Work the caller queued earlier through ohs_batch_process* touches the same per-stream state.  A pending
+    // deferred call is joined here (its convolutions run on the handle's own second stream); work on the CALLER's
+    // streams cannot be seen from here: the header asks for ohs_batch_sync first.
+    if (b->join_pending) {
+        HIP_TRY(hipStreamWaitEvent(b->st_comp, b->chunk_done[(size_t)b->chunk_done_n - 1], 0));
+        b->join_pending = false;
+    }
     // OHS_HOST_PIPE_TRACE=1: device timestamps around every stage of every chunk, printed after the call
     // (diagnostic; it adds six event records per chunk)
     static const bool trace = [] { const char *v = getenv("OHS_HOST_PIPE_TRACE"); return v && v[0] == '1'; }();
@@ -1879,30 +1984,38 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
     };
     const auto host_t0 = std::chrono::steady_clock::now();
     std::vector<double> host_ms;
+    // inside the loop a HIP failure must not return: the drain below has to run (the copies already queued write
+    // into the caller's buffers)
+#define PIPE_TRY(x)                                                                                        \
+    {                                                                                                      \
+        const hipError_t pe_ = (x);                                                                        \
+        if (pe_ != hipSuccess) { rc = fail(OHS_ERR_HIP, std::string(#x ": ") + hipGetErrorString(pe_)); break; } \
+    }
     for (size_t i = 0; i < n_chunks && rc == OHS_OK; ++i) {
         const int k = (int)(i % ohs_batch::kHostSlots);
         const size_t blk0 = i * chunk_blocks, nb = std::min(chunk_blocks, n_blocks - blk0);
         const size_t off = blk0 * BS, nf = nb * BS;
-        if (i >= (size_t)ohs_batch::kHostSlots) HIP_TRY(hipStreamWaitEvent(b->st_h2d, b->ev_d2h[k], 0));   // slot free again
+        if (i >= (size_t)ohs_batch::kHostSlots) PIPE_TRY(hipStreamWaitEvent(b->st_h2d, b->ev_d2h[k], 0))    // slot free again
         mark(b->st_h2d);
         rc = copy(true, b->d_slot[k], off, nf, b->st_h2d);
         if (rc) break;
         mark(b->st_h2d);
-        HIP_TRY(hipEventRecord(b->ev_h2d[k], b->st_h2d));
-        HIP_TRY(hipStreamWaitEvent(b->st_comp, b->ev_h2d[k], 0));
+        PIPE_TRY(hipEventRecord(b->ev_h2d[k], b->st_h2d))
+        PIPE_TRY(hipStreamWaitEvent(b->st_comp, b->ev_h2d[k], 0))
         mark(b->st_comp);
         rc = batch_process_impl(b, b->d_slot[k], b->d_slot[k], nb, 2 * b->slot_frames, b->slot_frames, b->st_comp, false);
         if (rc) break;
         mark(b->st_comp);
-        HIP_TRY(hipEventRecord(b->ev_comp[k], b->st_comp));
-        HIP_TRY(hipStreamWaitEvent(b->st_d2h, b->ev_comp[k], 0));
+        PIPE_TRY(hipEventRecord(b->ev_comp[k], b->st_comp))
+        PIPE_TRY(hipStreamWaitEvent(b->st_d2h, b->ev_comp[k], 0))
         mark(b->st_d2h);
         rc = copy(false, b->d_slot[k], off, nf, b->st_d2h);
         if (rc) break;
         mark(b->st_d2h);
-        HIP_TRY(hipEventRecord(b->ev_d2h[k], b->st_d2h));
+        PIPE_TRY(hipEventRecord(b->ev_d2h[k], b->st_d2h))
         if (trace) host_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
     }
+#undef PIPE_TRY
     // blocking call: the outputs are complete on return (also on a failure half-way: nothing may still be
     // writing into the caller's buffers)
     const hipError_t e1 = hipStreamSynchronize(b->st_h2d), e2 = hipStreamSynchronize(b->st_comp),

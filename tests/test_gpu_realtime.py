@@ -261,3 +261,74 @@ def test_chain_with_eq_through_the_resident_kernel_is_bit_identical_and_matches_
     keep = a_l.copy()
     ohs.process_chain(er, qr, a_l, a_r, master_bypass=True, eq_enable=True)
     assert np.array_equal(a_l, keep)
+
+
+def test_device_wide_waits_of_other_handles_do_not_stall_on_resident_kernels(ohs, synth):
+    """hipFree / hipDeviceSynchronize inside the library wait for every kernel on the device -- a resident kernel of
+    ANOTHER engine included, which would only leave after its ~2 s idle limit.  Library code about to make such a wait
+    asks the device's resident kernels to leave first (and holds new ones off meanwhile); their owners restart them
+    on the next call.  Two engines in real-time mode + set_ir / destroy / a batch's set_ir and reset on other handles:
+    nothing may take anywhere near the idle limit, and the real-time engines keep producing the right bits."""
+    a, ref_a, irs = _pair(ohs, synth, 512)
+    b, ref_b, _ = _pair(ohs, synth, 512)
+    a.set_realtime(True); b.set_realtime(True)
+    x = synth.white_noise([21], 64 * 1024)[0]
+    pos = 0
+
+    def step(n=1024):
+        nonlocal pos
+        l, r = x[0, pos:pos + n].copy(), x[1, pos:pos + n].copy()
+        for rt, ref in ((a, ref_a), (b, ref_b)):
+            g, e = rt.process_block(l, r), ref.process_block(l, r)
+            assert np.array_equal(np.stack(g).view(np.uint32), np.stack(e).view(np.uint32))
+        pos += n
+
+    for _ in range(4):
+        step()                                  # both resident kernels are up
+    c = ohs.ConvolutionEngine.new()
+    t0 = time.perf_counter()
+    for p in range(4):
+        c.set_ir(p, irs[p][:300])               # hipFree + stream syncs on a third handle
+    c.process_block(x[0, :20000].copy(), x[1, :20000].copy())     # grows FIFOs / staging buffers (more frees)
+    bp = ohs.BatchProcessor(3, num_bands=2)
+    for p in range(4):
+        bp.set_ir(p, irs[p])                    # hipDeviceSynchronize
+    bp.reset()
+    del c, bp                                   # destroy paths
+    import gc
+    gc.collect()
+    dt = time.perf_counter() - t0
+    assert dt < 1.0, f"device-wide waits took {dt:.2f} s: they sat behind a resident kernel"
+    for _ in range(6):
+        step()                                  # restarted on their next calls, state intact
+    # ... and while one engine keeps its doorbell ringing from another thread
+    import threading
+    stop = threading.Event()
+    errs = []
+
+    def ring():
+        rt2, ref2, _ = _pair(ohs, synth, 256)
+        rt2.set_realtime(True)
+        y = synth.white_noise([22], 1024)[0]
+        try:
+            while not stop.is_set():
+                g, e = rt2.process_block(y[0], y[1]), ref2.process_block(y[0], y[1])
+                if not np.array_equal(np.stack(g).view(np.uint32), np.stack(e).view(np.uint32)):
+                    errs.append("mismatch")
+                    return
+        except Exception as ex:     # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = threading.Thread(target=ring)
+    th.start()
+    time.sleep(0.2)
+    t0 = time.perf_counter()
+    for k in range(5):
+        d = ohs.ConvolutionEngine.new()
+        d.set_ir(0, irs[0][:100 + k])
+        del d
+    gc.collect()
+    dt = time.perf_counter() - t0
+    stop.set(); th.join()
+    assert not errs, errs
+    assert dt < 2.0, f"create / set_ir / destroy next to a busy real-time engine took {dt:.2f} s"

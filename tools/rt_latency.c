@@ -21,6 +21,15 @@ static double now_us(void)
 }
 static int cmp(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return x < y ? -1 : x > y; }
 
+/* "1.23" for b >= a within a second of each other (10 ns ticks), "n/a" for a phase that did not run */
+static const char *fmt_phase(char *buf, size_t cap, uint64_t a, uint64_t b)
+{
+    const int64_t d = (int64_t)(b - a);
+    if (a == 0 || b == 0 || d < 0 || d > 100000000) snprintf(buf, cap, "n/a");
+    else snprintf(buf, cap, "%.2f", (double)d * 0.01);
+    return buf;
+}
+
 static ohs_eq *g_eq = NULL;      /* != NULL: time ohs_chain_process (EQ -> convolution -> gain) instead of process_block */
 
 static int one_call(ohs_engine *e, float *il, float *ir, float *ol, float *orr, size_t n)
@@ -46,18 +55,21 @@ static void run(ohs_engine *e, size_t n, int calls, const char *what)
         if (one_call(e, il, ir, ol, orr, n)) { printf("error: %s\n", ohs_last_error()); exit(1); }
         t[c] = now_us() - t0;
     }
-    {   /* device-side phases of the last call, if the resident kernel served it (10 ns ticks) */
+    {   /* device-side phases of the last call, if the resident kernel served it (10 ns ticks).  A phase that did not
+         * run leaves its stamp behind the next one's (or at zero): differences are taken signed and printed as n/a */
         uint64_t st[16];
+        char buf[8][24];
+#define PHASE(k, a, b) (fmt_phase(buf[k], sizeof(buf[k]), st[a], st[b]))
         if (ohs_engine_debug_rt_stamps(e, st) == 0 && st[4] > st[0] && st[4] - st[0] < 100000)
-            printf("# device phases of the last call [us]: acquire %.2f, body %.2f, drain+barrier %.2f, release %.2f, total %.2f; shader clock %.0f MHz\n",
-                   (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[4] - st[0]) * 0.01,
-                   (double)st[5] / ((st[4] - st[0]) * 0.01));
+            printf("# device phases of the last call [us]: acquire %s, body %s, drain+barrier %s, release %s, total %s; shader clock %.0f MHz\n",
+                   PHASE(0, 0, 1), PHASE(1, 1, 2), PHASE(2, 2, 3), PHASE(3, 3, 4), PHASE(4, 0, 4),
+                   (double)st[5] / ((double)(int64_t)(st[4] - st[0]) * 0.01));
         if (g_eq && st[7] > st[6] && st[7] - st[6] < 100000)
-            printf("# EQ inside the resident kernel [us]: copy-in + table %.2f, EQ %.2f\n", (st[6] - st[0]) * 0.01, (st[7] - st[6]) * 0.01);
+            printf("# EQ inside the resident kernel [us]: copy-in + table %s, EQ %s\n", PHASE(0, 0, 6), PHASE(1, 6, 7));
         if (ohs_engine_debug_rt_stamps(e, st) == 0 && st[14] > st[8] && st[14] - st[8] < 100000)
-            printf("# inside the body [us]: pop %.2f, load+fwd FFT %.2f, barrier %.2f, MAC %.2f, 2 inverse FFTs %.2f, tails+barrier+store %.2f\n",
-                   (st[9] - st[8]) * 0.01, (st[10] - st[9]) * 0.01, (st[11] - st[10]) * 0.01, (st[12] - st[11]) * 0.01,
-                   (st[13] - st[12]) * 0.01, (st[14] - st[13]) * 0.01);
+            printf("# inside the body [us]: pop %s, load+fwd FFT %s, barrier %s, MAC %s, 2 inverse FFTs %s, tails+barrier+store %s\n",
+                   PHASE(0, 8, 9), PHASE(1, 9, 10), PHASE(2, 10, 11), PHASE(3, 11, 12), PHASE(4, 12, 13), PHASE(5, 13, 14));
+#undef PHASE
     }
     qsort(t, (size_t)calls, sizeof(double), cmp);
     if (calls >= 100000)
