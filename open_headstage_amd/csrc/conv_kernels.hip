@@ -1270,7 +1270,8 @@ hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-// I: one wave per (stream, block < n_mac)
+// I: one wave per (stream, block < n_mac); the 2 S trailing waves of the grid turn the last block's spectra into the
+// new state: overlaps (lsl + j lsr) from W1 and (rsl + j rsr) from W - W1 (until round 3 a kernel of their own)
 __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_inverse(const ConvTpArgs A)
 {
     ohs_set_fp_mode(A.fp_mode);
@@ -1281,11 +1282,30 @@ __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_inverse(const ConvTpA
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
     const long long gw = (long long)blockIdx.x * kTpWaves + wave;
-    if (gw >= (long long)A.n_streams * A.n_mac) return;
+    const long long n_main = (long long)A.n_streams * A.n_mac;
+    if (gw >= n_main + 2ll * A.n_streams) return;
+    const float scale = 1.0f / (float)kFft;
+    float2 v[16];
+    if (gw >= n_main) {
+        const size_t s = (size_t)((gw - n_main) >> 1);
+        const int which = (int)((gw - n_main) & 1);
+        const float2 *Wl = A.W + (s * (size_t)A.n_mac + (size_t)(A.n_mac - 1)) * kFft;
+        const float2 *W1 = A.W1 + s * (size_t)kFft;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 w1 = W1[r * 64 + lane];
+            if (which == 0) v[r] = w1;
+            else { const float2 w = Wl[r * 64 + lane]; v[r] = make_float2(w.x - w1.x, w.y - w1.y); }
+        }
+        wave_fft_inv(v, lds, tab, lane);
+        float2 *to = A.tails_out + s * (size_t)(2 * 8 * 64) + (size_t)which * (8 * 64);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) to[a * 64 + lane] = make_float2(v[a + 8].x * scale, v[a + 8].y * scale);
+        return;
+    }
     const size_t s = (size_t)(gw / A.n_mac);
     const int t = (int)(gw % A.n_mac);
     const float2 *Wt = A.W + (s * (size_t)A.n_mac + (size_t)t) * kFft;
-    float2 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = Wt[r * 64 + lane];
     if (t > 0) {
@@ -1299,7 +1319,6 @@ __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_inverse(const ConvTpA
         }
     }
     wave_fft_inv(v, lds, tab, lane);
-    const float scale = 1.0f / (float)kFft;
     float *out_l = A.out + s * A.out_stream_stride;
     float *out_r = out_l + A.out_ch_stride;
     const float2 *tails = A.tails + s * (size_t)(2 * 8 * 64);
@@ -1316,42 +1335,6 @@ __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_inverse(const ConvTpA
         out_r[idx] = orr * A.gain;
     }
 }
-// new state: overlaps of the segment's last block, (lsl + j lsr) from W1 and (rsl + j rsr) from W - W1
-__global__ __launch_bounds__(256) void k_conv_tp_tails(const ConvTpArgs A)
-{
-    ohs_set_fp_mode(A.fp_mode);
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float2 *tab = smem;
-    fill_twiddle_tables(tab, A.tw, threadIdx.x, 256);
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float2 *lds = smem + kTabComplex + wave * kWaveLdsComplex;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
-    if (gw >= (long long)A.n_streams * 2) return;
-    const size_t s = (size_t)(gw >> 1);
-    const int which = (int)(gw & 1);
-    const float2 *Wl = A.W + (s * (size_t)A.n_mac + (size_t)(A.n_mac - 1)) * kFft;
-    const float2 *W1 = A.W1 + s * (size_t)kFft;
-    float2 v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float2 w1 = W1[r * 64 + lane];
-        if (which == 0) v[r] = w1;
-        else { const float2 w = Wl[r * 64 + lane]; v[r] = make_float2(w.x - w1.x, w.y - w1.y); }
-    }
-    wave_fft_inv(v, lds, tab, lane);
-    const float scale = 1.0f / (float)kFft;
-    float2 *to = A.tails_out + s * (size_t)(2 * 8 * 64) + (size_t)which * (8 * 64);
-#pragma unroll
-    for (int a = 0; a < 8; ++a) to[a * 64 + lane] = make_float2(v[a + 8].x * scale, v[a + 8].y * scale);
-}
-hipError_t launch_conv_tp_tails(const ConvTpArgs &a, hipStream_t st)
-{
-    const size_t shmem = (kTabComplex + 4 * kWaveLdsComplex) * sizeof(float2);
-    const long long waves = (long long)a.n_streams * 2;
-    hipLaunchKernelGGL(k_conv_tp_tails, dim3((unsigned)((waves + 3) / 4)), dim3(256), shmem, st, a);
-    return hipGetLastError();
-}
 
 hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st)
 {
@@ -1360,7 +1343,7 @@ hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st)
     static std::atomic<unsigned long long> lds_ok{0};
     const hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_tp_inverse), shmem, lds_ok);
     if (e != hipSuccess) return e;
-    const long long waves = (long long)a.n_streams * a.n_mac;
+    const long long waves = (long long)a.n_streams * a.n_mac + 2ll * a.n_streams;     // + the new state, two waves per stream
     hipLaunchKernelGGL(k_conv_tp_inverse, dim3((unsigned)((waves + kTpWaves - 1) / kTpWaves)), dim3(64 * kTpWaves), shmem, st, a);
     return hipGetLastError();
 }

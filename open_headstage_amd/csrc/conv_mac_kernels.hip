@@ -53,9 +53,14 @@ constexpr int kTB = OHS_MAC_TB;     // output blocks per register tile
 #define OHS_MAC_PI 16
 #endif
 constexpr int kPI = OHS_MAC_PI;     // partitions per register window (Ppad is a multiple of 16, so 8 or 16)
+__device__ __forceinline__ void conv_tp_w1_job(const ConvTpArgs &A, int wg);
+
 __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 {
     ohs_set_fp_mode(A.fp_mode);
+    // the trailing workgroups of the grid compute W1 (below): one launch instead of two, and they fill the slots the
+    // MAC's last round leaves empty
+    if ((int)blockIdx.x >= A.main_wgs) { conv_tp_w1_job(A, (int)blockIdx.x - A.main_wgs); return; }
     // XCD-aware mapping.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own
     // 4 MiB L2; all workgroups of one stream re-read that stream's history ring (P + n_mac spectra,
     // 2.3 MiB on config 4), so a stream's workgroups are given ids that are congruent mod 8: its ring
@@ -110,16 +115,17 @@ __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 
 // The segment's LAST block additionally needs its L-speaker part W1 = sum_i X_l A_i, with
 // X_l = (Z + conj(Zm))/2 and A_i = H_lsl + j H_lsr = C_i + D_i, so that the four per-path overlaps of
-// the state at rest can be rebuilt (W2 = W - W1).  One block per stream: its own tiny kernel, so the
-// main MAC loop carries no per-iteration test for it (that test cost the main kernel 55 %).
-__global__ __launch_bounds__(256) void k_conv_tp_w1(const ConvTpArgs A)
+// the state at rest can be rebuilt (W2 = W - W1).  One block per stream: workgroups of their own (the trailing
+// ones of k_conv_tp_mac's grid, three per stream), so the main MAC loop carries no per-iteration test for it (that
+// test cost the main kernel 55 %); until round 3 they were a kernel of their own.
+__device__ __forceinline__ void conv_tp_w1_job(const ConvTpArgs &A, int wg)
 {
-    ohs_set_fp_mode(A.fp_mode);
-    const int pi = blockIdx.x * 256 + threadIdx.x;
+    const int per_stream = (A.n_pairs + 255) / 256;
+    const int pi = (wg % per_stream) * 256 + (int)threadIdx.x;
     if (pi >= A.n_pairs) return;
     const int b = A.pairs[pi];
     const int mb = mirror_position(b);
-    const size_t s = blockIdx.y;
+    const size_t s = (size_t)(wg / per_stream);
     const float2 *hist = A.hist + s * (size_t)A.cap * kFft;
     const unsigned long long mask = (unsigned long long)(A.cap - 1);
     const unsigned long long last = A.cnt + (unsigned long long)(A.n_mac - 1);
@@ -160,10 +166,9 @@ hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
     const unsigned groups = ((unsigned)a.n_streams + 7u) / 8u;
     const bool xcd_map = getenv("OHS_MAC_NO_XCD") == nullptr;       // tuning experiments
     if (!xcd_map) m.mac_tiles = -m.mac_tiles;
-    hipLaunchKernelGGL(k_conv_tp_mac, dim3(groups * 8u * wps), dim3(256), 0, st, m);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_conv_tp_w1, dim3((a.n_pairs + 255) / 256, a.n_streams), dim3(256), 0, st, a);
+    m.main_wgs = (int)(groups * 8u * wps);
+    const unsigned w1_wgs = (unsigned)((a.n_pairs + 255) / 256) * (unsigned)a.n_streams;
+    hipLaunchKernelGGL(k_conv_tp_mac, dim3((unsigned)m.main_wgs + w1_wgs), dim3(256), 0, st, m);
     return hipGetLastError();
 }
 

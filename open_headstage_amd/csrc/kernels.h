@@ -160,6 +160,8 @@ struct ConvTpArgs {
     const int *pairs;           // leaders b of the 514 position pairs {b, mirror(b)} (device)
     int n_pairs;
     int mac_tiles;              // set by launch_conv_tp_mac: 8-block time tiles per stream
+    int main_wgs;               // set by the launchers: workgroups (MAC) / waves (inverse) of the main job; the grid's
+                                // trailing ones compute W1 / the new state
     float2 *W;                  // [stream][n_mac][1024] scratch
     float2 *W1;                 // [stream][1024]: L-speaker part (lsl + j lsr) of the LAST block's spectrum
     const float2 *tails;        // state in (sum of the two packed tails feeds block 0)
@@ -170,8 +172,7 @@ struct ConvTpArgs {
 };
 hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st);
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st);
-hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st);
-hipError_t launch_conv_tp_tails(const ConvTpArgs &a, hipStream_t st);
+hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st);     // + the new state (the last block's four overlaps)
 int conv_tp_build_pairs(int *out);   // host: fills <= 514 leaders, returns the count
 // CD[i][0] = (A_i - jB_i)/2, CD[i][1] = (A_i + jB_i)/2 for i < Ppad; H_p,i := 0 for i >= P_p
 hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,

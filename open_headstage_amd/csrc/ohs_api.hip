@@ -459,8 +459,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
                 hipError_t e = launch_conv_tp_forward(a, st);
                 if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
-                if (e == hipSuccess) e = launch_conv_tp_inverse(a, st);   // block 0 reads the OLD state
-                if (e == hipSuccess) e = launch_conv_tp_tails(a, st);     // new state -> the other slab
+                if (e == hipSuccess) e = launch_conv_tp_inverse(a, st);   // block 0 reads the OLD state; new state -> the other slab
                 if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp: ") + hipGetErrorString(e));
                 std::swap(c.d_tails, c.d_tails_alt);
                 done += seg;
