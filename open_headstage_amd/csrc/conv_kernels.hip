@@ -858,6 +858,15 @@ hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2,
 #ifndef OHS_P1_WAVES
 #define OHS_P1_WAVES 16
 #endif
+// The audio of k_conv_p1 is read once and written once: non-temporal loads / stores (-2.7 % on config 3 without EQ,
+// three interleaved runs each: 0.583 / 0.577 / 0.587 against 0.605 / 0.595 / 0.594 ms; -DOHS_P1_NO_NT = plain accesses)
+#ifndef OHS_P1_NO_NT
+#define OHS_P1_LD(p) __builtin_nontemporal_load(p)
+#define OHS_P1_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define OHS_P1_LD(p) (*(p))
+#define OHS_P1_ST(p, v) (*(p) = (v))
+#endif
 // waves per workgroup = per CU, four per SIMD.  LDS: 8.5 KiB of twiddle tables + 16 KiB of C / D + 16 slabs of 8672 B
 // = 163 840 B, every byte of the CU's 160 KiB (the w64 table hides in the padding of the w1024 table's rows,
 // wave_fft.hpp, and a slab ends where its last image does).
@@ -985,7 +994,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     const float *pl = in_l + (size_t)b0 * kBlock + lane, *pr = in_r + (size_t)b0 * kBlock + lane;
     float *ql = out_l + (size_t)b0 * kBlock + lane, *qr = out_r + (size_t)b0 * kBlock + lane;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) { xl[a] = pl[64 * a]; xr[a] = pr[64 * a]; }
+    for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
     // Issue arbitration between the four waves of a SIMD is "priority, then age": left alone, the oldest wave of
     // every SIMD runs almost unimpeded and the youngest gets the leftover slots -- waves 0..3 of a workgroup finished
     // their ranges after 156 us, waves 12..15 after 268 us (tools/p1_stamps.py), and a CU's slots stood empty for a
@@ -1029,15 +1038,15 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #else
         wave_fft_inv(w, lds, tab, lane);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) { xl[a] = pl[64 * a]; xr[a] = pr[64 * a]; }
+        for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
 #endif
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
 #ifdef OHS_KO_STORE
             if (w[a].x == 123.456f) {       // never true: the stores stay in the code, none is executed
 #endif
-            ql[64 * a] = (w[a].x + tail[a].x) * A.gain;         // (1/N is in C and D)
-            qr[64 * a] = (w[a].y + tail[a].y) * A.gain;
+            OHS_P1_ST(&ql[64 * a], (w[a].x + tail[a].x) * A.gain);         // (1/N is in C and D)
+            OHS_P1_ST(&qr[64 * a], (w[a].y + tail[a].y) * A.gain);
 #ifdef OHS_KO_STORE
             }
 #endif

@@ -1571,10 +1571,29 @@ int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch *
         delete b;
         return fail(OHS_ERR_HIP, "hipStreamCreate failed");
     }
-    if (hipStreamCreateWithFlags(&b->st2, hipStreamNonBlocking) != hipSuccess) {
-        hipStreamDestroy(b->st);
-        delete b;
-        return fail(OHS_ERR_HIP, "hipStreamCreate failed");
+    {
+        // experiment: OHS_CONV_CU_MASK="w0,w1,..." (hex words, bit i = CU i) confines the overlapped convolution's
+        // stream to a CU set (hipExtStreamCreateWithCUMask)
+        hipError_t se = hipErrorUnknown;
+        if (const char *m = getenv("OHS_CONV_CU_MASK")) {
+            std::vector<uint32_t> mask;
+            const char *p = m;
+            while (*p) {
+                char *end = nullptr;
+                const unsigned long v = strtoul(p, &end, 16);
+                if (end == p) break;
+                mask.push_back((uint32_t)v);
+                p = (*end == ',') ? end + 1 : end;
+            }
+            if (!mask.empty()) se = hipExtStreamCreateWithCUMask(&b->st2, (uint32_t)mask.size(), mask.data());
+            if (se != hipSuccess) fprintf(stderr, "[ohs] OHS_CONV_CU_MASK ignored: %s\n", hipGetErrorString(se));
+        }
+        if (se != hipSuccess) se = hipStreamCreateWithFlags(&b->st2, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            hipStreamDestroy(b->st);
+            delete b;
+            return fail(OHS_ERR_HIP, "hipStreamCreate failed");
+        }
     }
     {
         // EQ || convolution overlap policy.  An EQ wave saturates the vector unit of its SIMD (every instruction of

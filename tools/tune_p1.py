@@ -26,8 +26,8 @@ for p in range(4):
 bp.set_eq_enabled(False)
 x = synth.white_noise_torch(0, S, frames, dev)
 y = torch.empty_like(x)
-settings = [dict(OHS_P1_TARGET_WAVES=str(tw), OHS_P1_STAGGER=str(sg))
-            for tw, sg in itertools.product((3840, 4096, 7680, 8192, 11520, 12288), (0,))]
+targets = [int(t) for t in os.environ.get("TUNE_P1_TARGETS", "3840,4096,7680,8192,11520,12288").split(",")]
+settings = [dict(OHS_P1_TARGET_WAVES=str(tw), OHS_P1_STAGGER=str(sg)) for tw, sg in itertools.product(targets, (0,))]
 res = {i: [] for i in range(len(settings))}
 for rnd in range(6):
     for i, st in enumerate(settings):
