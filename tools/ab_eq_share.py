@@ -16,7 +16,7 @@ import open_headstage_amd as ohs  # noqa: E402
 from open_headstage_amd import synth  # noqa: E402
 
 FRAMES = 480256
-KNOBS = ("OHS_CONV_CU_MASK", "OHS_EQ_LDS", "OHS_EQ_RING_V1", "OHS_EQ_NO_PRIO", "OHS_EQ_WG_WAVES", "OHS_NO_OVERLAP", "OHS_OVERLAP_CUTS", "OHS_P1_TARGET_WAVES",
+KNOBS = ("OHS_AB_SIDE_STREAM", "OHS_CONV_CU_MASK", "OHS_EQ_LDS", "OHS_EQ_RING_V1", "OHS_EQ_NO_PRIO", "OHS_EQ_WG_WAVES", "OHS_NO_OVERLAP", "OHS_OVERLAP_CUTS", "OHS_P1_TARGET_WAVES",
          "OHS_EQ_PRIO", "OHS_LIB")
 
 
@@ -31,13 +31,17 @@ def run(S, steps=4, warmup=3):
     bp.set_eq_enabled(True)
     x = synth.white_noise_torch(0, S, FRAMES, dev)
     y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    # OHS_AB_SIDE_STREAM=1: the calls go to a non-blocking stream of their own instead of the legacy default stream
+    side = torch.cuda.Stream() if os.environ.get("OHS_AB_SIDE_STREAM") == "1" else None
+    hs = side.cuda_stream if side is not None else None
     for _ in range(warmup):
-        bp.process(x, out=y)
+        bp.process(x, out=y, hip_stream=hs)
     torch.cuda.synchronize()
     bp.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        bp.process(x, out=y)
+        bp.process(x, out=y, hip_stream=hs)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     eq_ms, conv_ms, n, _, _ = bp.profile_read()
