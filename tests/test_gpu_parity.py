@@ -505,6 +505,44 @@ def test_batch_strided_buffers(ohs, synth, oracle):
         assert_parity(o[s_, :, :frames], np.stack([l, r]), f"strided stream {s_}")
 
 
+def test_batch_strides_beyond_32_bit_lane_offsets(ohs, synth, oracle):
+    """The ring-form EQ addresses a lane's samples by a 32-bit byte offset from its wave's base (the offset spans the
+    wave's two streams): a stream stride of 2^30 floats (4 GiB) does not fit, the launcher must take the conveyor form
+    (64-bit addresses) -- same bits -- and the convolution its own 64-bit stream offsets."""
+    import torch
+    S, frames = 2, 1536
+    ss, cs = 1 << 30, 4096
+    irs = synth.hrir_set(512)
+    bp = ohs.BatchProcessor(S, num_bands=10)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i, b in enumerate(synth.eq_table()):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(True)
+    x = synth.white_noise(range(S), frames)
+    n = (S - 1) * ss + cs + frames
+    big = torch.zeros(n, device="cuda")
+    out = torch.zeros(n, device="cuda")
+    for s_ in range(S):
+        for c in range(2):
+            big[s_ * ss + c * cs: s_ * ss + c * cs + frames] = torch.from_numpy(x[s_, c]).cuda()
+    bp.process_ptr(big.data_ptr(), out.data_ptr(), frames // 512, ss, cs, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for s_ in range(S):
+        eo = oracle.ConvolutionEngine()
+        for p in range(4):
+            eo.set_ir(p, irs[p])
+        qo = oracle.StereoParametricEQ(10, synth.FS)
+        for i, b in enumerate(synth.eq_table()):
+            qo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+        l, r = x[s_, 0].copy(), x[s_, 1].copy()
+        oracle.chain_process(eo, qo, l, r, eq_enable=True, gain=1.0)
+        got = np.stack([out[s_ * ss + c * cs: s_ * ss + c * cs + frames].cpu().numpy() for c in range(2)])
+        assert_parity(got, np.stack([l, r]), f"far-apart stream {s_}")
+    del big, out
+    torch.cuda.empty_cache()
+
+
 def test_autoeq_profile_drives_the_eq_bit_exact(ohs, synth, oracle):
     """f3 end to end: CSV -> bands -> coefficients -> EQ kernel, bit-exact against the oracle fed the
     same parsed rows."""
