@@ -292,6 +292,12 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) v[rr] = lds_ld(&lds[t2_index(rr, rbase)]);   // rr = 4 p_lo + c
     float2 m[16];
+#ifdef OHS_KO_MIRROR    // timing experiment (wrong results): no mirror reads, no mirror DFT4s
+    if constexpr (MIRROR) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) m[rr] = v[15 - rr];
+    }
+#else
     if constexpr (MIRROR) {
         const int la = 63 - lane, lb = (64 - lane) & 63;
         const int rbA = t2_sigma(la >> 2, la & 3), rbB = t2_sigma(lb >> 2, lb & 3);
@@ -300,6 +306,7 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
 #pragma unroll
         for (int rr = 4; rr < 16; ++rr) m[rr] = lds_ld(&lds[t2_index(rr, rbA)]);              // groups j' = 1..3 of lane 63 - L
     }
+#endif
     wave_lds_sync();
     // DFT4 over c for each j = p_lo; result to reg 4 r + j
 #pragma unroll
@@ -312,8 +319,10 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
     t = v[7];  v[7] = v[13];  v[13] = t;
     t = v[11]; v[11] = v[14]; v[14] = t;
     if constexpr (MIRROR) {
+#ifndef OHS_KO_MIRROR
 #pragma unroll
         for (int j = 0; j < 4; ++j) dft4<false>(m[4 * j], m[4 * j + 1], m[4 * j + 2], m[4 * j + 3]);   // m[4 j' + r']
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -357,9 +366,17 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
+#ifdef OHS_KO_MIRROR_TW   // timing experiment: one w64 read per (j, c) as a paired bin layout would need
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 w = OHS_TW_LD(&tab[tabB_index((lane >> 2) ^ (3 * j), c)]);
+            v[4 * j + c] = cmulc(v[4 * j + c], w);
+        }
+#else
         const float2 w = OHS_TW_LD(&tab[tabB_index(lane >> 2, c)]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
+#endif
     }
     const int rbase = t2_sigma(lane >> 2, lane & 3);
 #pragma unroll
