@@ -928,8 +928,22 @@ extern "C" int ohs_debug_p1_clk(unsigned long long *out, size_t n_waves)
                                     hipMemcpyDeviceToHost);
 }
 #endif
+// workgroup index inside the launch's XCD set, or -1 for a workgroup on another XCD (kernels.h: xcd_grid)
+__device__ __forceinline__ long long p1_xcd_block(const ConvP1Args &A)
+{
+    unsigned bid = blockIdx.x;
+    if (A.xcd_n != 8) {
+        const unsigned x = (bid & 7u) - (unsigned)A.xcd_lo;
+        if (x >= (unsigned)A.xcd_n) return -1;
+        bid = (bid >> 3) * (unsigned)A.xcd_n + x;
+    }
+    return (long long)bid;
+}
+
 __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 {
+    const long long wg = p1_xcd_block(A);
+    if (wg < 0) return;
     ohs_set_fp_mode(A.fp_mode);
 #ifdef OHS_P1_STAMPS
     const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
@@ -950,7 +964,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     // pointers then cost no VGPRs and the address arithmetic runs on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + 2 * kFft + wave * kWaveLdsComplex;
-    const long long gw = (long long)blockIdx.x * kP1Waves + wave;
+    const long long gw = wg * kP1Waves + wave;
     if (gw >= (long long)A.n_streams * A.chunks) return;
     const int s = (int)(gw / A.chunks);
     const int ck = (int)(gw % A.chunks);
@@ -1125,6 +1139,8 @@ __global__ __launch_bounds__(64 * kP1StateWaves) void k_conv_p1_state(const Conv
 
 __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Args A)
 {
+    const long long wg = p1_xcd_block(A);
+    if (wg < 0) return;
     ohs_set_fp_mode(A.fp_mode);
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
@@ -1140,7 +1156,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Arg
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + 2 * kFft + wave * kWaveLdsComplex;
-    const long long gw = (long long)blockIdx.x * kP1Waves + wave;
+    const long long gw = wg * kP1Waves + wave;
     if (gw >= (long long)A.n_streams * (A.chunks - 1)) return;
     const int s = (int)(gw / (A.chunks - 1));
     const int e = 1 + (int)(gw % (A.chunks - 1));
@@ -1170,6 +1186,7 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
     if (a.n_blocks <= 0 || a.n_streams <= 0 || a.chunks < 1) return hipErrorInvalidValue;
     if (a.chunks > a.n_blocks) return hipErrorInvalidValue;
     if ((unsigned long long)a.n_blocks * kBlock >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit frame offsets
+    if (a.xcd_n < 1 || a.xcd_n > 8 || a.xcd_lo < 0 || a.xcd_lo + a.xcd_n > 8) return hipErrorInvalidValue;
     const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
     {   // 1a. the state the launch leaves behind
         const size_t shmem_state = (kTabComplex + kP1StateWaves * kWaveLdsComplex) * sizeof(float2);
@@ -1184,8 +1201,8 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1_edges), shmem_main, lds_ok);
         if (e != hipSuccess) return e;
         const long long waves = (long long)a.n_streams * (a.chunks - 1);
-        hipLaunchKernelGGL(k_conv_p1_edges, dim3((unsigned)((waves + kP1Waves - 1) / kP1Waves)), dim3(64 * kP1Waves),
-                           shmem_main, st, a);
+        hipLaunchKernelGGL(k_conv_p1_edges, dim3(xcd_grid((unsigned)((waves + kP1Waves - 1) / kP1Waves), a.xcd_n)),
+                           dim3(64 * kP1Waves), shmem_main, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1194,8 +1211,8 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
         static std::atomic<unsigned long long> lds_ok{0};
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1), shmem_main, lds_ok);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_conv_p1, dim3((unsigned)((waves + kP1Waves - 1) / kP1Waves)), dim3(64 * kP1Waves),
-                           shmem_main, st, a);
+        hipLaunchKernelGGL(k_conv_p1, dim3(xcd_grid((unsigned)((waves + kP1Waves - 1) / kP1Waves), a.xcd_n)),
+                           dim3(64 * kP1Waves), shmem_main, st, a);
         return hipGetLastError();
     }
 }

@@ -39,7 +39,7 @@ constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
 // pass-on lanes run 1*x + 0).
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
                           long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
-                          hipStream_t st, bool exact_specials = false, int fp_mode = 0);
+                          hipStream_t st, bool exact_specials = false, int fp_mode = 0, int xcd_lo = 0, int xcd_n = 8);
 
 // |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
 hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,
@@ -114,6 +114,16 @@ hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned 
 // Fast path when every path has exactly one partition (taps <= 512): time-parallel over
 // `chunks` contiguous block ranges per stream, one forward + one inverse FFT per block, the
 // combined spectra C = (A - jB)/2, D = (A + jB)/2 (A = H0 + jH1, B = H2 + jH3) held in LDS.
+// XCD partition of a launch.  The dispatcher hands workgroup b of a grid to XCD b % 8 (MI355X: 8 XCDs of 32 CUs, each
+// with its own L2); a kernel confined to the XCDs [lo, lo + n) is launched with xcd_grid(workgroups, n) workgroups, those
+// on other XCDs return at once and the rest renumber themselves ((b >> 3) * n + (b & 7) - lo).  ohs_batch_process gives
+// the EQ and the overlapped convolution disjoint XCD sets: an EQ wave saturates the vector unit of its SIMD, and a
+// convolution workgroup that shares a CU with one waits for its starved waves.
+inline unsigned xcd_grid(unsigned workgroups, int xcd_n)
+{
+    return xcd_n == 8 ? workgroups : ((workgroups + (unsigned)xcd_n - 1) / (unsigned)xcd_n) * 8u;
+}
+
 struct ConvP1Args {
     const float *in;
     float *out;
@@ -133,6 +143,7 @@ struct ConvP1Args {
     int prio_mode;              // issue priority of the waves: 0 = hardware default (oldest first), 1 = rotating per block
     int weights[4];             // relative length of a chunk by the age rank of the wave that runs it (conv_kernels.hip: p1_chunk_begin)
     int fp_mode;                // denormal handling, see ohs_set_fp_mode
+    int xcd_lo, xcd_n;          // XCDs the main and edges kernels may use (xcd_grid); 0, 8 = all
 };
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
 int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)

@@ -182,6 +182,7 @@ struct ConvState {
     size_t w_blocks = 0;
     float2 *d_W1 = nullptr;         // [S][1024]
     int fp_mode = 0;                // denormal handling of every launch on this state (kernels.h: ohs_set_fp_mode)
+    int xcd_lo = 0, xcd_n = 8;      // XCDs the P = 1 kernels may use (kernels.h: xcd_grid); set per call by the batch
 };
 
 void conv_free(ConvState &c)
@@ -307,9 +308,9 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
 // S * K that FILLS its last round -- all waves of a launch take the same time, so 2.13 rounds cost 3 (1024 and
 // 2048 streams with K = ceil(2 R / S) ran at 71 % for that reason).  K is the smallest value from ceil(2 R / S)
 // upwards whose last round is >= 97 % full (S * K = 8 R at 2048 streams).
-long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override)
+long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override, int xcd_n = 8)
 {
-    const long long R = (long long)ctx->num_cus * conv_p1_waves_per_cu();
+    const long long R = (long long)ctx->num_cus * xcd_n / 8 * conv_p1_waves_per_cu();
     long long K;
     if (target_override > 0) {
         K = (target_override + (long long)S - 1) / (long long)S;
@@ -347,7 +348,12 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         // tuning experiments (read per call so that one process can sweep them: tools/tune_p1.py)
         const char *env_tw = getenv("OHS_P1_TARGET_WAVES");
         const long long target_override = env_tw ? atoll(env_tw) : 0LL;
-        const long long K = conv_p1_chunks(ctx, c.S, n_blocks, target_override);
+        int xcd_lo = c.xcd_lo, xcd_n = c.xcd_n;
+        if (const char *env_x = getenv("OHS_P1_XCD")) {         // tuning experiments: "lo,n" for every P = 1 launch
+            int lo = 0, n = 8;
+            if (sscanf(env_x, "%d,%d", &lo, &n) == 2 && n >= 1 && lo >= 0 && lo + n <= 8) { xcd_lo = lo; xcd_n = n; }
+        }
+        const long long K = conv_p1_chunks(ctx, c.S, n_blocks, target_override, xcd_n);
         if ((size_t)K > c.chunk_tails_cap) {
             DeviceWideSection dws;
             HIP_TRY(hipStreamSynchronize(st));
@@ -365,6 +371,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
         a.tails = c.d_tails; a.tails_out = c.d_tails_alt; a.chunk_tails = c.d_chunk_tails;
         a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
+        a.xcd_lo = xcd_lo; a.xcd_n = xcd_n;
         const char *env_sg = getenv("OHS_P1_STAGGER");          // tuning experiments
         a.stagger = env_sg ? atoi(env_sg) : 0;
         const char *env_pr = getenv("OHS_P1_PRIO");             // tuning experiments: 1 = rotate the issue priority per block
@@ -480,6 +487,7 @@ struct EqState {
     float *d_state = nullptr;    // [chains][kEqStateSlots][2], indexed by band
     bool exact_specials = false; // ohs_*_set_eq_exact_specials: conveyor kernel, exact for -0.0 / around non-finite input
     int fp_mode = 0;             // denormal handling (kernels.h: ohs_set_fp_mode)
+    int xcd_lo = 0, xcd_n = 8;   // XCDs the ring kernel's launches may use (kernels.h: xcd_grid); set per call by the batch
 };
 
 using ohs_host::rbj;
@@ -550,7 +558,13 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
                 t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
             }
         }
-        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials, e.fp_mode);
+        int xcd_lo = e.xcd_lo, xcd_n = e.xcd_n;
+        if (const char *env_x = getenv("OHS_EQ_XCD")) {         // tuning experiments: "lo,n" for every ring launch
+            int lo = 0, n = 8;
+            if (sscanf(env_x, "%d,%d", &lo, &n) == 2 && n >= 1 && lo >= 0 && lo + n <= 8) { xcd_lo = lo; xcd_n = n; }
+        }
+        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials, e.fp_mode,
+                                        xcd_lo, xcd_n);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
         did = true;
@@ -662,6 +676,7 @@ struct ohs_batch {
     float gain = 1.0f;
     hipStream_t st2 = nullptr;  // convolution of time chunk i runs here while the EQ of chunk i+1 runs on the caller's stream
     bool overlap = true;
+    int xcd_split = 0;          // x > 0: overlapped calls run the EQ on XCDs [0, x) and the convolution on [x, 8)
     // optional per-kernel timing: (begin, end, kind) event pairs; kind 0 = EQ, 1 = convolution
     bool profiling = false;
     struct Span { hipEvent_t a, b; int kind; };
@@ -1610,6 +1625,11 @@ int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch *
         b->overlap = eq_cus * 8 <= (size_t)cus * 7;
         if (e && e[0] == '1') b->overlap = false;
         if (f && f[0] == '1') b->overlap = true;
+        // experiment: OHS_XCD_SPLIT=x gives the EQ launches XCDs [0, x) and the overlapped convolution [x, 8)
+        if (const char *x = getenv("OHS_XCD_SPLIT")) {
+            const int v = atoi(x);
+            if (v >= 1 && v <= 7) b->xcd_split = v;
+        }
     }
     rc = conv_init(b->conv, n_streams, b->st);
     if (rc == OHS_OK) rc = eq_init(b->eq, num_bands, 2 * n_streams, 48000.0f, b->st);
@@ -1823,6 +1843,15 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
         return c;
     }();
     const int nch = (b->overlap && n_blocks >= 64) ? (int)kCut.size() - 1 : 1;
+    // XCD partition of the overlapped launches: the EQ on XCDs [0, x), the convolution on [x, 8)
+    struct XcdScope {
+        ohs_batch *b;
+        XcdScope(ohs_batch *b_, int x) : b(b_)
+        {
+            if (x > 0 && x < 8) { b->eq.xcd_lo = 0; b->eq.xcd_n = x; b->conv.xcd_lo = x; b->conv.xcd_n = 8 - x; }
+        }
+        ~XcdScope() { b->eq.xcd_lo = 0; b->eq.xcd_n = 8; b->conv.xcd_lo = 0; b->conv.xcd_n = 8; }
+    } xcd_scope(b, nch > 1 ? b->xcd_split : 0);
     for (int i = 0; i < nch; ++i) {
         const size_t blk0 = nch == 1 ? 0 : (size_t)(kCut[i] * (double)n_blocks);
         const size_t blk1 = nch == 1 ? n_blocks : (i == nch - 1 ? n_blocks : (size_t)(kCut[i + 1] * (double)n_blocks));

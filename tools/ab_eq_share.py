@@ -16,7 +16,7 @@ import open_headstage_amd as ohs  # noqa: E402
 from open_headstage_amd import synth  # noqa: E402
 
 FRAMES = 480256
-KNOBS = ("OHS_AB_SIDE_STREAM", "OHS_CONV_CU_MASK", "OHS_EQ_LDS", "OHS_EQ_RING_V1", "OHS_EQ_NO_PRIO", "OHS_EQ_WG_WAVES", "OHS_NO_OVERLAP", "OHS_OVERLAP_CUTS", "OHS_P1_TARGET_WAVES",
+KNOBS = ("OHS_P1_XCD", "OHS_EQ_XCD", "OHS_XCD_SPLIT", "OHS_FORCE_OVERLAP", "OHS_AB_SIDE_STREAM", "OHS_CONV_CU_MASK", "OHS_EQ_LDS", "OHS_EQ_RING_V1", "OHS_EQ_NO_PRIO", "OHS_EQ_WG_WAVES", "OHS_NO_OVERLAP", "OHS_OVERLAP_CUTS", "OHS_P1_TARGET_WAVES",
          "OHS_EQ_PRIO", "OHS_LIB")
 
 

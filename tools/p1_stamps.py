@@ -46,6 +46,8 @@ assert rc == 0, rc
 st = np.frombuffer(buf, dtype=np.uint64).reshape(n_waves, 4).astype(np.int64)
 ok = st[:, 2] > 0
 st = st[ok]
+xcc = (st[:, 3] >> 32) & 0xF
+print("waves per XCC id:", {int(k): int(v) for k, v in zip(*np.unique(xcc, return_counts=True))})
 t0 = st[:, 0].min()
 entry, start, end = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, (st[:, 2] - t0) / 100.0      # microseconds
 print(f"waves {len(st)}; kernel span {end.max():.1f} us; wave life (start->end) mean {np.mean(end - start):.1f} us, "
@@ -63,6 +65,8 @@ print(f"workgroups {g}: span mean {np.mean(wg_end - wg_entry):.1f} us; inside a 
       f"slot use inside a workgroup {np.mean(life.sum(1) / (16 * (wg_end - wg_entry))):.1%}")
 order = np.argsort(wg_entry)
 first, second = order[:256], order[256:]
+if len(second) == 0:
+    second = first
 print(f"first round: entry {wg_entry[first].min():.1f}..{wg_entry[first].max():.1f} us, end {wg_end[first].min():.1f}.."
       f"{wg_end[first].max():.1f}; second round: entry {wg_entry[second].min():.1f}..{wg_entry[second].max():.1f}, "
       f"end {wg_end[second].min():.1f}..{wg_end[second].max():.1f}")
