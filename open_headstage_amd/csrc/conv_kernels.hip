@@ -890,6 +890,22 @@ __device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float
     }
 }
 
+// The same product in the paired bin layout of k_conv_p1 (wave_fft.hpp): the mirror values are the lane's own
+// registers; cd holds C and D in that layout ([16][64] float4, filled by the kernel).  Operation for operation the
+// arithmetic of p1_spectral_product.
+__device__ __forceinline__ void p1_spectral_product_paired(const float2 (&z)[16], float2 (&w)[16], const float2 *cd, int lane)
+{
+    const bool lane32 = lane == 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float2 zz = z[i], m = paired_mirror(z, i >> 2, i & 3, lane32);
+        float2 c, d;
+        lds_ld2(reinterpret_cast<const float4 *>(cd) + i * 64 + lane, c, d);
+        w[i].x = fmaf(m.y, d.y, fmaf(m.x, d.x, fmaf(-zz.y, c.y, zz.x * c.x)));
+        w[i].y = fmaf(-m.y, d.x, fmaf(m.x, d.y, fmaf(zz.y, c.x, zz.x * c.y)));
+    }
+}
+
 // First block of chunk ck of stream s.  Chunk (s, ck) is the work of wave (s * chunks + ck) % 16 of its workgroup,
 // and a wave's speed depends on that index: issue arbitration among the four waves of a SIMD is oldest first, so
 // waves 0..3 of a workgroup (the oldest of their SIMDs) run 2.3x as fast as waves 12..15 while all sixteen are
@@ -952,10 +968,15 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     float2 *tab = smem;
     float2 *cd = smem + kTabComplex;                    // [2][16][64]
     fill_twiddle_tables(tab, A.tw, threadIdx.x, 64 * kP1Waves);
-    {   // C and D interleaved position by position: cd4[i] = (C[i], D[i])
+    {   // C and D interleaved position by position: cd4[i] = (C[i], D[i]) -- i in the layout the block loop computes in
         float4 *dst = reinterpret_cast<float4 *>(cd);
         for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) {
-            const float2 c = A.CD[i], d = A.CD[kFft + i];
+#ifndef OHS_P1_NATURAL
+            const int src = paired_to_natural(i & 63, i >> 6);
+#else
+            const int src = i;
+#endif
+            const float2 c = A.CD[src], d = A.CD[kFft + src];
             dst[i] = make_float4(c.x, c.y, d.x, d.y);
         }
     }
@@ -1017,6 +1038,9 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     // every level a quarter of the time and all sixteen finish together.
     const int age_rank = wave >> 2;
     int prio_phase = age_rank;
+#if !defined(OHS_P1_BPERMUTE_MIRROR) && !defined(OHS_P1_NATURAL)
+    const PairedPlan plan = paired_plan(lane);
+#endif
     for (int t = b0; t < b1; ++t) {
         if (A.prio_mode == 1) {
             switch (prio_phase & 3) {       // (s_setprio takes an immediate)
@@ -1034,23 +1058,32 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
             v[a + 8] = make_float2(0.0f, 0.0f);
         }
         float2 w[16];
-#ifdef OHS_P1_BPERMUTE_MIRROR
+#if defined(OHS_P1_BPERMUTE_MIRROR)
         wave_fft_fwd_zpad(v, lds, tab, lane);
         wave_mirror(v, w, lane);
-#else
-        wave_fft_fwd_mirror(v, w, lds, tab, lane);
-#endif
         p1_spectral_product(v, w, cd, lane);
+#elif defined(OHS_P1_NATURAL)
+        wave_fft_fwd_mirror(v, w, lds, tab, lane);
+        p1_spectral_product(v, w, cd, lane);
+#else
+        wave_fft_fwd_paired(v, lds, tab, lane, plan);
+        p1_spectral_product_paired(v, w, cd, lane);
+#endif
         // the prefetch of block t + 1 needs no guard except behind the launch's last block, where it re-reads that
         // block (its own frames: in bounds; the values are never used)
         const int adv = (t + 1 < A.n_blocks) ? kBlock : 0;
         pl += adv; pr += adv;
+#if defined(OHS_P1_BPERMUTE_MIRROR) || defined(OHS_P1_NATURAL)
+#define OHS_P1_INV(w) wave_fft_inv(w, lds, tab, lane)
+#else
+#define OHS_P1_INV(w) wave_fft_inv_paired(w, lds, tab, lane, plan)
+#endif
 #ifdef OHS_P1_PREFETCH_EARLY
 #pragma unroll
-        for (int a = 0; a < 8; ++a) { xl[a] = pl[64 * a]; xr[a] = pr[64 * a]; }
-        wave_fft_inv(w, lds, tab, lane);
+        for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
+        OHS_P1_INV(w);
 #else
-        wave_fft_inv(w, lds, tab, lane);
+        OHS_P1_INV(w);
 #pragma unroll
         for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
 #endif

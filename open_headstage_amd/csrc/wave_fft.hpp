@@ -249,9 +249,10 @@ __host__ __device__ __forceinline__ constexpr int t2_index(int rr, int sigma) { 
 // j == 0, of lane 64 - L -- and runs four more DFT4s: 16 ds_read_b64 + 64 adds instead of the 32
 // ds_bpermute_b32 of wave_mirror (5.7 LDS cycles each, tools/ubench_lds.py).
 // ZPAD: the caller guarantees v[8..15] == 0 on entry (a 512-frame block padded to 1024).
-template <bool MIRROR, bool ZPAD>
-__device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[16], float2 *lds, const float2 *tab,
-                                                  int lane)
+// forward transform up to and including the T2 write: on return the T2 image holds, at t2_index(4 j + c, sigma(L)),
+// input c of the last stage's 4-point group (L, j) -- the group whose outputs are the bins 4 L + j + 256 r
+template <bool ZPAD>
+__device__ __forceinline__ void wave_fft_fwd_head(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
 {
     dft16<false, ZPAD>(v);                                  // over a -> p
     {
@@ -288,6 +289,13 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
 #pragma unroll
     for (int q = 0; q < 16; ++q) lds_st(&lds[t2_index(rrw, t2_sigma(q, p_hi))], v[q]);  // T2
     wave_lds_sync();
+}
+
+template <bool MIRROR, bool ZPAD>
+__device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[16], float2 *lds, const float2 *tab,
+                                                  int lane)
+{
+    wave_fft_fwd_head<ZPAD>(v, lds, tab, lane);
     const int rbase = t2_sigma(lane >> 2, lane & 3);
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) v[rr] = lds_ld(&lds[t2_index(rr, rbase)]);   // rr = 4 p_lo + c
@@ -352,6 +360,8 @@ __device__ __forceinline__ void wave_fft_fwd_mirror(float2 (&v)[16], float2 (&zm
     wave_fft_fwd_impl<true, true>(v, zm, lds, tab, lane);
 }
 
+__device__ __forceinline__ void wave_fft_inv_tail(float2 (&v)[16], float2 *lds, const float2 *tab, int lane);
+
 // bin layout -> time layout (unnormalised inverse DFT)
 __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
 {
@@ -382,6 +392,12 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) lds_st(&lds[t2_index(rr, rbase)], v[rr]);     // T2'
     wave_lds_sync();
+    wave_fft_inv_tail(v, lds, tab, lane);
+}
+
+// inverse transform from the T2' image on (the counterpart of wave_fft_fwd_head)
+__device__ __forceinline__ void wave_fft_inv_tail(float2 (&v)[16], float2 *lds, const float2 *tab, int lane)
+{
     const int pp = lane >> 2, c = lane & 3;
     const int p_lo = pp & 3, p_hi = pp >> 2;
     const int rrw = 4 * p_lo + c;
@@ -407,6 +423,138 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     wave_lds_sync();
 #endif
     dft16<true>(v);                                         // over p -> a
+}
+
+// ---------------------------------------------------------------------------------
+// Paired bin layout (k_conv_p1): bins k and N - k in the SAME lane, so that W = Z C + conj(Z[N-k]) D needs no
+// mirror spectrum -- none of the 16 extra ds_read_b64 and four extra DFT4s of wave_fft_fwd_mirror.  The last
+// forward stage is a DFT4 per group (L', j) -> bins 4 L' + j + 256 r, and the mirror of group (L', j) is the group
+// (63 - L', 4 - j) with r reversed (j = 0: (64 - L', 0); (0, 0) and (32, 0) mirror themselves).  Lane L therefore takes
+// four groups, slot g -> register 4 g + r:
+//     g = 0: (L, 1)          g = 1: (63 - L, 3)                               mirrors of each other, r <-> 3 - r
+//     g = 2: (L, 2)          g = 3: (63 - L, 2)          lanes  0..31         mirrors of each other, r <-> 3 - r
+//     g = 2: (L, 0)          g = 3: (64 - L, 0)          lanes 33..63         mirrors of each other, r <-> 3 - r
+//     g = 2: (32, 0)         g = 3: (0, 0)               lane 32              each its own mirror (r <-> 3 - r, r <-> (4 - r) & 3)
+// Per instruction and 32-lane half the group index j is uniform and the lanes L' are a permutation of one half (per
+// 16 lanes of a write: of a set with the same bank census), so the bank behaviour is that of the natural layout
+// (tools/proto_wave_fft.py checks coverage, mirror map, numerics and the census).  The inverse transform pays with
+// w64 rows per slot -- slots 0 and 2 hold groups of the lane itself (row L >> 2), slots 1 and 3 have rows of their
+// own: 9 table reads instead of 3.  The arithmetic per bin is that of the natural layout, operation for operation:
+// results are bit-identical.
+// ---------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ constexpr void paired_group(int lane, int g, int &lg, int &j)
+{
+    if (g == 0) { lg = lane; j = 1; }
+    else if (g == 1) { lg = 63 - lane; j = 3; }
+    else if (lane < 32) { lg = g == 2 ? lane : 63 - lane; j = 2; }
+    else { lg = g == 2 ? lane : (64 - lane) & 31; j = 0; }      // (lane 32: slot 3 = group (0, 0))
+}
+// position in the natural bin layout (register * 64 + lane) of the bin that paired register 4 g + r of `lane` holds
+__host__ __device__ __forceinline__ constexpr int paired_to_natural(int lane, int reg)
+{
+    int lg = 0, j = 0;
+    paired_group(lane, reg >> 2, lg, j);
+    return (4 * (reg & 3) + j) * 64 + lg;
+}
+// per-lane constants of the paired layout: T2-image offset of a slot's element c = 0 (element c: + 65 c) and the
+// slot's row of the w64 table (entry c: + c)
+struct PairedPlan {
+    int t2[4];
+    int tw[4];
+};
+__device__ __forceinline__ PairedPlan paired_plan(int lane)
+{
+    PairedPlan p;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int lg = 0, j = 0;
+        paired_group(lane, g, lg, j);
+        p.t2[g] = t2_index(4 * j, t2_sigma(lg >> 2, lg & 3));
+        p.tw[g] = tabB_index(lg >> 2, 0);
+    }
+    return p;
+}
+
+// zero-padded block in (v[8..15] == 0), spectrum in the paired layout out
+__device__ __forceinline__ void wave_fft_fwd_paired(float2 (&v)[16], float2 *lds, const float2 *tab, int lane,
+                                                    const PairedPlan &pl)
+{
+    wave_fft_fwd_head<true>(v, lds, tab, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * g + c] = lds_ld(&lds[pl.t2[g] + 65 * c]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dft4<false>(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);     // c -> r
+}
+
+// the paired register of the same lane that holds bin N - k for the bin k of register 4 g + r
+__host__ __device__ __forceinline__ constexpr int paired_mirror_reg(int g, int r, bool lane32)
+{
+    if (g == 0) return 4 + (3 - r);
+    if (g == 1) return 3 - r;
+    if (lane32) return 4 * g + (g == 2 ? 3 - r : (4 - r) & 3);
+    return (g == 2 ? 12 : 8) + (3 - r);
+}
+// compile-time check of the plan: every DFT4 group in exactly one slot, every mirror in the lane that needs it
+constexpr bool paired_layout_ok()
+{
+    bool seen[256] = {};
+    for (int lane = 0; lane < 64; ++lane)
+        for (int g = 0; g < 4; ++g) {
+            int lg = 0, j = 0;
+            paired_group(lane, g, lg, j);
+            if (lg < 0 || lg > 63 || seen[4 * lg + j]) return false;
+            seen[4 * lg + j] = true;
+            for (int r = 0; r < 4; ++r) {
+                const int m = paired_mirror_reg(g, r, lane == 32);
+                int lm = 0, jm = 0;
+                paired_group(lane, m >> 2, lm, jm);
+                if ((4 * lg + j + 256 * r + 4 * lm + jm + 256 * (m & 3)) % kFft != 0) return false;
+            }
+        }
+    return true;
+}
+static_assert(paired_layout_ok(), "paired bin layout: coverage / mirror map");
+
+// the mirror value Z[N - k] of paired register 4 g + r, from the lane's own registers
+__device__ __forceinline__ float2 paired_mirror(const float2 (&z)[16], int g, int r, bool lane32)
+{
+    if (g < 2) return z[paired_mirror_reg(g, r, false)];
+    const float2 other = z[paired_mirror_reg(g, r, false)], self = z[paired_mirror_reg(g, r, true)];
+    return make_float2(lane32 ? self.x : other.x, lane32 ? self.y : other.y);
+}
+
+// paired layout in, time layout out (unnormalised inverse DFT)
+__device__ __forceinline__ void wave_fft_inv_paired(float2 (&v)[16], float2 *lds, const float2 *tab, int lane,
+                                                    const PairedPlan &pl)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dft4<true>(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);      // r -> c
+    {
+        float2 tw[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g == 2) continue;       // the lane's own row again: slot 0's values
+#pragma unroll
+            for (int c = 1; c < 4; ++c) tw[4 * g + c] = OHS_TW_LD(&tab[pl.tw[g] + c]);
+        }
+        OHS_TW_PIN();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int c = 1; c < 4; ++c) v[4 * g + c] = cmulc(v[4 * g + c], tw[4 * (g == 2 ? 0 : g) + c]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lds_st(&lds[pl.t2[g] + 65 * c], v[4 * g + c]);                    // T2'
+    }
+    wave_lds_sync();
+    wave_fft_inv_tail(v, lds, tab, lane);
 }
 
 // Fetch, for every register of the bin layout, the value at bin (N - k).

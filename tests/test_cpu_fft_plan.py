@@ -1,6 +1,6 @@
 """CPU suite: the index plan of the wavefront FFT-1024 (tools/proto_wave_fft.py, a numpy model of csrc/wave_fft.hpp):
 forward / inverse against numpy, the mirror-bin map, the mirror spectrum read back from the T2 image (round 2),
-and the LDS bank census under the gfx950 grouping rules (two 32-lane groups per ds_read_b64, four 16-lane groups
+the paired bin layout of k_conv_p1 (round 3), and the LDS bank census under the gfx950 grouping rules (two 32-lane groups per ds_read_b64, four 16-lane groups
 per ds_write_b64) -- everything conflict-free except the documented 2-way conflict of the inverse T2 write."""
 import os
 import subprocess
@@ -19,3 +19,5 @@ def test_wave_fft_index_plan_and_bank_census():
     assert "T2 inv write 2 read 1" in out                      # the one documented 2-way conflict
     assert "T2 mirror reads 1 1" in out and "twiddle table rows / columns 1 1" in out
     assert "w64 table in the row padding, forward / inverse 1 1" in out and "slab 1084 entries: OK" in out
+    # round 3: the paired bin layout of k_conv_p1 (coverage, mirror map and numerics are asserted by the tool itself)
+    assert "paired layout: OK" in out and "T2 paired read 1 write 2" in out and "w64 rows, paired inverse 1" in out

@@ -369,6 +369,38 @@ def test_batch_p1_no_eq_inplace(ohs, synth, oracle):
         assert_parity(g[s], o, f"in-place stream {s}")
 
 
+def test_batch_p1_output_bits_are_those_of_the_natural_bin_layout(ohs, synth):
+    """k_conv_p1 computes in a paired bin layout (bins k and N - k in one lane: no mirror-spectrum reads).  Bin by bin
+    its arithmetic is that of the natural layout, operation for operation, so the output BITS must be the ones the
+    natural-layout build (-DOHS_P1_NATURAL) produced: tests/golden/p1_output_sha256.txt, written by tools/p1_hash.py
+    with that build.  A deliberate change of the kernel's arithmetic needs the file regenerated (and says so here)."""
+    import hashlib
+    import os
+    import torch
+    want = {}
+    with open(os.path.join(os.path.dirname(__file__), "golden", "p1_output_sha256.txt")) as f:
+        for line in f:
+            S, blocks, calls, digest = line.split()
+            want[(int(S), int(blocks), int(calls))] = digest
+    assert len(want) == 6
+    dev = torch.device("cuda:0")
+    for (S, blocks, calls), digest in want.items():
+        bp = ohs.BatchProcessor(S, num_bands=10)
+        irs = synth.hrir_set(512)
+        for p in range(4):
+            bp.set_ir(p, irs[p])
+        bp.set_eq_enabled(False)
+        bp.set_gain(0.7)
+        h = hashlib.sha256()
+        for c in range(calls):
+            x = synth.white_noise_torch(10 * S + c, S, blocks * 512, dev)
+            y = torch.empty_like(x)
+            bp.process(x, out=y)
+            torch.cuda.synchronize()
+            h.update(y.cpu().numpy().tobytes())
+        assert h.hexdigest() == digest, f"k_conv_p1 output bits changed: {S} streams x {blocks} blocks x {calls} calls"
+
+
 def test_batch_long_ir_p32(ohs, synth, oracle):
     w = _batch_vs_oracle(ohs, synth, oracle, S=3, taps=16384, n_blocks=20, eq_on=False, calls=2)
     print("batch P=32 worst rel RMS", w)

@@ -221,4 +221,51 @@ if __name__ == "__main__":
                 got = m[4 * (4 - j) + (3 - r)] if j else (m[(4 - r) & 3] if L == 0 else m[3 - r])
                 assert abs(got - ref[(N - bins_of(L, 4 * r + j)) % N]) < 1e-9, (L, r, j)
     print("mirror from the T2 image: OK")
+    # round 3: the paired bin layout of k_conv_p1 (wave_fft.hpp: paired_group) -- bins k and N - k in one lane
+    def paired_group(L, g):
+        if g == 0:
+            return L, 1
+        if g == 1:
+            return 63 - L, 3
+        if L < 32:
+            return (L if g == 2 else 63 - L), 2
+        return (L if g == 2 else (64 - L) & 31), 0
+    seen = set()
+    for L in range(64):
+        for g in range(4):
+            seen.add(paired_group(L, g))
+    assert len(seen) == 256 and seen == {(l, j) for l in range(64) for j in range(4)}      # every DFT4 group exactly once
+    def paired_bin(L, g, r):
+        lg, j = paired_group(L, g)
+        return 4 * lg + j + 256 * r
+    def paired_mirror(L, g, r):          # (slot, register) of the SAME lane holding bin N - k
+        if g == 0:
+            return 1, 3 - r
+        if g == 1:
+            return 0, 3 - r
+        if L == 32:
+            return (2, 3 - r) if g == 2 else (3, (4 - r) & 3)
+        return (3 if g == 2 else 2), 3 - r
+    for L in range(64):
+        for g in range(4):
+            for r in range(4):
+                mg, mr = paired_mirror(L, g, r)
+                assert paired_bin(L, mg, mr) == (N - paired_bin(L, g, r)) % N, (L, g, r)
+    # numerics: DFT4 of the T2-image group gives the paired bins
+    for L in range(64):
+        for g in range(4):
+            lg, j = paired_group(L, g)
+            u = dft_small(np.array([img[addr2(j, c, lg >> 2, lg & 3)] for c in range(4)]), 4, +1)
+            for r in range(4):
+                assert abs(u[r] - ref[paired_bin(L, g, r)]) < 1e-9
+    # bank census: register 4 g + c of lane L is element c of its slot-g group
+    def paired_addr(L, reg):
+        lg, j = paired_group(L, reg >> 2)
+        return addr2(j, reg & 3, lg >> 2, lg & 3)
+    print("T2 paired read", worst(halves, paired_addr, 32), "write", worst(g16, paired_addr, 16))
+    # w64 rows of the inverse transform: slots 0 and 2 are groups of the lane itself (the same row)
+    for L in range(64):
+        assert paired_group(L, 0)[0] >> 2 == paired_group(L, 2)[0] >> 2 == L >> 2
+    print("w64 rows, paired inverse", worst_distinct(halves, lambda L, reg: tab_b(paired_group(L, reg >> 2)[0] >> 2, reg & 3), 32))
+    print("paired layout: OK")
     print("OK")
