@@ -42,7 +42,7 @@ def _units():
         # FFT kernels: no SLP vectoriser (see conv_mac_kernels.hip); no implicit FMA contraction -- the fused
         # operations are written out (wave_fft.hpp), so that every kernel inlining them rounds alike
         ("conv_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
-        ("conv_mac_kernels.hip", [f"-DOHS_MAC_TB={os.environ.get('OHS_MAC_TB', '16')}",
+        ("conv_mac_kernels.hip", [f"-DOHS_MAC_TB={os.environ.get('OHS_MAC_TB', '0')}",
                                   f"-DOHS_MAC_PI={os.environ.get('OHS_MAC_PI', '16')}"]),
         ("eq_kernels.hip", ["-ffp-contract=off"]),
         ("ohs_api.hip", []),

@@ -42,19 +42,20 @@ __device__ __forceinline__ int mirror_position(int b)
 // registers run out -- config 4, whole convolution step:
 //   compiler-scheduled MAC, (TB,PI) = (8,8): 0.372 ms | explicit v_pk_fma_f32 (8,8): 0.334 | (8,16): 0.313
 //   (16,8): 0.286 | (16,16): 0.277 (137 VGPRs) | (32,8): 0.265 | (32,16): 0.256 (254 VGPRs)
-// (16,16) is the default: short segments (many streams) waste less of a tile than with TB = 32.
+// Both (16,16) and (32,16) are built; the launcher takes TB = 32 where the segment's block count fills its tiles well
+// enough (launch_conv_tp_mac): short segments (many streams) waste less of a tile with TB = 16.
 // (A variant with one thread per position PAIR {b, mirror(b)} halves the history reads; with the
 // compiler-scheduled MAC it needed 256 VGPRs and ran at 0.69 ms.)
 #ifndef OHS_MAC_TB
-#define OHS_MAC_TB 16
+#define OHS_MAC_TB 0                // 0: chosen per launch between 16 and 32; 16 / 32: that tile only (experiments)
 #endif
-constexpr int kTB = OHS_MAC_TB;     // output blocks per register tile
 #ifndef OHS_MAC_PI
 #define OHS_MAC_PI 16
 #endif
 constexpr int kPI = OHS_MAC_PI;     // partitions per register window (Ppad is a multiple of 16, so 8 or 16)
 __device__ __forceinline__ void conv_tp_w1_job(const ConvTpArgs &A, int wg);
 
+template <int kTB>                  // output blocks per register tile
 __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
 {
     ohs_set_fp_mode(A.fp_mode);
@@ -157,10 +158,20 @@ __device__ __forceinline__ void conv_tp_w1_job(const ConvTpArgs &A, int wg)
     if (b != mb) A.W1[s * (size_t)kFft + mb] = acc1m;
 }
 
+// time tile of a segment of n blocks: 32 x 16 runs a block 11 % faster than 16 x 16 (config 4: 0.269 -> 0.250 ms per step
+// in all) but rounds the segment up to a multiple of 32
+static int mac_time_tile(int n)
+{
+    if (OHS_MAC_TB != 0) return OHS_MAC_TB;
+    const long long c32 = (long long)((n + 31) / 32) * 32 * 89, c16 = (long long)((n + 15) / 16) * 16 * 100;
+    return c32 < c16 ? 32 : 16;
+}
+
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
 {
     if (a.n_mac <= 0) return hipSuccess;
     ConvTpArgs m = a;
+    const int kTB = mac_time_tile(a.n_mac);
     m.mac_tiles = (a.n_mac + kTB - 1) / kTB;
     const unsigned wps = (unsigned)(kFft / 256) * (unsigned)m.mac_tiles;
     const unsigned groups = ((unsigned)a.n_streams + 7u) / 8u;
@@ -168,7 +179,12 @@ hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
     if (!xcd_map) m.mac_tiles = -m.mac_tiles;
     m.main_wgs = (int)(groups * 8u * wps);
     const unsigned w1_wgs = (unsigned)((a.n_pairs + 255) / 256) * (unsigned)a.n_streams;
-    hipLaunchKernelGGL(k_conv_tp_mac, dim3((unsigned)m.main_wgs + w1_wgs), dim3(256), 0, st, m);
+    const dim3 grid((unsigned)m.main_wgs + w1_wgs);
+    switch (kTB) {
+    case 16: hipLaunchKernelGGL(k_conv_tp_mac<16>, grid, dim3(256), 0, st, m); break;
+    case 32: hipLaunchKernelGGL(k_conv_tp_mac<32>, grid, dim3(256), 0, st, m); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -475,10 +475,12 @@ def test_synth_torch_generator_matches_numpy(synth):
 
 # ------------------------------------------------------------------ edge cases of the fast paths
 @pytest.mark.parametrize("taps,n_blocks", [(512, 1), (512, 2), (512, 3), (512, 5), (512, 67),
-                                           (2000, 1), (2000, 3), (2000, 4), (2000, 9), (2000, 17)])
+                                           (2000, 1), (2000, 3), (2000, 4), (2000, 9), (2000, 17), (2000, 32),
+                                           (2000, 33), (2000, 50)])
 def test_batch_small_block_counts_every_kernel_path(ohs, synth, oracle, taps, n_blocks):
-    """P=1: chunks <= n_blocks, fix-up kernel; P>1: general kernel below 4 blocks, time-parallel
-    kernels from 4 (tile of 8 partially filled), three consecutive calls chaining the state."""
+    """P=1: chunks <= n_blocks; P>1: general kernel below 4 blocks, time-parallel kernels from 4 (time tiles of 16 or
+    32 blocks, partially filled: 9 -> 16, 17 and 32 -> 32, 33 -> 3 x 16, 50 -> 2 x 32), three consecutive calls chaining
+    the state."""
     _batch_vs_oracle(ohs, synth, oracle, S=3, taps=taps, n_blocks=n_blocks, eq_on=False, calls=3)
 
 
