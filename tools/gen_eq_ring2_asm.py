@@ -49,6 +49,8 @@ FULL = "row_mask:0xf bank_mask:0xf"
 KNOCK = os.environ.get("EQ_RING_KNOCKOUT", "").split()      # timing experiments only: store / load / port / wait
 WAITS = int(os.environ.get("EQ_RING2_WAITS", "2"))          # waits per group: 2 (default) or 4
 WAITCNT = 8 if WAITS == 2 else 12                           # each wait retires the loads of the next 4 (2) chunks
+VMEM_DELAY = int(os.environ.get("EQ_RING2_VMEM_DELAY", "0"))  # experiment: the port's store / load issued this many VALU
+                                                            # instructions behind the DPP move that wrote the store register
 VOFF, B2, X, ST = "v0", "v1", "v2", "v3"
 XIN = [f"v{16 + q}" for q in range(8)]
 XNEXT = "v24"
@@ -69,7 +71,27 @@ def size_of(line):
 
 def gen(first_step=0, loads=True, loop=False):
     out = []
-    e = out.append
+    pending = []                # [countdown, instruction]: the port's VMEM instructions when VMEM_DELAY > 0
+
+    def flush(force=False):
+        while pending and (force or pending[0][0] <= 0):
+            out.append(pending.pop(0)[1])
+
+    def e(line):
+        is_valu = line.startswith("v_") and not line.startswith("v_add_u32")
+        if not is_valu:
+            flush(force=True)   # waits, branches, the offset advance: nothing may be pending across them
+        out.append(line)
+        if is_valu:
+            for it in pending:
+                it[0] -= 1
+            flush()
+
+    def vmem(line):
+        if VMEM_DELAY > 0:
+            pending.append([VMEM_DELAY, line])
+        else:
+            out.append(line)
 
     P = f"v_pk_mul_f32 v[4:5], v[12:13], v[2:3] op_sel_hi:[1,0]"
     M = f"v_mul_f32_dpp v7, {X}, {B2} row_ror:1 {FULL}"
@@ -106,14 +128,14 @@ def gen(first_step=0, loads=True, loop=False):
             e("s_nop 0")
         e(f"v_mov_b32_dpp {ST}, {X} {ror(4 * b + 4)} row_mask:0xf bank_mask:0x{1 << b:x}")
         if b == 3 and "store" not in KNOCK:
-            e(f"global_store_dword {VOFF}, {ST}, %[dst] offset:{store_imm(q)}")
+            vmem(f"global_store_dword {VOFF}, {ST}, %[dst] offset:{store_imm(q)}")
         if nxt == 128:
             src = XIN[0] if loads else XNEXT
         else:
             src = XIN[q]
         e(f"v_mov_b32_dpp {X}, {src} {ror(12 - 4 * b)} row_mask:0xf bank_mask:0x8")
         if b == 3 and loads and "load" not in KNOCK:
-            e(f"global_load_dword {XIN[q]}, {VOFF}, %[src] offset:{load_imm(q)}")
+            vmem(f"global_load_dword {XIN[q]}, {VOFF}, %[src] offset:{load_imm(q)}")
 
     e(".p2align 5")
     head = first_step == 16
@@ -146,6 +168,7 @@ def gen(first_step=0, loads=True, loop=False):
                 e("v_nop_e64")      # 8 bytes: keeps the stream aligned (order experiments only)
             else:
                 e({"O": O, "T": T, "A": A, "N": N, "P": P, "M": M}[tok])
+    flush(force=True)
     if loop:
         e("s_cmp_lg_u32 %[cnt], 0")
         e("s_cbranch_scc1 1b")
