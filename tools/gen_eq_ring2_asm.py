@@ -10,7 +10,8 @@ the 16 lanes of a DPP row form a RING; band L's work is split over two lanes,
                       T  t2 = b1x(row_ror:1) + s2              = band L+1's next input, already in place)
                       A  (a1,a2) * X'                      N  (s1,s2) = (t2, b2x) - ao
 6 VALU per step + the I/O port every 4th step (CAP: bank 3 of X -> one bank of the store register, INJ: the next
-4 inputs -> bank 3 of X) = 6.5 VALU per sample.
+4 inputs -> bank 3 of X) = 6.5 VALU per sample; every 16th step the port also stores a finished output register and
+refills the input register it has just emptied, the two memory instructions back to back.
 
 What changed against round 2:
   * every register is pinned ("{vN}" constraints in eq_ring2_body.hpp); nothing is copied in or out of a block:
@@ -49,6 +50,11 @@ FULL = "row_mask:0xf bank_mask:0xf"
 KNOCK = os.environ.get("EQ_RING_KNOCKOUT", "").split()      # timing experiments only: store / load / port / wait
 WAITS = int(os.environ.get("EQ_RING2_WAITS", "2"))          # waits per group: 2 (default) or 4
 WAITCNT = 8 if WAITS == 2 else 12                           # each wait retires the loads of the next 4 (2) chunks
+# The port's store and load are issued BACK TO BACK, behind the port's second move (which reads the register the load
+# refills): a lone wave pays ~12 cycles for a vector-memory instruction between VALU instructions but only ~4 more for a
+# second one right behind it (tools/ubench_vmem_issue.hip) -- 11.82 -> 11.61 ns per sample.  EQ_RING2_VMEM_ADJ=0: round
+# 3's first order (move, store, move, load).
+VMEM_ADJ = os.environ.get("EQ_RING2_VMEM_ADJ", "1") == "1"
 VMEM_DELAY = int(os.environ.get("EQ_RING2_VMEM_DELAY", "0"))  # experiment: the port's store / load issued this many VALU
                                                             # instructions behind the DPP move that wrote the store register
 VOFF, B2, X, ST = "v0", "v1", "v2", "v3"
@@ -127,13 +133,15 @@ def gen(first_step=0, loads=True, loop=False):
             e(f"s_waitcnt vmcnt({WAITCNT})")
             e("s_nop 0")
         e(f"v_mov_b32_dpp {ST}, {X} {ror(4 * b + 4)} row_mask:0xf bank_mask:0x{1 << b:x}")
-        if b == 3 and "store" not in KNOCK:
+        if b == 3 and "store" not in KNOCK and not VMEM_ADJ:
             vmem(f"global_store_dword {VOFF}, {ST}, %[dst] offset:{store_imm(q)}")
         if nxt == 128:
             src = XIN[0] if loads else XNEXT
         else:
             src = XIN[q]
         e(f"v_mov_b32_dpp {X}, {src} {ror(12 - 4 * b)} row_mask:0xf bank_mask:0x8")
+        if b == 3 and "store" not in KNOCK and VMEM_ADJ:
+            vmem(f"global_store_dword {VOFF}, {ST}, %[dst] offset:{store_imm(q)}")
         if b == 3 and loads and "load" not in KNOCK:
             vmem(f"global_load_dword {XIN[q]}, {VOFF}, %[src] offset:{load_imm(q)}")
 
