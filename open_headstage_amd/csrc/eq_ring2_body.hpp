@@ -1,4 +1,4 @@
-// eq_ring2_body.hpp -- the ring-form DF2T cascade (<= 12 bands) on 24 pinned VGPRs: device code shared by
+// eq_ring2_body.hpp -- the ring-form DF2T cascade (<= 12 bands) on 25 pinned VGPRs: device code shared by
 // eq_kernels.hip (k_eq_ring) and conv_kernels.hip (the resident real-time kernel runs the plugin's whole chain).
 // Every file that includes this header MUST be built with -ffp-contract=off: the recurrence rounds each product
 // and sum separately, as the reference does (src/dsp/parametric_eq.rs:116-122).
@@ -8,7 +8,8 @@
 // is new here is the register plan: round 2's asm bodies named v100..v113 as temporaries, which made k_eq_ring a
 // 114-VGPR kernel -- and k_conv_p1 takes 4 x 120 of a SIMD's 512 registers, so an EQ wave and a convolution
 // workgroup could never share a CU: the two kernels partitioned the chip (<= 1024 streams) or serialised (2048).
-// Now every value of the steady state lives in a pinned register v0..v23 (v24 in the two NOLOAD forms), the eight
+// Now every value of the steady state lives in a pinned register v0..v23 (v24 in the two NOLOAD forms; v25 the second
+// store register of the interior groups, whose memory instructions go out two chunks at a time), the eight
 // input registers are reloaded in place, addresses are SGPR base + one 32-bit VGPR offset, and the interior groups
 // loop inside ONE asm statement.  The kernel as a whole stays within 32 VGPRs.
 //
@@ -104,7 +105,7 @@ __device__ __forceinline__ void eq_ring2_full_groups(const RingLane &c, RingRegs
     asm volatile(EQ_RING2_MAIN
                  : EQ_RING2_STATE, [x1] "+{v17}"(x1), [voff] "+{v0}"(lane_off), [cnt] "+s"(interior_groups)
                  : EQ_RING2_CONSTS, [xn] "{v24}"(xnext), [src] "s"(src), [dst] "s"(dst), [k512] "s"(k512), [only] "s"(only)
-                 : EQ_RING2_CLOBBERS, "v16", "v18", "v19", "v20", "v21", "v22", "v23", "scc");
+                 : EQ_RING2_CLOBBERS, "v16", "v18", "v19", "v20", "v21", "v22", "v23", "v25", "v26", "v27", "scc");
 }
 
 // the strides the ring form's 32-bit lane offsets can address (host side, launch_eq_pass)
@@ -122,7 +123,7 @@ __device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long 
 {
     constexpr int G = 8;            // chunks per group (128 samples per chain)
     if (wave_id * 4 >= n_chains) return;
-    // The kernel has 32 VGPRs and the asm blocks pin 25 of them, so only ONE per-lane value of the compiler's
+    // The kernel has 32 VGPRs and the asm blocks pin 26 of them, so only ONE per-lane value of the compiler's
     // crosses the blocks: the lane id.  Each phase (head, ragged end, state write-back) derives its own copies of
     // the band index, the sample offset ... from a laundered lane id, which keeps hipcc from hoisting the common
     // subexpressions of the phases above the blocks and holding them in registers it does not have.

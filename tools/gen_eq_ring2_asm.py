@@ -20,6 +20,9 @@ What changed against round 2:
         v[4:5] (b0x, b1x)   v[6:7] (t2, b2x)   v[8:9] (a1 out, a2 out)   v[10:11] (s1, s2)
         v[12:13] (b0, b1) of the pre lane   v[14:15] (a1, a2)   v16..v23 the group's 8 input registers
         v24 (NOLOAD forms only) chunk 0 of the NEXT group
+        v25 second store register (interior and closing groups: the memory instructions of two chunks go out together,
+            store, store, load, load -- a lone wave pays ~12 cycles for a vector-memory instruction between VALU
+            instructions, ~17 for two back to back, ~20 for four: 11.82 -> 11.61 -> 11.43 ns per sample)
   * the input registers are reloaded IN PLACE: chunk q's register is dead after its last INJ (step 16q + 12) and
     the load of the next group's chunk q is issued right there -- 8 I/O registers instead of 16.  vmcnt is counted
     by hand (vector-memory operations retire in issue order): per group the queue sees S0 L0 S1 L1 ... S7 L7, and
@@ -55,11 +58,18 @@ WAITCNT = 8 if WAITS == 2 else 12                           # each wait retires 
 # second one right behind it (tools/ubench_vmem_issue.hip) -- 11.82 -> 11.61 ns per sample.  EQ_RING2_VMEM_ADJ=0: round
 # 3's first order (move, store, move, load).
 VMEM_ADJ = os.environ.get("EQ_RING2_VMEM_ADJ", "1") == "1"
+# Memory instructions of CLUSTER consecutive chunks issued together (1, 2 or 4): the outputs wait in CLUSTER store
+# registers (v3, v25, v26, v27), the input registers of the cluster's chunks are refilled together.  Interior and closing
+# groups only; the launch's first group keeps one store + one load per chunk.  The two waits per group stay where they
+# are and keep their count (a group issues 16 memory instructions whatever their grouping).
+CLUSTER = int(os.environ.get("EQ_RING2_CLUSTER", "2"))       # 1: 11.61, 2: 11.43, 4: 11.42-11.52 ns per sample
+assert CLUSTER in (1, 2, 4)
 VMEM_DELAY = int(os.environ.get("EQ_RING2_VMEM_DELAY", "0"))  # experiment: the port's store / load issued this many VALU
                                                             # instructions behind the DPP move that wrote the store register
 VOFF, B2, X, ST = "v0", "v1", "v2", "v3"
 XIN = [f"v{16 + q}" for q in range(8)]
 XNEXT = "v24"
+ST_REGS = [ST, "v25", "v26", "v27"]
 
 
 def ror(n):
@@ -108,12 +118,14 @@ def gen(first_step=0, loads=True, loop=False):
 
     # Offsets: V = row offset + 4 (j ^ 3) + 512 g on entry of group g.  The LOOP form advances V by 512 in front of
     # chunk 4 (the instruction pairs with that wait); every other form leaves it alone.
-    def store_imm(q):
-        adv = loop and q >= 4
+    cl = CLUSTER if first_step == 0 else 1
+
+    def store_imm(q, at=None):      # output chunk q - 1, issued at the port of chunk `at`
+        adv = loop and (q if at is None else at) >= 4
         return 64 * q - 64 - (512 if adv else 0)
 
-    def load_imm(q):
-        adv = loop and q >= 4
+    def load_imm(q, at=None):
+        adv = loop and (q if at is None else at) >= 4
         return 512 + 64 * q - (512 if adv else 0)
 
     def port(nxt):              # in front of step nxt (nxt % 4 == 0); nxt == 128: the next group's step 0
@@ -132,18 +144,22 @@ def gen(first_step=0, loads=True, loop=False):
         if loop and WAITS == 4 and nxt in (32, 96) and "wait" not in KNOCK:
             e(f"s_waitcnt vmcnt({WAITCNT})")
             e("s_nop 0")
-        e(f"v_mov_b32_dpp {ST}, {X} {ror(4 * b + 4)} row_mask:0xf bank_mask:0x{1 << b:x}")
+        e(f"v_mov_b32_dpp {ST_REGS[q % cl]}, {X} {ror(4 * b + 4)} row_mask:0xf bank_mask:0x{1 << b:x}")
+        cluster = b == 3 and (q + 1) % cl == 0
         if b == 3 and "store" not in KNOCK and not VMEM_ADJ:
+            assert cl == 1
             vmem(f"global_store_dword {VOFF}, {ST}, %[dst] offset:{store_imm(q)}")
         if nxt == 128:
             src = XIN[0] if loads else XNEXT
         else:
             src = XIN[q]
         e(f"v_mov_b32_dpp {X}, {src} {ror(12 - 4 * b)} row_mask:0xf bank_mask:0x8")
-        if b == 3 and "store" not in KNOCK and VMEM_ADJ:
-            vmem(f"global_store_dword {VOFF}, {ST}, %[dst] offset:{store_imm(q)}")
-        if b == 3 and loads and "load" not in KNOCK:
-            vmem(f"global_load_dword {XIN[q]}, {VOFF}, %[src] offset:{load_imm(q)}")
+        if cluster and "store" not in KNOCK and VMEM_ADJ:
+            for qq in range(q - cl + 1, q + 1):
+                vmem(f"global_store_dword {VOFF}, {ST_REGS[qq % cl]}, %[dst] offset:{store_imm(qq, q)}")
+        if cluster and loads and "load" not in KNOCK:
+            for qq in range(q - cl + 1, q + 1):
+                vmem(f"global_load_dword {XIN[qq]}, {VOFF}, %[src] offset:{load_imm(qq, q)}")
 
     e(".p2align 5")
     head = first_step == 16
