@@ -10,7 +10,7 @@ for f in rt_latency rt_soak ubench_lds ubench_pcie; do [ -s $o/$f.txt ] && cp $o
 for wl in headline c3noeq c4; do
     # kernel statistics of our own kernels only (the torch elementwise kernels of the synthetic-data generator are not ours)
     head -1 $o/kt_$wl/run_kernel_stats.csv > profiles/${tag}_kernel_stats_$wl.csv
-    grep '"ohs::' $o/kt_$wl/run_kernel_stats.csv >> profiles/${tag}_kernel_stats_$wl.csv
+    grep 'ohs::' $o/kt_$wl/run_kernel_stats.csv >> profiles/${tag}_kernel_stats_$wl.csv
     python3 tools/pmc_table.py ${tag}_hbm_$wl $o/pmc_fetch_$wl/run_counter_collection.csv $o/pmc_write_$wl/run_counter_collection.csv > /dev/null
 done
 cp profiles/${tag}_kernel_stats_headline.csv profiles/${tag}_kernel_stats.csv
