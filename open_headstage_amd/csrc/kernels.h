@@ -1,6 +1,7 @@
 // kernels.h -- host-callable launchers of the gfx950 kernels (internal to the library).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace ohs {
@@ -39,7 +40,11 @@ constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
 // pass-on lanes run 1*x + 0).
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
                           long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
-                          hipStream_t st, bool exact_specials = false, int fp_mode = 0, int xcd_lo = 0, int xcd_n = 8);
+                          hipStream_t st, bool exact_specials = false, int fp_mode = 0, int xcd_lo = 0, int xcd_n = 8,
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// (ev_start / ev_stop: recorded at the start / completion of THIS launch.  The ring kernel's dispatch carries them
+// itself -- hipExtLaunchKernelGGL -- which spares the queue the marker packets of hipEventRecord and the gap they open
+// between back-to-back launches: 12-13 -> 7 us per chunk boundary of the overlapped batch step with profiling on.)
 
 // |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
 hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,

@@ -325,6 +325,20 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
             if (eff >= 0.97) break;
         }
     }
+    if (K > n_blocks && target_override <= 0) {
+        // A launch too short for two rounds of waves (the last, 2 % time chunk of an overlapped batch step: 19 blocks).
+        // One block per wave would start a second, almost empty round (256 streams x 19 = 1.19 R) and make the pre-pass
+        // compute a boundary tail per block.  Cost in block times: rounds x blocks per wave for the main kernel + rounds
+        // for the boundary tails; the smallest K of minimal cost (19 blocks: K = 10, one round of two blocks).
+        long long best_k = n_blocks, best_cost = -1;
+        for (long long k = 1; k <= n_blocks; ++k) {
+            const long long rounds_main = ((long long)S * k + R - 1) / R, per_wave = (n_blocks + k - 1) / k;
+            const long long rounds_edge = k > 1 ? ((long long)S * (k - 1) + R - 1) / R : 0;
+            const long long cost = rounds_main * per_wave + rounds_edge;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_k = k; }
+        }
+        K = best_k;
+    }
     if (K > n_blocks) K = n_blocks;
     if (K < 1) K = 1;
     return K;
@@ -536,8 +550,9 @@ int eq_single_pass_table(const EqState &e, EqPassTable &t)
 }
 
 // run the cascade over n frames of `chains` chains, in place allowed
+// ev_start / ev_stop (optional): recorded at the start of the first and the completion of the last pass
 int eq_launch(EqState &e, const float *in, float *out, long long ss, long long cs, long long n,
-              hipStream_t st, bool *did_anything = nullptr)
+              hipStream_t st, bool *did_anything = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
     bool did = false;
     const float *src = in;
@@ -563,11 +578,16 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
             int lo = 0, n = 8;
             if (sscanf(env_x, "%d,%d", &lo, &n) == 2 && n >= 1 && lo >= 0 && lo + n <= 8) { xcd_lo = lo; xcd_n = n; }
         }
+        const bool first = p0 == 0, last = p0 + 16 >= on.size();
         hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials, e.fp_mode,
-                                        xcd_lo, xcd_n);
+                                        xcd_lo, xcd_n, first ? ev_start : nullptr, last ? ev_stop : nullptr);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
         did = true;
+    }
+    if (!did) {     // no enabled band: the events mark this point of the stream
+        if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
+        if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, st));
     }
     if (did_anything) *did_anything = did;
     return OHS_OK;
@@ -1872,21 +1892,24 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
             continue;
         }
         if (chunk_waits) HIP_TRY(hipStreamWaitEvent(st, b->chunk_done[(size_t)i], 0));
-        rc = span_begin(st, 0); if (rc) return rc;
-        rc = eq_launch(b->eq, d_in + off, d_out + off, ss, cs, (long long)nb_i * BS, st);
+        // The EQ launch carries its own events (start / completion of the dispatch: no marker packets between the
+        // back-to-back EQ launches of a step); the completion event is what the convolution's stream waits for.
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (b->profiling) {
+            ohs_batch::Span sp; sp.kind = 0; sp.a = nullptr; sp.b = nullptr;
+            rc = get_event(&sp.a); if (rc) return rc;
+            rc = get_event(&sp.b); if (rc) return rc;
+            b->spans.push_back(sp);
+            ev_a = sp.a; ev_b = sp.b;
+        } else if (nch > 1) {
+            rc = get_event(&ev_b); if (rc) return rc;
+            b->ev_inflight.push_back(ev_b);
+        }
+        rc = eq_launch(b->eq, d_in + off, d_out + off, ss, cs, (long long)nb_i * BS, st, nullptr, ev_a, ev_b);
         if (rc) return rc;
-        rc = span_end(st); if (rc) return rc;
         hipStream_t cst = st;
         if (nch > 1) {
-            if (b->profiling) {     // the span's end event marks the same point: one record less on the EQ stream
-                HIP_TRY(hipStreamWaitEvent(b->st2, b->spans.back().b, 0));
-            } else {
-                hipEvent_t ev;
-                rc = get_event(&ev); if (rc) return rc;
-                HIP_TRY(hipEventRecord(ev, st));
-                HIP_TRY(hipStreamWaitEvent(b->st2, ev, 0));
-                b->ev_inflight.push_back(ev);
-            }
+            HIP_TRY(hipStreamWaitEvent(b->st2, ev_b, 0));
             cst = b->st2;
         }
         rc = span_begin(cst, 1); if (rc) return rc;
