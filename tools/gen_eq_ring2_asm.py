@@ -64,6 +64,7 @@ VMEM_ADJ = os.environ.get("EQ_RING2_VMEM_ADJ", "1") == "1"
 # are and keep their count (a group issues 16 memory instructions whatever their grouping).
 CLUSTER = int(os.environ.get("EQ_RING2_CLUSTER", "2"))       # 1: 11.61, 2: 11.43, 4: 11.42-11.52 ns per sample
 assert CLUSTER in (1, 2, 4)
+assert not (CLUSTER == 4 and int(os.environ.get("EQ_RING2_WAITS", "2")) == 4), "four waits per group retire two chunks each: clusters of 1 or 2 chunks only"
 VMEM_DELAY = int(os.environ.get("EQ_RING2_VMEM_DELAY", "0"))  # experiment: the port's store / load issued this many VALU
                                                             # instructions behind the DPP move that wrote the store register
 VOFF, B2, X, ST = "v0", "v1", "v2", "v3"
