@@ -914,16 +914,60 @@ __device__ __forceinline__ void p1_spectral_product_paired(const float2 (&z)[16]
 // therefore cut in proportion to the age rank's weight w[(wave index) >> 2]; w = {1, 1, 1, 1} is the plain
 // equal-length partition.  (Rotating the issue priority per block instead evens the speeds out but lowers the
 // SIMD's total rate by a fifth: OHS_P1_PRIO=1.)
+// With 2, 4 or 8 chunks per stream (1024 streams and more) consecutive waves would put all chunks of a stream on ONE age
+// rank (4 consecutive waves = the four SIMDs' waves of equal age) and the weights could balance nothing: the oldest
+// waves' streams would finish 2.3x earlier than the youngest's.  Those launches deal a workgroup's waves out across its
+// 16 / K streams instead, so that every stream owns waves of all ranks (K = 2: ranks {0, 3} or {1, 2}, whose weights
+// add up alike).
+__device__ __forceinline__ bool p1_spread(int chunks)
+{
+    return kP1Waves == 16 && (chunks == 2 || chunks == 4 || chunks == 8);
+}
+// wave gw of the main kernel's grid -> (stream, chunk)
+__device__ __forceinline__ void p1_wave_job(long long gw, int chunks, long long &s, int &ck)
+{
+    if (p1_spread(chunks)) {
+        const int w = (int)(gw & 15), rank = w >> 2, p = w & 3;
+        int sl;
+        if (chunks == 4) { sl = p; ck = rank; }
+        else if (chunks == 8) { sl = p & 1; ck = 2 * rank + (p >> 1); }
+        else { sl = p + ((rank == 1 || rank == 2) ? 4 : 0); ck = rank >> 1; }
+        s = (gw >> 4) * (16 / chunks) + sl;
+    } else {
+        s = gw / chunks;
+        ck = (int)(gw % chunks);
+    }
+}
+// age rank of the wave that p1_wave_job gives chunk i of stream s
+__device__ __forceinline__ int p1_chunk_rank(int s, int i, int chunks)
+{
+    if (p1_spread(chunks)) {
+        if (chunks == 4) return i;
+        if (chunks == 8) return i >> 1;
+        return (s & 7) < 4 ? (i ? 3 : 0) : (i ? 2 : 1);
+    }
+    return (int)(((((unsigned)s * (unsigned)chunks) % (unsigned)kP1Waves + (unsigned)i) % (unsigned)kP1Waves) >> 2) & 3;
+}
 __device__ __forceinline__ int p1_chunk_begin(int s, int ck, int n_main, int chunks, const int (&w)[4])
 {
-    const int per16 = 4 * (w[0] + w[1] + w[2] + w[3]);
+    static_assert(kP1Waves % 4 == 0 && kP1Waves <= 16, "age ranks: four waves per SIMD");
+    if (p1_spread(chunks)) {
+        long long c = 0, total = 0;
+        for (int i = 0; i < chunks; ++i) {
+            const int wi = w[p1_chunk_rank(s, i, chunks)];
+            if (i < ck) c += wi;
+            total += wi;
+        }
+        return (int)(c * n_main / total);
+    }
+    int per_wg = 0;                 // one workgroup's waves: four per age rank (fewer ranks in the OHS_P1_WAVES < 16 experiments)
+    for (int i = 0; i < kP1Waves; ++i) per_wg += w[(i >> 2) & 3];
     const unsigned base = ((unsigned)s * (unsigned)chunks) % (unsigned)kP1Waves;
     auto cum = [&](int k) -> long long {
-        long long c = (long long)(k / kP1Waves) * per16;
+        long long c = (long long)(k / kP1Waves) * per_wg;
         for (int i = 0; i < k % kP1Waves; ++i) c += w[(((base + i) % kP1Waves) >> 2) & 3];
         return c;
     };
-    static_assert(kP1Waves % 4 == 0 && kP1Waves <= 16, "age ranks: four waves per SIMD");
     return (int)(cum(ck) * n_main / cum(chunks));
 }
 
@@ -986,9 +1030,11 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *lds = smem + kTabComplex + 2 * kFft + wave * kWaveLdsComplex;
     const long long gw = wg * kP1Waves + wave;
-    if (gw >= (long long)A.n_streams * A.chunks) return;
-    const int s = (int)(gw / A.chunks);
-    const int ck = (int)(gw % A.chunks);
+    long long s64;
+    int ck;
+    p1_wave_job(gw, A.chunks, s64, ck);
+    if (s64 >= (long long)A.n_streams) return;
+    const int s = (int)s64;
     const int n_main = A.n_blocks;        // every block's output is this kernel's
     const int b0 = __builtin_amdgcn_readfirstlane(p1_chunk_begin(s, ck, n_main, A.chunks, A.weights));
     const int b1 = __builtin_amdgcn_readfirstlane(p1_chunk_begin(s, ck + 1, n_main, A.chunks, A.weights));

@@ -304,10 +304,12 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     return OHS_OK;
 }
 
-// Chunks per stream of the P = 1 kernel: at least two rounds of resident waves (CUs x 15), and a wave count
-// S * K that FILLS its last round -- all waves of a launch take the same time, so 2.13 rounds cost 3 (1024 and
-// 2048 streams with K = ceil(2 R / S) ran at 71 % for that reason).  K is the smallest value from ceil(2 R / S)
-// upwards whose last round is >= 97 % full (S * K = 8 R at 2048 streams).
+// Chunks per stream of the P = 1 kernel: at least ONE round of resident waves (CUs x 16), and a wave count S * K that
+// FILLS its last round -- all waves of a launch take the same time, so 2.13 rounds cost 3 (1024 and 2048 streams with
+// K = ceil(2 R / S) ran at 71 % for that reason).  K is the smallest value from ceil(R / S) upwards whose last round is
+// >= 97 % full.  (Rounds 1 and 2 asked for two rounds; since the chunk lengths follow the waves' age ranks one exact
+// round is the faster plan -- config 3 without EQ: 4096 waves 0.537-0.541 ms, 8192 waves 0.549-0.555, 3840 0.563,
+// 4352 0.81 -- and the pre-pass has half the boundary tails to compute.  OHS_P1_ROUNDS=2 restores the old rule.)
 long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override, int xcd_n = 8)
 {
     const long long R = (long long)ctx->num_cus * xcd_n / 8 * conv_p1_waves_per_cu();
@@ -315,23 +317,28 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
     if (target_override > 0) {
         K = (target_override + (long long)S - 1) / (long long)S;
     } else {
-        const long long k0 = std::max<long long>(1, (2 * R + (long long)S - 1) / (long long)S);
+        static const long long rounds = [] {
+            const char *e = getenv("OHS_P1_ROUNDS");        // tuning experiments
+            const long long v = e ? atoll(e) : 1;
+            return v >= 1 && v <= 4 ? v : 1;
+        }();
+        const long long k0 = std::max<long long>(1, (rounds * R + (long long)S - 1) / (long long)S);
         K = k0;
         double best = 0.0;
         for (long long k = k0; k < k0 + 32; ++k) {
-            const double rounds = (double)((long long)S * k) / (double)R;
-            const double eff = rounds / std::ceil(rounds - 1e-9);
+            const double rd = (double)((long long)S * k) / (double)R;
+            const double eff = rd / std::ceil(rd - 1e-9);
             if (eff > best + 1e-9) { best = eff; K = k; }
             if (eff >= 0.97) break;
         }
     }
-    if (K > n_blocks && target_override <= 0) {
-        // A launch too short for two rounds of waves (the last, 2 % time chunk of an overlapped batch step: 19 blocks).
-        // One block per wave would start a second, almost empty round (256 streams x 19 = 1.19 R) and make the pre-pass
-        // compute a boundary tail per block.  Cost in block times: rounds x blocks per wave for the main kernel + rounds
-        // for the boundary tails; the smallest K of minimal cost (19 blocks: K = 10, one round of two blocks).
-        long long best_k = n_blocks, best_cost = -1;
-        for (long long k = 1; k <= n_blocks; ++k) {
+    if (n_blocks < 4 * K && target_override <= 0) {
+        // A short launch (the last, 2 % time chunk of an overlapped batch step: 19 blocks), a few blocks per wave at
+        // best: every chunk boundary costs the pre-pass a block's work, and a wave count just above a round starts a second,
+        // almost empty one.  Cost in block times: rounds x blocks per wave for the main kernel + rounds for the boundary
+        // tails; the smallest K of minimal cost (19 blocks x 256 streams: K = 10, one round of two blocks).
+        long long best_k = std::min(K, n_blocks), best_cost = -1;
+        for (long long k = 1; k <= std::min(K, n_blocks); ++k) {
             const long long rounds_main = ((long long)S * k + R - 1) / R, per_wave = (n_blocks + k - 1) / k;
             const long long rounds_edge = k > 1 ? ((long long)S * (k - 1) + R - 1) / R : 0;
             const long long cost = rounds_main * per_wave + rounds_edge;

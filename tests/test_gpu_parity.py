@@ -401,6 +401,39 @@ def test_batch_p1_output_bits_are_those_of_the_natural_bin_layout(ohs, synth):
         assert h.hexdigest() == digest, f"k_conv_p1 output bits changed: {S} streams x {blocks} blocks x {calls} calls"
 
 
+@pytest.mark.parametrize("S,n_blocks", [(512, 64), (1024, 32), (2048, 16), (1000, 40)])
+def test_batch_p1_many_streams_chunk_plans_agree_bit_for_bit(ohs, synth, monkeypatch, S, n_blocks):
+    """From 512 streams up a stream has 8, 4 or 2 chunks and k_conv_p1 deals a workgroup's waves out across its streams
+    (p1_wave_job: every stream owns waves of all age ranks).  Where a stream is cut does not change a bit of the result,
+    so the default plan must equal a plan of three chunks per stream (consecutive waves, OHS_P1_TARGET_WAVES) and one
+    without any cut, over two calls that chain the state."""
+    import torch
+    dev = torch.device("cuda:0")
+    irs = synth.hrir_set(512)
+    outs = []
+    for target in (None, 3 * S, S):
+        if target is None:
+            monkeypatch.delenv("OHS_P1_TARGET_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("OHS_P1_TARGET_WAVES", str(target))
+        bp = ohs.BatchProcessor(S, num_bands=10)
+        for p in range(4):
+            bp.set_ir(p, irs[p])
+        bp.set_eq_enabled(False)
+        ys = []
+        for c in range(2):
+            x = synth.white_noise_torch(7 + c, S, n_blocks * 512, dev)
+            y = torch.empty_like(x)
+            bp.process(x, out=y)
+            torch.cuda.synchronize()
+            ys.append(y.cpu())
+        outs.append(torch.cat(ys, dim=-1))
+        del bp
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
+
+
 def test_batch_long_ir_p32(ohs, synth, oracle):
     w = _batch_vs_oracle(ohs, synth, oracle, S=3, taps=16384, n_blocks=20, eq_on=False, calls=2)
     print("batch P=32 worst rel RMS", w)
