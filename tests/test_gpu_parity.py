@@ -434,6 +434,41 @@ def test_batch_p1_many_streams_chunk_plans_agree_bit_for_bit(ohs, synth, monkeyp
     assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
 
 
+def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, monkeypatch):
+    """The XCD partition experiment (kernels.h: xcd_grid -- workgroups on XCDs outside the launch's set return at once, the
+    others renumber themselves) must leave results untouched: EQ on XCDs [0, 2), P = 1 convolution on [2, 5), against the
+    unpartitioned launches."""
+    import torch
+    dev = torch.device("cuda:0")
+    S, n_blocks = 37, 70
+    irs = synth.hrir_set(512)
+    outs = []
+    for part in (False, True):
+        if part:
+            monkeypatch.setenv("OHS_P1_XCD", "2,3")
+            monkeypatch.setenv("OHS_EQ_XCD", "0,2")
+        else:
+            monkeypatch.delenv("OHS_P1_XCD", raising=False)
+            monkeypatch.delenv("OHS_EQ_XCD", raising=False)
+        bp = ohs.BatchProcessor(S, num_bands=10)
+        for p in range(4):
+            bp.set_ir(p, irs[p])
+        for i, b in enumerate(synth.eq_table()):
+            bp.update_band_coeffs(i, synth.FS, b)
+        bp.set_eq_enabled(True)
+        ys = []
+        for c in range(2):
+            x = synth.white_noise_torch(3 + c, S, n_blocks * 512, dev)
+            y = torch.empty_like(x)
+            bp.process(x, out=y)
+            torch.cuda.synchronize()
+            ys.append(y.cpu())
+        outs.append(torch.cat(ys, dim=-1))
+        del bp
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+
+
 def test_batch_long_ir_p32(ohs, synth, oracle):
     w = _batch_vs_oracle(ohs, synth, oracle, S=3, taps=16384, n_blocks=20, eq_on=False, calls=2)
     print("batch P=32 worst rel RMS", w)
