@@ -1033,12 +1033,23 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     long long s64;
     int ck;
     p1_wave_job(gw, A.chunks, s64, ck);
-    if (s64 >= (long long)A.n_streams) return;
-    const int s = (int)s64;
+    // A.own_tails: the wave computes the overlap entering its chunk itself -- one dry block in front of its range (b0 - 1,
+    // nothing stored) instead of a boundary tail from the pre-pass.  In place that block's input is the LAST thing the
+    // wave of chunk ck - 1 overwrites, so every wave of the workgroup (all chunks of a stream live in one workgroup in
+    // these launches: launch_conv_p1) reads its first inputs in front of a barrier and stores behind it; waves without
+    // work take part in the barrier too.
+    bool active = s64 < (long long)A.n_streams;
+    const int s = active ? (int)s64 : 0;
     const int n_main = A.n_blocks;        // every block's output is this kernel's
     const int b0 = __builtin_amdgcn_readfirstlane(p1_chunk_begin(s, ck, n_main, A.chunks, A.weights));
     const int b1 = __builtin_amdgcn_readfirstlane(p1_chunk_begin(s, ck + 1, n_main, A.chunks, A.weights));
-    if (b0 >= b1) return;
+    active = active && b0 < b1;
+    if (!active) {
+        if (A.own_tails) __syncthreads();
+        return;
+    }
+    const bool own_tail = A.own_tails && ck > 0;
+    const int t_first = own_tail ? b0 - 1 : b0;
 #ifdef OHS_P1_STAMPS
     const unsigned long long stamp_start = __builtin_amdgcn_s_memrealtime();
     const unsigned long long clk_start = __builtin_amdgcn_s_memtime();
@@ -1057,6 +1068,9 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
             const float2 t1 = tails[a * 64 + lane], t2 = tails[(8 + a) * 64 + lane];
             tail[a] = make_float2(t1.x + t2.x, t1.y + t2.y);
         }
+    } else if (own_tail) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) tail[a] = make_float2(0.0f, 0.0f);
     } else {
         const float2 *ct = A.chunk_tails + ((size_t)s * A.chunks + ck) * (size_t)(8 * 64);
 #pragma unroll
@@ -1072,10 +1086,11 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     // peak: hipcc spilled 80 VGPRs at 4 waves per SIMD and still 24 at 3.)
     float xl[8], xr[8];
     // one address per channel and direction, advanced by a block per iteration; every access is base + immediate
-    const float *pl = in_l + (size_t)b0 * kBlock + lane, *pr = in_r + (size_t)b0 * kBlock + lane;
-    float *ql = out_l + (size_t)b0 * kBlock + lane, *qr = out_r + (size_t)b0 * kBlock + lane;
+    const float *pl = in_l + (size_t)t_first * kBlock + lane, *pr = in_r + (size_t)t_first * kBlock + lane;
+    float *ql = out_l + (size_t)t_first * kBlock + lane, *qr = out_r + (size_t)t_first * kBlock + lane;
 #pragma unroll
     for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
+    if (A.own_tails) __syncthreads();       // (waits for the loads above: no wave has stored anything yet)
     // Issue arbitration between the four waves of a SIMD is "priority, then age": left alone, the oldest wave of
     // every SIMD runs almost unimpeded and the youngest gets the leftover slots -- waves 0..3 of a workgroup finished
     // their ranges after 156 us, waves 12..15 after 268 us (tools/p1_stamps.py), and a CU's slots stood empty for a
@@ -1087,7 +1102,8 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #if !defined(OHS_P1_BPERMUTE_MIRROR) && !defined(OHS_P1_NATURAL)
     const PairedPlan plan = paired_plan(lane);
 #endif
-    for (int t = b0; t < b1; ++t) {
+    for (int t = t_first; t < b1; ++t) {
+        const bool dry = t < b0;            // the block in front of the range: its overlap is all that is wanted
         if (A.prio_mode == 1) {
             switch (prio_phase & 3) {       // (s_setprio takes an immediate)
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -1133,18 +1149,21 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #pragma unroll
         for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
 #endif
+        if (!dry) {
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
+            for (int a = 0; a < 8; ++a) {
 #ifdef OHS_KO_STORE
-            if (w[a].x == 123.456f) {       // never true: the stores stay in the code, none is executed
+                if (w[a].x == 123.456f) {       // never true: the stores stay in the code, none is executed
 #endif
-            OHS_P1_ST(&ql[64 * a], (w[a].x + tail[a].x) * A.gain);         // (1/N is in C and D)
-            OHS_P1_ST(&qr[64 * a], (w[a].y + tail[a].y) * A.gain);
+                OHS_P1_ST(&ql[64 * a], (w[a].x + tail[a].x) * A.gain);         // (1/N is in C and D)
+                OHS_P1_ST(&qr[64 * a], (w[a].y + tail[a].y) * A.gain);
 #ifdef OHS_KO_STORE
+                }
+#endif
             }
-#endif
-            tail[a] = w[a + 8];
         }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) tail[a] = w[a + 8];
         ql += kBlock; qr += kBlock;
     }
 #ifdef OHS_P1_STAMPS
@@ -1275,7 +1294,9 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (a.chunks > 1) {   // 1b. the boundary tails
+    if (a.own_tails && !(kP1Waves == 16 && (a.chunks == 2 || a.chunks == 4 || a.chunks == 8 || a.chunks == 16)))
+        return hipErrorInvalidValue;        // all chunks of a stream must live in one workgroup (p1_wave_job)
+    if (a.chunks > 1 && !a.own_tails) {   // 1b. the boundary tails
         static std::atomic<unsigned long long> lds_ok{0};
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1_edges), shmem_main, lds_ok);
         if (e != hipSuccess) return e;

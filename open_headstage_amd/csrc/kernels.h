@@ -149,6 +149,8 @@ struct ConvP1Args {
     int weights[4];             // relative length of a chunk by the age rank of the wave that runs it (conv_kernels.hip: p1_chunk_begin)
     int fp_mode;                // denormal handling, see ohs_set_fp_mode
     int xcd_lo, xcd_n;          // XCDs the main and edges kernels may use (xcd_grid); 0, 8 = all
+    int own_tails;              // 1: no boundary-tail pre-pass, every wave runs one dry block in front of its chunk (chunks 2, 4, 8 or
+                                // 16: all chunks of a stream in one workgroup -- p1_wave_job); 0: k_conv_p1_edges fills chunk_tails
 };
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
 int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)

@@ -393,6 +393,11 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         a.tails = c.d_tails; a.tails_out = c.d_tails_alt; a.chunk_tails = c.d_chunk_tails;
         a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
         a.xcd_lo = xcd_lo; a.xcd_n = xcd_n;
+        {   // boundary tails by the chunks' own waves where a stream's chunks share a workgroup (OHS_P1_OWN_TAILS=0: pre-pass)
+            const char *env_ot = getenv("OHS_P1_OWN_TAILS");    // tuning experiments, read per call
+            const bool allowed = conv_p1_waves_per_cu() == 16 && (K == 2 || K == 4 || K == 8 || K == 16);
+            a.own_tails = (allowed && !(env_ot && env_ot[0] == '0')) ? 1 : 0;
+        }
         const char *env_sg = getenv("OHS_P1_STAGGER");          // tuning experiments
         a.stagger = env_sg ? atoi(env_sg) : 0;
         const char *env_pr = getenv("OHS_P1_PRIO");             // tuning experiments: 1 = rotate the issue priority per block
@@ -2192,14 +2197,16 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
     // re-reads that are served by L2 are not counted).  This is NOT the SURVEY 8d per-block model
     // (ohs_batch_algorithmic_bytes): the P = 1 kernel keeps overlaps in registers and writes no history.
     //   EQ:             audio in + out, state + coefficients
-    //   P = 1:          audio in + out; per stream the K chunk-boundary tails (written by the pre-pass, read by the
-    //                   main kernel, 4 KiB each) and the four-overlap state (8 KiB in + 8 KiB out)
+    //   P = 1:          audio in + out; per stream and chunk boundary the input block in front of it once more (4 KiB;
+    //                   where the pre-pass computes the boundary tails, K not in {2, 4, 8, 16}: the tail written and read
+    //                   as well) and the four-overlap state (8 KiB in + 8 KiB out)
     //   P > 1 (time-parallel): audio in, ring write, ring read once, W write, W read, audio out
     const uint64_t eq_sb = 4096u + 4096u + 520u;
     *eq_bytes = b->eq_enable ? nbk * S * eq_sb : 0;
     if (P == 1) {
         const uint64_t K = (uint64_t)conv_p1_chunks(b->ctx, (size_t)S, (long long)nbk, 0);
-        *conv_bytes = nbk * S * 8192u + S * (K * 2u * 4096u + 2u * 8192u);
+        const bool own_tails = conv_p1_waves_per_cu() == 16 && (K == 2 || K == 4 || K == 8 || K == 16);
+        *conv_bytes = nbk * S * 8192u + S * ((K - 1) * (own_tails ? 1u : 3u) * 4096u + 2u * 8192u);
     } else {
         *conv_bytes = nbk * S * (4096u + 8192u + 8192u + 8192u + 8192u + 4096u);
     }
