@@ -336,12 +336,17 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
         // A short launch (the last, 2 % time chunk of an overlapped batch step: 19 blocks), a few blocks per wave at
         // best: every chunk boundary costs the pre-pass a block's work, and a wave count just above a round starts a second,
         // almost empty one.  Cost in block times: rounds x blocks per wave for the main kernel + rounds for the boundary
-        // tails; the smallest K of minimal cost (19 blocks x 256 streams: K = 10, one round of two blocks).
+        // tails (one more block per wave where the chunks' own waves compute them -- K = 2, 4, 8, 16 --, else a pre-pass
+        // launch: its rounds + about a block time of launch); the smallest K of minimal cost (19 blocks x 256 streams:
+        // K = 16, one round of at most 2 + 1 blocks, no pre-pass).
+        const bool own_ok = conv_p1_waves_per_cu() == 16;
         long long best_k = std::min(K, n_blocks), best_cost = -1;
         for (long long k = 1; k <= std::min(K, n_blocks); ++k) {
             const long long rounds_main = ((long long)S * k + R - 1) / R, per_wave = (n_blocks + k - 1) / k;
-            const long long rounds_edge = k > 1 ? ((long long)S * (k - 1) + R - 1) / R : 0;
-            const long long cost = rounds_main * per_wave + rounds_edge;
+            long long cost;
+            if (k == 1) cost = rounds_main * per_wave;
+            else if (own_ok && (k == 2 || k == 4 || k == 8 || k == 16)) cost = rounds_main * (per_wave + 1);
+            else cost = rounds_main * per_wave + ((long long)S * (k - 1) + R - 1) / R + 1;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_k = k; }
         }
         K = best_k;
