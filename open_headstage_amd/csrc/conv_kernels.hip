@@ -1061,7 +1061,11 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     float *out_r = out_l + A.out_ch_stride;
 
     float2 tail[8];
-    if (ck == 0) {
+    if (ck == 0 && A.merged_in) {
+        const float2 *mt = A.merged_in + (size_t)s * (8 * 64);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) tail[a] = mt[a * 64 + lane];
+    } else if (ck == 0) {
         const float2 *tails = A.tails + (size_t)s * (2 * 8 * 64);
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -1112,6 +1116,11 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
             default: __builtin_amdgcn_s_setprio(3); break;
             }
             ++prio_phase;
+        }
+        if (A.last_in && t == A.n_blocks - 1) {     // lazy state: the launch's last block keeps a copy of its input
+            float *li = A.last_in + (size_t)s * (2 * kBlock) + lane;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) { li[64 * a] = xl[a]; li[kBlock + 64 * a] = xr[a]; }
         }
         float2 v[16];
 #pragma unroll
@@ -1165,6 +1174,11 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #pragma unroll
         for (int a = 0; a < 8; ++a) tail[a] = w[a + 8];
         ql += kBlock; qr += kBlock;
+    }
+    if (A.merged_out && b1 == A.n_blocks) {         // lazy state: the merged overlap the launch leaves behind
+        float2 *mo = A.merged_out + (size_t)s * (8 * 64);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) mo[a * 64 + lane] = tail[a];
     }
 #ifdef OHS_P1_STAMPS
     if (lane == 0 && gw < 32768) {
@@ -1279,6 +1293,16 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Arg
 
 int conv_p1_waves_per_cu() { return kP1Waves; }
 
+hipError_t launch_conv_p1_state(const ConvP1Args &a, hipStream_t st)
+{
+    if (a.n_blocks <= 0 || a.n_streams <= 0 || !a.tails_out) return hipErrorInvalidValue;
+    const size_t shmem_state = (kTabComplex + kP1StateWaves * kWaveLdsComplex) * sizeof(float2);
+    const long long waves = 2ll * a.n_streams;
+    hipLaunchKernelGGL(k_conv_p1_state, dim3((unsigned)((waves + kP1StateWaves - 1) / kP1StateWaves)),
+                       dim3(64 * kP1StateWaves), shmem_state, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
 {
     if (a.n_blocks <= 0 || a.n_streams <= 0 || a.chunks < 1) return hipErrorInvalidValue;
@@ -1286,12 +1310,9 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
     if ((unsigned long long)a.n_blocks * kBlock >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit frame offsets
     if (a.xcd_n < 1 || a.xcd_n > 8 || a.xcd_lo < 0 || a.xcd_lo + a.xcd_n > 8) return hipErrorInvalidValue;
     const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
-    {   // 1a. the state the launch leaves behind
-        const size_t shmem_state = (kTabComplex + kP1StateWaves * kWaveLdsComplex) * sizeof(float2);
-        const long long waves = 2ll * a.n_streams;
-        hipLaunchKernelGGL(k_conv_p1_state, dim3((unsigned)((waves + kP1StateWaves - 1) / kP1StateWaves)),
-                           dim3(64 * kP1StateWaves), shmem_state, st, a);
-        hipError_t e = hipGetLastError();
+    if ((a.merged_out == nullptr) != (a.last_in == nullptr)) return hipErrorInvalidValue;
+    if (!a.merged_out) {   // 1a. the state the launch leaves behind, in the per-path form (else: lazily, kernels.h)
+        hipError_t e = launch_conv_p1_state(a, st);
         if (e != hipSuccess) return e;
     }
     if (a.own_tails && !(kP1Waves == 16 && (a.chunks == 2 || a.chunks == 4 || a.chunks == 8 || a.chunks == 16)))

@@ -149,10 +149,20 @@ struct ConvP1Args {
     int weights[4];             // relative length of a chunk by the age rank of the wave that runs it (conv_kernels.hip: p1_chunk_begin)
     int fp_mode;                // denormal handling, see ohs_set_fp_mode
     int xcd_lo, xcd_n;          // XCDs the main and edges kernels may use (xcd_grid); 0, 8 = all
+    // Lazy state (batch objects): merged_out != nullptr -- the launch leaves its state as the MERGED overlap of its last
+    // block ([stream][8][64], what its own chunks hand each other) plus a copy of that block's input frames
+    // (last_in: [stream][2][512]), and k_conv_p1_state is not launched; the per-path overlaps the state at rest
+    // consists of are computed from last_in when somebody needs them (ohs_api.hip: conv_materialise_state).
+    // merged_in != nullptr: the state the launch starts from is such a merged overlap (else tails: the per-path form).
+    const float2 *merged_in;
+    float2 *merged_out;
+    float *last_in;
     int own_tails;              // 1: no boundary-tail pre-pass, every wave runs one dry block in front of its chunk (chunks 2, 4, 8 or
                                 // 16: all chunks of a stream in one workgroup -- p1_wave_job); 0: k_conv_p1_edges fills chunk_tails
 };
 hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
+// k_conv_p1_state alone: the per-path overlaps block n_blocks - 1 of a.in leaves behind -> a.tails_out
+hipError_t launch_conv_p1_state(const ConvP1Args &a, hipStream_t st);
 int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)
 // CD[0][..] = (A - jB)/2, CD[1][..] = (A + jB)/2 from four single-partition spectra
 hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,

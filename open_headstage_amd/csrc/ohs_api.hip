@@ -183,6 +183,11 @@ struct ConvState {
     float2 *d_W1 = nullptr;         // [S][1024]
     int fp_mode = 0;                // denormal handling of every launch on this state (kernels.h: ohs_set_fp_mode)
     int xcd_lo = 0, xcd_n = 8;      // XCDs the P = 1 kernels may use (kernels.h: xcd_grid); set per call by the batch
+    // Lazy state of the P = 1 fast path (batch objects; kernels.h: ConvP1Args::merged_out).  While tails_lazy, d_tails is
+    // stale and the state is {d_merged, d_last_in}; conv_materialise_state turns it back into the per-path overlaps.
+    bool lazy_ok = false, tails_lazy = false;
+    float2 *d_merged = nullptr, *d_merged_alt = nullptr;    // [S][8][64]
+    float *d_last_in = nullptr;                             // [S][2][512]
 };
 
 void conv_free(ConvState &c)
@@ -197,6 +202,10 @@ void conv_free(ConvState &c)
     if (c.d_cdm) hipFree(c.d_cdm);
     if (c.d_W) hipFree(c.d_W);
     if (c.d_W1) hipFree(c.d_W1);
+    if (c.d_merged) hipFree(c.d_merged);
+    if (c.d_merged_alt) hipFree(c.d_merged_alt);
+    if (c.d_last_in) hipFree(c.d_last_in);
+    c.d_merged = nullptr; c.d_merged_alt = nullptr; c.d_last_in = nullptr; c.tails_lazy = false; c.lazy_ok = false;
     c.d_cdm = nullptr; c.d_W = nullptr; c.d_W1 = nullptr;
     c.d_hist = nullptr; c.d_tails = nullptr; c.d_tails_alt = nullptr; c.d_cd = nullptr; c.d_chunk_tails = nullptr;
 }
@@ -220,6 +229,41 @@ int conv_init(ConvState &c, size_t S, hipStream_t st)
     HIP_TRY(hipMalloc(&c.d_tails_alt, S * 2 * 8 * 64 * sizeof(float2)));
     HIP_TRY(hipMalloc(&c.d_cd, 2 * NF * sizeof(float2)));
     c.cd_valid = false;
+    return OHS_OK;
+}
+
+// Batch objects let the P = 1 fast path leave its state behind lazily: a k_conv_p1 launch then ends with the merged
+// overlap of its last block and a copy of that block's input instead of a k_conv_p1_state launch (9 us + a launch gap
+// per call, hidden nowhere when the convolution runs alone); the next fast launch starts from the merged overlap -- which
+// also makes a call boundary invisible in the output bits.  OHS_P1_LAZY_STATE=0: the per-path state after every launch.
+int conv_enable_lazy_state(ConvState &c)
+{
+    const char *e = getenv("OHS_P1_LAZY_STATE");
+    if (e && e[0] == '0') return OHS_OK;
+    HIP_TRY(hipMalloc(&c.d_merged, c.S * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c.d_merged_alt, c.S * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c.d_last_in, c.S * 2 * BS * sizeof(float)));
+    c.lazy_ok = true;
+    c.tails_lazy = false;
+    return OHS_OK;
+}
+
+// the per-path overlaps (d_tails) from the lazy state: whoever reads or edits d_tails calls this first -- a per-path
+// set_ir (with the OLD spectra still in place: the overlaps belong to them), the general and the long-IR kernels
+int conv_materialise_state(ConvState &c, DeviceCtx *ctx, hipStream_t st)
+{
+    if (!c.tails_lazy) return OHS_OK;
+    ConvP1Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = c.d_last_in; a.in_stream_stride = 2 * (long long)BS; a.in_ch_stride = (long long)BS;
+    a.n_blocks = 1; a.n_streams = (int)c.S;
+    for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
+    a.tails_out = c.d_tails;
+    a.tw = ctx->d_tw; a.fp_mode = c.fp_mode;
+    a.xcd_lo = 0; a.xcd_n = 8;
+    hipError_t e = launch_conv_p1_state(a, st);
+    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1_state launch: ") + hipGetErrorString(e));
+    c.tails_lazy = false;
     return OHS_OK;
 }
 
@@ -259,6 +303,10 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
     DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    {   // the overlaps at rest belong to the spectra that are about to be replaced
+        const int rcm = conv_materialise_state(c, ctx, st);
+        if (rcm) return rcm;
+    }
     // every failure path below frees what it allocated: a HIP_TRY inside the lambda returns from the
     // lambda only, the buffers are released after it
     float2 *nH = nullptr;
@@ -396,6 +444,9 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         a.CD = c.d_cd;
         for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
         a.tails = c.d_tails; a.tails_out = c.d_tails_alt; a.chunk_tails = c.d_chunk_tails;
+        a.merged_in = c.tails_lazy ? c.d_merged : nullptr;
+        a.merged_out = c.lazy_ok ? c.d_merged_alt : nullptr;
+        a.last_in = c.lazy_ok ? c.d_last_in : nullptr;
         a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
         a.xcd_lo = xcd_lo; a.xcd_n = xcd_n;
         {   // boundary tails by the chunks' own waves where a stream's chunks share a workgroup (OHS_P1_OWN_TAILS=0: pre-pass)
@@ -425,8 +476,17 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         for (int g = 0; g < 4; ++g) a.weights[g] = weighted ? kWeights[(size_t)g] : 1;
         hipError_t e = launch_conv_p1(a, st);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
-        std::swap(c.d_tails, c.d_tails_alt);
+        if (c.lazy_ok) {
+            std::swap(c.d_merged, c.d_merged_alt);
+            c.tails_lazy = true;
+        } else {
+            std::swap(c.d_tails, c.d_tails_alt);
+        }
     } else {
+        {   // these kernels read and write the per-path overlaps
+            const int rcm = conv_materialise_state(c, ctx, st);
+            if (rcm) return rcm;
+        }
         int Pmax = 1;
         for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
         const bool since_equal = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3];
@@ -1669,6 +1729,7 @@ int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch *
         }
     }
     rc = conv_init(b->conv, n_streams, b->st);
+    if (rc == OHS_OK) rc = conv_enable_lazy_state(b->conv);
     if (rc == OHS_OK) rc = eq_init(b->eq, num_bands, 2 * n_streams, 48000.0f, b->st);
     if (rc == OHS_OK && hipStreamSynchronize(b->st) != hipSuccess) rc = fail(OHS_ERR_HIP, "sync failed");
     if (rc) { ohs_batch_destroy(b); return rc; }
@@ -1782,6 +1843,7 @@ int ohs_batch_reset(ohs_batch *b)
     ConvState &c = b->conv;
     HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), b->st));
     HIP_TRY(hipMemsetAsync(c.d_tails, 0, c.S * 2 * 8 * 64 * sizeof(float2), b->st));
+    c.tails_lazy = false;       // (the zeroed per-path overlaps are the state)
     c.cnt = 0;
     for (int p = 0; p < 4; ++p) c.since[p] = 0;
     int rc = eq_reset(b->eq, b->st);
@@ -2211,7 +2273,10 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
     if (P == 1) {
         const uint64_t K = (uint64_t)conv_p1_chunks(b->ctx, (size_t)S, (long long)nbk, 0);
         const bool own_tails = conv_p1_waves_per_cu() == 16 && (K == 2 || K == 4 || K == 8 || K == 16);
-        *conv_bytes = nbk * S * 8192u + S * ((K - 1) * (own_tails ? 1u : 3u) * 4096u + 2u * 8192u);
+        // state: per-path overlaps 8 KiB in + 8 KiB out, or (lazy, kernels.h) merged overlap 4 KiB in + 4 KiB out + the
+        // last block's input copy 4 KiB
+        const uint64_t state = b->conv.lazy_ok ? 3u * 4096u : 2u * 8192u;
+        *conv_bytes = nbk * S * 8192u + S * ((K - 1) * (own_tails ? 1u : 3u) * 4096u + state);
     } else {
         *conv_bytes = nbk * S * (4096u + 8192u + 8192u + 8192u + 8192u + 4096u);
     }

@@ -373,7 +373,9 @@ def test_batch_p1_output_bits_are_those_of_the_natural_bin_layout(ohs, synth):
     """k_conv_p1 computes in a paired bin layout (bins k and N - k in one lane: no mirror-spectrum reads).  Bin by bin
     its arithmetic is that of the natural layout, operation for operation, so the output BITS must be the ones the
     natural-layout build (-DOHS_P1_NATURAL) produced: tests/golden/p1_output_sha256.txt, written by tools/p1_hash.py
-    with that build.  A deliberate change of the kernel's arithmetic needs the file regenerated (and says so here)."""
+    with that build.  A deliberate change of the kernel's arithmetic needs the file regenerated (and says so here):
+    last done when batch objects began to carry the MERGED overlap across call boundaries (lazy state) -- the
+    multi-call shapes changed, the single-call ones did not; OHS_P1_LAZY_STATE=0 still reproduces the older file."""
     import hashlib
     import os
     import torch
@@ -432,6 +434,52 @@ def test_batch_p1_many_streams_chunk_plans_agree_bit_for_bit(ohs, synth, monkeyp
     assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
+
+
+@pytest.mark.parametrize("eq_on", [False, True])
+def test_batch_p1_call_boundaries_are_invisible_in_the_output_bits(ohs, synth, eq_on):
+    """A batch object carries the merged overlap of its last block from one P = 1 call to the next (the lazy state of
+    conv_launch) -- what the chunks of one launch hand each other -- and the EQ's state is exact anyway: cutting a
+    signal into calls of 40 + 1 + 39 blocks gives the bits of one call of 80, and a per-path set_ir afterwards still
+    finds the per-path overlaps (materialised from the saved last block)."""
+    import torch
+    dev = torch.device("cuda:0")
+    S, n = 7, 80
+    irs = synth.hrir_set(512)
+    x = synth.white_noise_torch(21, S, n * 512, dev)
+
+    def make():
+        bp = ohs.BatchProcessor(S, num_bands=10)
+        for p in range(4):
+            bp.set_ir(p, irs[p])
+        for i, b in enumerate(synth.eq_table()):
+            bp.update_band_coeffs(i, synth.FS, b)
+        bp.set_eq_enabled(eq_on)
+        return bp
+
+    one = make()
+    y1 = torch.empty_like(x)
+    one.process(x, out=y1)
+    parts = make()
+    ys = []
+    for a, b in ((0, 40), (40, 41), (41, 80)):
+        xi = x[:, :, a * 512:b * 512].contiguous()
+        yi = torch.empty_like(xi)
+        parts.process(xi, out=yi)
+        ys.append(yi)
+    torch.cuda.synchronize()
+    y2 = torch.cat(ys, dim=-1)
+    assert torch.equal(y1.view(torch.int32), y2.view(torch.int32))
+    # the state at rest is still the reference's: replace one path mid-stream on both objects, same continuation
+    for bp in (one, parts):
+        bp.set_ir(2, irs[2][:100])
+    z = synth.white_noise_torch(22, S, 10 * 512, dev)
+    z1, z2 = torch.empty_like(z), torch.empty_like(z)
+    one.process(z, out=z1)
+    parts.process(z, out=z2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(z1).all()
+    assert torch.equal(z1.view(torch.int32), z2.view(torch.int32))
 
 
 def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, monkeypatch):
