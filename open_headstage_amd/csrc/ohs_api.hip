@@ -1951,6 +1951,7 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
         }
         ~XcdScope() { b->eq.xcd_lo = 0; b->eq.xcd_n = 8; b->conv.xcd_lo = 0; b->conv.xcd_n = 8; }
     } xcd_scope(b, nch > 1 ? b->xcd_split : 0);
+    bool joined = false;        // the last convolution ran on the caller's stream: nothing left to join
     for (int i = 0; i < nch; ++i) {
         const size_t blk0 = nch == 1 ? 0 : (size_t)(kCut[i] * (double)n_blocks);
         const size_t blk1 = nch == 1 ? n_blocks : (i == nch - 1 ? n_blocks : (size_t)(kCut[i + 1] * (double)n_blocks));
@@ -1987,7 +1988,18 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
         rc = eq_launch(b->eq, d_in + off, d_out + off, ss, cs, (long long)nb_i * BS, st, nullptr, ev_a, ev_b);
         if (rc) return rc;
         hipStream_t cst = st;
-        if (nch > 1) {
+        // The LAST chunk's convolution has nothing to hide under: it runs on the caller's stream right behind its EQ
+        // launch (after the earlier convolutions on st2, whose state it continues), which spares the step the hop to
+        // st2 and the join back -- two cross-stream waits of 10-25 us each in front of the caller's next launch.
+        const bool tail_on_caller = nch > 1 && !deferred && i == nch - 1;
+        if (tail_on_caller) {
+            hipEvent_t ev;
+            rc = get_event(&ev); if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev, b->st2));
+            HIP_TRY(hipStreamWaitEvent(st, ev, 0));
+            b->ev_inflight.push_back(ev);
+            joined = true;
+        } else if (nch > 1) {
             HIP_TRY(hipStreamWaitEvent(b->st2, ev_b, 0));
             cst = b->st2;
         }
@@ -2009,7 +2021,7 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
         b->join_pending = true;
         b->chunk_done_n = nch;
         b->pend_out = d_out; b->pend_blocks = n_blocks; b->pend_ss = stream_stride; b->pend_cs = channel_stride;
-    } else if (nch > 1) {           // join: the caller's stream continues only after the last convolution
+    } else if (nch > 1 && !joined) {    // join: the caller's stream continues only after the last convolution
         hipEvent_t ev;
         rc = get_event(&ev); if (rc) return rc;
         HIP_TRY(hipEventRecord(ev, b->st2));
