@@ -1303,7 +1303,7 @@ hipError_t launch_conv_p1_state(const ConvP1Args &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
+hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (a.n_blocks <= 0 || a.n_streams <= 0 || a.chunks < 1) return hipErrorInvalidValue;
     if (a.chunks > a.n_blocks) return hipErrorInvalidValue;
@@ -1311,6 +1311,8 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
     if (a.xcd_n < 1 || a.xcd_n > 8 || a.xcd_lo < 0 || a.xcd_lo + a.xcd_n > 8) return hipErrorInvalidValue;
     const size_t shmem_main = (kTabComplex + 2 * kFft + kP1Waves * kWaveLdsComplex) * sizeof(float2);
     if ((a.merged_out == nullptr) != (a.last_in == nullptr)) return hipErrorInvalidValue;
+    const bool single_kernel = a.merged_out && (a.own_tails || a.chunks == 1);
+    if (ev_start && !single_kernel) { hipError_t e = hipEventRecord(ev_start, st); if (e != hipSuccess) return e; }
     if (!a.merged_out) {   // 1a. the state the launch leaves behind, in the per-path form (else: lazily, kernels.h)
         hipError_t e = launch_conv_p1_state(a, st);
         if (e != hipSuccess) return e;
@@ -1332,9 +1334,15 @@ hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st)
         static std::atomic<unsigned long long> lds_ok{0};
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k_conv_p1), shmem_main, lds_ok);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_conv_p1, dim3(xcd_grid((unsigned)((waves + kP1Waves - 1) / kP1Waves), a.xcd_n)),
-                           dim3(64 * kP1Waves), shmem_main, st, a);
-        return hipGetLastError();
+        const dim3 grid(xcd_grid((unsigned)((waves + kP1Waves - 1) / kP1Waves), a.xcd_n));
+        if (single_kernel && (ev_start || ev_stop)) {
+            hipExtLaunchKernelGGL(k_conv_p1, grid, dim3(64 * kP1Waves), shmem_main, st, ev_start, ev_stop, 0, a);
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL(k_conv_p1, grid, dim3(64 * kP1Waves), shmem_main, st, a);
+        e = hipGetLastError();
+        if (e == hipSuccess && ev_stop) e = hipEventRecord(ev_stop, st);
+        return e;
     }
 }
 

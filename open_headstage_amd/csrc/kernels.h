@@ -160,7 +160,9 @@ struct ConvP1Args {
     int own_tails;              // 1: no boundary-tail pre-pass, every wave runs one dry block in front of its chunk (chunks 2, 4, 8 or
                                 // 16: all chunks of a stream in one workgroup -- p1_wave_job); 0: k_conv_p1_edges fills chunk_tails
 };
-hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st);
+// (ev_start / ev_stop, optional: recorded at the start / completion of the launches; carried by the dispatch itself when
+// the call is a single kernel -- see launch_eq_pass)
+hipError_t launch_conv_p1(const ConvP1Args &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // k_conv_p1_state alone: the per-path overlaps block n_blocks - 1 of a.in leaves behind -> a.tails_out
 hipError_t launch_conv_p1_state(const ConvP1Args &a, hipStream_t st);
 int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one workgroup)

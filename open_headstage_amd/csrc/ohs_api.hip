@@ -406,9 +406,18 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
 
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
                 float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
-                bool allow_fast = true)
+                bool allow_fast = true, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
-    if (n_blocks <= 0) return OHS_OK;       // nothing to do (the pre-pass would index block -1)
+    // (ev_start / ev_stop: recorded at the start / completion of the call's launches)
+    struct EvScope {        // the paths that do not carry the events in a dispatch: recorded around their launches
+        hipStream_t st; hipEvent_t stop; bool armed;
+        ~EvScope() { if (armed && stop) hipEventRecord(stop, st); }
+    } ev_scope{st, ev_stop, false};
+    if (n_blocks <= 0) {                    // nothing to do (the pre-pass would index block -1)
+        if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
+        if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, st));
+        return OHS_OK;
+    }
     const bool p1 = c.P[0] == 1 && c.P[1] == 1 && c.P[2] == 1 && c.P[3] == 1;
     if (p1 && allow_fast) {
         // every path has one partition: time-parallel single-FFT-pair kernel
@@ -474,7 +483,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         // every chunk must keep >= 2 blocks: mean length x (smallest weight / mean weight) >= 2
         const bool weighted = (long long)n_blocks * 4 * wmin >= 2ll * K * wsum;
         for (int g = 0; g < 4; ++g) a.weights[g] = weighted ? kWeights[(size_t)g] : 1;
-        hipError_t e = launch_conv_p1(a, st);
+        hipError_t e = launch_conv_p1(a, st, ev_start, ev_stop);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
         if (c.lazy_ok) {
             std::swap(c.d_merged, c.d_merged_alt);
@@ -483,6 +492,8 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             std::swap(c.d_tails, c.d_tails_alt);
         }
     } else {
+        if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
+        ev_scope.armed = true;
         {   // these kernels read and write the per-path overlaps
             const int rcm = conv_materialise_state(c, ctx, st);
             if (rcm) return rcm;
@@ -2003,10 +2014,18 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
             HIP_TRY(hipStreamWaitEvent(b->st2, ev_b, 0));
             cst = b->st2;
         }
-        rc = span_begin(cst, 1); if (rc) return rc;
-        rc = conv_launch(b->conv, b->ctx, d_out + off, ss, cs, d_out + off, ss, cs, nb_i, b->gain, cst);
-        if (rc) return rc;
-        rc = span_end(cst); if (rc) return rc;
+        {
+            hipEvent_t cv_a = nullptr, cv_b = nullptr;
+            if (b->profiling) {
+                ohs_batch::Span sp; sp.kind = 1; sp.a = nullptr; sp.b = nullptr;
+                rc = get_event(&sp.a); if (rc) return rc;
+                rc = get_event(&sp.b); if (rc) return rc;
+                b->spans.push_back(sp);
+                cv_a = sp.a; cv_b = sp.b;
+            }
+            rc = conv_launch(b->conv, b->ctx, d_out + off, ss, cs, d_out + off, ss, cs, nb_i, b->gain, cst, true, cv_a, cv_b);
+            if (rc) return rc;
+        }
         if (nch > 1 && deferred) {
             while (b->chunk_done.size() <= (size_t)i) {
                 hipEvent_t ev;
