@@ -287,10 +287,10 @@ def self_launch(n: int) -> int:
     return worst
 
 
-# one MI355X, ms per headline step by streams per GPU (profiles/r03_eq_share.txt, run 4): what strong scaling of a
-# 2048-stream job must look like, whatever the fabric does -- the step time is one EQ chain's serial time up to ~1000
-# streams per GPU, so fewer streams per GPU do not make a step shorter
-STEP_MS_BY_STREAMS = {256: 6.07, 512: 5.96, 1024: 7.37, 1536: 9.14, 2048: 11.39, 4096: 23.33}
+# one MI355X, ms per headline step by streams per GPU (profiles/r03_step_by_streams.txt, end of round 3): what strong
+# scaling of a 2048-stream job must look like, whatever the fabric does -- the step time is one EQ chain's serial time
+# up to ~1000 streams per GPU, so fewer streams per GPU do not make a step shorter
+STEP_MS_BY_STREAMS = {128: 5.64, 256: 5.66, 512: 5.78, 1024: 6.40, 1536: 8.09, 2048: 10.16, 4096: 20.4}
 
 
 def expected_step_ms(streams: int) -> float:

@@ -380,6 +380,10 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
             if (eff >= 0.97) break;
         }
     }
+    // One chunk per stream (4096 streams and more) leaves the age ranks nothing to balance: two chunks, dealt out over
+    // ranks {0, 3} / {1, 2} (conv_kernels.hip: p1_wave_job), cost a second round but end together -- 4096 streams: 8.9 ->
+    // 8.0 ms of convolution per step.
+    if (K == 1 && n_blocks >= 16 && target_override <= 0 && conv_p1_waves_per_cu() == 16) K = 2;
     if (n_blocks < 4 * K && target_override <= 0) {
         // A short launch (the last, 2 % time chunk of an overlapped batch step: 19 blocks), a few blocks per wave at
         // best: every chunk boundary costs the pre-pass a block's work, and a wave count just above a round starts a second,
