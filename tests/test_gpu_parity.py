@@ -403,7 +403,7 @@ def test_batch_p1_output_bits_are_those_of_the_natural_bin_layout(ohs, synth):
         assert h.hexdigest() == digest, f"k_conv_p1 output bits changed: {S} streams x {blocks} blocks x {calls} calls"
 
 
-@pytest.mark.parametrize("S,n_blocks", [(512, 64), (1024, 32), (2048, 16), (1000, 40)])
+@pytest.mark.parametrize("S,n_blocks", [(512, 64), (1024, 32), (2048, 16), (1000, 40), (4100, 16)])
 def test_batch_p1_many_streams_chunk_plans_agree_bit_for_bit(ohs, synth, monkeypatch, S, n_blocks):
     """From 512 streams up a stream has 8, 4 or 2 chunks and k_conv_p1 deals a workgroup's waves out across its streams
     (p1_wave_job: every stream owns waves of all age ranks).  Where a stream is cut does not change a bit of the result,
