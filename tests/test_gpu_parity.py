@@ -517,6 +517,41 @@ def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, monkeypa
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
 
 
+def test_batch_p1_random_shapes_default_plan_equals_one_chunk_per_stream(ohs, synth, monkeypatch):
+    """Seeded sweep over stream counts, block counts and call sequences: the launch plan conv_p1_chunks picks (chunk count
+    by rounds / cost rule, waves dealt out across streams, boundary tails by the chunks' own waves or by the pre-pass,
+    lazy state across calls) against the plainest plan there is -- one wave per stream, no cut -- bit for bit, in place."""
+    import torch
+    rng = np.random.default_rng(20261004)
+    dev = torch.device("cuda:0")
+    irs = synth.hrir_set(512)
+    shapes = [(1, 1), (2, 3), (16, 16), (17, 33), (255, 20), (256, 16), (257, 70), (300, 5)]
+    shapes += [(int(rng.integers(1, 700)), int(rng.integers(1, 130))) for _ in range(14)]
+    for S, n in shapes:
+        calls = [n, max(1, n // 3), n]
+        outs = []
+        for plain in (False, True):
+            if plain:
+                monkeypatch.setenv("OHS_P1_TARGET_WAVES", str(S))
+            else:
+                monkeypatch.delenv("OHS_P1_TARGET_WAVES", raising=False)
+            bp = ohs.BatchProcessor(S, num_bands=10)
+            for p in range(4):
+                bp.set_ir(p, irs[p])
+            bp.set_eq_enabled(False)
+            bp.set_gain(0.9)
+            ys = []
+            for c, nb in enumerate(calls):
+                x = synth.white_noise_torch(100 + c, S, nb * 512, dev)
+                bp.process(x, out=x)            # in place
+                ys.append(x.cpu())
+            torch.cuda.synchronize()
+            outs.append(torch.cat(ys, dim=-1))
+            del bp
+        assert torch.isfinite(outs[0]).all(), (S, n)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (S, n)
+
+
 def test_batch_long_ir_p32(ohs, synth, oracle):
     w = _batch_vs_oracle(ohs, synth, oracle, S=3, taps=16384, n_blocks=20, eq_on=False, calls=2)
     print("batch P=32 worst rel RMS", w)
