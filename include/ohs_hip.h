@@ -63,6 +63,8 @@ int         ohs_version(void);               /* (major<<16)|(minor<<8)|patch */
 const char *ohs_status_string(int status);
 const char *ohs_last_error(void);            /* thread-local detail of the last failure */
 int         ohs_device_count(int *count);    /* OHS_ERR_NO_DEVICE if the runtime is unusable */
+/* "domain:bus:device.function" of HIP device `device` (hipDeviceGetPCIBusId): which physical GPU a shard ran on */
+int         ohs_device_pci_bus_id(int device, char *out, size_t capacity);
 
 /* Diagnostic: `batch` natural-order complex DFT-1024s (interleaved re,im; host pointers) through the
  * wavefront FFT primitive -- the device counterpart of rustfft's `Fft::process`
@@ -324,8 +326,7 @@ int  ohs_node_batch_create(int n_devices, const int *devices, size_t streams_tot
 void ohs_node_batch_destroy(ohs_node_batch *nb);
 /* the shard of device slot `slot` (0 .. n_devices - 1): HIP device index, first stream id, number of streams */
 int  ohs_node_batch_shard(const ohs_node_batch *nb, int slot, int *device, size_t *first_stream, size_t *n_streams);
-/* the per-device handle, for callers that keep their audio in device memory: ohs_batch_process(handle, ...) on that
- * device with that shard's streams.  Owned by the node batch. */
+/* the per-device handle (owned by the node batch), for callers that drive a device themselves */
 int  ohs_node_batch_device_batch(ohs_node_batch *nb, int slot, ohs_batch **out);
 /* All shared tables at once: four impulse responses (HOST pointers, lens[p] == 0 => that path is muted) and the EQ
  * table (coeffs: num_bands x {b0,b1,b2,a1,a2}, enabled: num_bands ints; both may be NULL = leave the EQ table as
@@ -346,6 +347,25 @@ int  ohs_node_batch_reset(ohs_node_batch *nb);
  * ohs_batch_process_host on one device with the same chunk_blocks: streams do not interact. */
 int  ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h_out, size_t n_blocks,
                                  size_t stream_stride, size_t channel_stride, size_t chunk_blocks);
+/* THE DATA PATH OF THE NODE: ohs_batch_process on every device at once, audio resident in device memory.
+ * d_in[slot] / d_out[slot] (slot = 0 .. n_devices - 1) are DEVICE pointers on that slot's device holding that shard's
+ * n_streams(slot) streams, planar, same strides (in floats) on every device; d_in[slot] may equal d_out[slot].  Every
+ * device's launches are issued by a host thread of its own (created with the node batch) on a stream of its own, so
+ * the devices' queues fill side by side; nothing crosses PCIe or xGMI -- all mutable state is per stream
+ * (convolution.rs:36-42,76-79; parametric_eq.rs:125-129).  Returns when every device has QUEUED its work: the outputs
+ * are complete after ohs_node_batch_sync.  Calls queue up in order; the set_* / reset calls of the node batch wait for
+ * what is queued.  Results are bit-identical to ohs_batch_process on one device holding the same streams. */
+int  ohs_node_batch_process(ohs_node_batch *nb, const float *const d_in[], float *const d_out[], size_t n_blocks,
+                            size_t stream_stride, size_t channel_stride);
+/* waits (host side) for everything ohs_node_batch_process has queued, on every device */
+int  ohs_node_batch_sync(ohs_node_batch *nb);
+/* the stream (hipStream_t) ohs_node_batch_process queues slot's work on: a caller that produces its audio on the device
+ * orders its own kernels against it with events */
+int  ohs_node_batch_stream(ohs_node_batch *nb, int slot, void **hip_stream);
+/* device time of what is queued between the two calls, per device slot (HIP events on the slots' streams; _end waits):
+ * ms_per_slot has n_devices entries.  The node's rate is the job's frames / the largest entry. */
+int  ohs_node_batch_timer_begin(ohs_node_batch *nb);
+int  ohs_node_batch_timer_end(ohs_node_batch *nb, float *ms_per_slot);
 /* what RCCL reports for the communicators in use: ncclCommCount of slot 0's, and 1 if librccl.so is loaded */
 int  ohs_node_batch_rccl_info(const ohs_node_batch *nb, int *comm_size, int *rccl_loaded);
 

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "ohs_status_string": (C.c_char_p, [C.c_int]),
     "ohs_last_error": (C.c_char_p, []),
     "ohs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "ohs_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "ohs_debug_fft1024": (C.c_int, [C.c_int, fp, fp, C.c_int, C.c_size_t]),
     "ohs_engine_create": (C.c_int, [C.c_int, vpp]),
     "ohs_engine_clone": (C.c_int, [vp, vpp]),
@@ -116,6 +117,12 @@ PROTOTYPES = {
     "ohs_node_batch_set_gain": (C.c_int, [vp, C.c_float]),
     "ohs_node_batch_reset": (C.c_int, [vp]),
     "ohs_node_batch_process_host": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "ohs_node_batch_process": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t,
+                                         C.c_size_t]),
+    "ohs_node_batch_sync": (C.c_int, [vp]),
+    "ohs_node_batch_stream": (C.c_int, [vp, C.c_int, vpp]),
+    "ohs_node_batch_timer_begin": (C.c_int, [vp]),
+    "ohs_node_batch_timer_end": (C.c_int, [vp, fp]),
     "ohs_node_batch_rccl_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 

@@ -142,11 +142,18 @@ class BatchProcessor:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and getattr(self, "_borrowed", None) is None:
             try:
                 lib().ohs_batch_destroy(h)
             except Exception:
                 pass
+
+
+def device_pci_bus_id(device: int) -> str:
+    """'domain:bus:device.function' of HIP device `device` (ohs_device_pci_bus_id)"""
+    buf = C.create_string_buffer(64)
+    check(lib().ohs_device_pci_bus_id(int(device), buf, 64))
+    return buf.value.decode()
 
 
 class NodeBatchProcessor:
@@ -216,6 +223,68 @@ class NodeBatchProcessor:
         n, ok = C.c_int(), C.c_int()
         check(lib().ohs_node_batch_rccl_info(self._h, C.byref(n), C.byref(ok)))
         return int(n.value), bool(ok.value)
+
+    def device_batch(self, slot: int) -> "BatchProcessor":
+        """the per-device batch of slot `slot` as a BatchProcessor VIEW (owned by the node batch: profiling, byte
+        models and direct ohs_batch_process calls on that device)"""
+        dev, _, cnt = self.shard(slot)
+        h = C.c_void_p()
+        check(lib().ohs_node_batch_device_batch(self._h, int(slot), C.byref(h)))
+        v = BatchProcessor.__new__(BatchProcessor)
+        v.n_streams, v.num_bands, v.device = cnt, self.num_bands, dev
+        v._h = h
+        v._borrowed = self         # keeps the owner alive; __del__ must not destroy the handle
+        return v
+
+    # -- device-resident data path ---------------------------------------------------------
+    def process_ptrs(self, d_in, d_out, n_blocks: int, stream_stride: int, channel_stride: int) -> None:
+        """d_in / d_out: one device address per slot (ohs_node_batch_process).  Returns when every device has queued
+        its work; sync() waits for it."""
+        n = self.n_devices
+        if len(d_in) != n or len(d_out) != n:
+            raise ValueError("one pointer per device slot")
+        ai = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_in])
+        ao = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_out])
+        check(lib().ohs_node_batch_process(self._h, ai, ao, int(n_blocks), int(stream_stride), int(channel_stride)))
+
+    def process(self, xs, outs=None):
+        """xs: one float32 CUDA tensor [n_streams(slot), 2, frames] per slot, each on its slot's device; outs likewise
+        (None = in place).  Asynchronous: sync() before reading.  torch is only the owner of the device memory here --
+        nothing is queued on torch's streams, so the tensors must be complete (torch.cuda.synchronize) beforehand."""
+        if outs is None:
+            outs = xs
+        frames = None
+        for slot, (x, y) in enumerate(zip(xs, outs)):
+            dev, _, cnt = self.shard(slot)
+            if not (x.is_cuda and x.dim() == 3 and x.is_contiguous() and x.device.index == dev and y.shape == x.shape
+                    and y.is_contiguous() and y.device == x.device and str(x.dtype) == "torch.float32" and y.dtype == x.dtype):
+                raise TypeError(f"slot {slot}: need contiguous float32 CUDA tensors on device {dev}")
+            if x.shape[0] != cnt or x.shape[1] != 2 or x.shape[2] % BLOCK_SIZE:
+                raise ValueError(f"slot {slot}: expected [{cnt}, 2, k*{BLOCK_SIZE}], got {tuple(x.shape)}")
+            if frames is None:
+                frames = x.shape[2]
+            elif frames != x.shape[2]:
+                raise ValueError("every slot must hold the same number of frames")
+        self.process_ptrs([x.data_ptr() for x in xs], [y.data_ptr() for y in outs], frames // BLOCK_SIZE, 2 * frames, frames)
+        return outs
+
+    def sync(self) -> None:
+        check(lib().ohs_node_batch_sync(self._h))
+
+    def stream(self, slot: int) -> int:
+        """the hipStream_t (as an integer) the slot's work is queued on"""
+        p = C.c_void_p()
+        check(lib().ohs_node_batch_stream(self._h, int(slot), C.byref(p)))
+        return int(p.value or 0)
+
+    def timer_begin(self) -> None:
+        check(lib().ohs_node_batch_timer_begin(self._h))
+
+    def timer_end(self):
+        """-> device milliseconds per slot of what was queued since timer_begin (waits for it)"""
+        ms = (C.c_float * self.n_devices)()
+        check(lib().ohs_node_batch_timer_end(self._h, ms))
+        return [float(v) for v in ms]
 
     def process_host(self, x, out=None, chunk_blocks: int = 0):
         """x, out: contiguous float32 HOST buffers [streams_total, 2, frames] (numpy, or torch tensors -- pinned ones

@@ -188,6 +188,64 @@ hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+// O: gated contributions of the blocks the ring held before the call (kernels.h: ConvTpOldArgs).  Old block -d may be
+// seen by path p iff d <= since[p] (the reference resets only THAT path's history, convolution.rs:135-138); it meets
+// partition i = t + d of output block t.  The combined spectra are built per (d, i) from the visible paths exactly as
+// k_build_cd_multi builds them from all four: C = (A - jB)/2, D = (A + jB)/2, A = H0 + jH1, B = H2 + jH3.
+__global__ __launch_bounds__(256) void k_conv_tp_old(const ConvTpOldArgs A)
+{
+    ohs_set_fp_mode(A.fp_mode);
+    const int b = (int)(blockIdx.x & (kFft / 256 - 1)) * 256 + threadIdx.x;
+    const int t = (int)(blockIdx.x / (kFft / 256)) % A.n_old;
+    const size_t s = (size_t)(blockIdx.x / (kFft / 256)) / (size_t)A.n_old;
+    if (s >= (size_t)A.n_streams) return;
+    const int mb = mirror_position(b);
+    const float2 *hist = A.hist + s * (size_t)A.cap * kFft;
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+    float2 acc = make_float2(0.f, 0.f);
+    bool any = false;
+    const int d_end = A.Pmax - t;               // i = t + d <= Pmax - 1
+    for (int d = 1; d < d_end; ++d) {
+        const int i = t + d;
+        const bool g0 = i < A.P[0] && (long long)d <= A.since[0];
+        const bool g1 = i < A.P[1] && (long long)d <= A.since[1];
+        const bool g2 = i < A.P[2] && (long long)d <= A.since[2];
+        const bool g3 = i < A.P[3] && (long long)d <= A.since[3];
+        if (!(g0 || g1 || g2 || g3)) continue;      // (wave-uniform)
+        any = true;
+        const float2 *hs = hist + (size_t)((A.cnt_old - (unsigned long long)d) & mask) * kFft;
+        const float2 z = hs[b], m = hs[mb];
+        // branch-free over the paths: the partition index is clamped into the path's own range, a gated-off path's
+        // spectrum is multiplied by 0 (block_mac in conv_kernels.hip does the same)
+        const float f0 = g0 ? 1.0f : 0.0f, f1 = g1 ? 1.0f : 0.0f, f2 = g2 ? 1.0f : 0.0f, f3 = g3 ? 1.0f : 0.0f;
+        const float2 h0 = A.H[0][(size_t)(i < A.P[0] ? i : A.P[0] - 1) * kFft + b];
+        const float2 h1 = A.H[1][(size_t)(i < A.P[1] ? i : A.P[1] - 1) * kFft + b];
+        const float2 h2 = A.H[2][(size_t)(i < A.P[2] ? i : A.P[2] - 1) * kFft + b];
+        const float2 h3 = A.H[3][(size_t)(i < A.P[3] ? i : A.P[3] - 1) * kFft + b];
+        const float2 A_ = make_float2(h0.x * f0 - h1.y * f1, h0.y * f0 + h1.x * f1);
+        const float2 B_ = make_float2(h2.x * f2 - h3.y * f3, h2.y * f2 + h3.x * f3);
+        const float2 c = make_float2(0.5f * (A_.x + B_.y), 0.5f * (A_.y - B_.x));
+        const float2 dd = make_float2(0.5f * (A_.x - B_.y), 0.5f * (A_.y + B_.x));
+        acc.x += z.x * c.x - z.y * c.y + m.x * dd.x + m.y * dd.y;
+        acc.y += z.x * c.y + z.y * c.x + m.x * dd.y - m.y * dd.x;
+    }
+    if (any) {
+        float2 *w = A.W + (s * (size_t)A.n_mac + (size_t)t) * kFft + b;
+        const float2 o = *w;
+        *w = make_float2(o.x + acc.x, o.y + acc.y);
+    }
+}
+
+hipError_t launch_conv_tp_old(const ConvTpOldArgs &a, hipStream_t st)
+{
+    if (a.n_old <= 0 || a.n_streams <= 0) return hipSuccess;
+    if (a.n_old > a.n_mac) return hipErrorInvalidValue;
+    const unsigned long long wgs = (unsigned long long)(kFft / 256) * (unsigned long long)a.n_old * (unsigned long long)a.n_streams;
+    if (wgs > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv_tp_old, dim3((unsigned)wgs), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // host helper: the leaders of the 514 position pairs {b, mirror(b)}, ordered so that consecutive
 // threads touch consecutive addresses as far as possible (ascending b)
 int conv_tp_build_pairs(int *out)

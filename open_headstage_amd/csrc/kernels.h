@@ -203,6 +203,26 @@ struct ConvTpArgs {
 hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st);
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st);
 hipError_t launch_conv_tp_inverse(const ConvTpArgs &a, hipStream_t st);     // + the new state (the last block's four overlaps)
+// O: the blocks the ring held BEFORE the call, under per-path gating -- what the three kernels above cannot do.  After a
+// per-path set_ir in mid-stream path p must not see blocks older than its own reset (convolution.rs:135-138: that
+// path's history is all zero again), while the other paths still do.  The host hides the old blocks from F / M / I by
+// starting the call Ppad - 1 zeroed ring slots further on; this kernel then adds, for the first n_old = Pmax - 1 blocks
+// of the call, W_t += sum_{d >= 1, i = t + d < Pmax} Z_{-d} C_i^(d) + conj(Z_{-d}[N-k]) D_i^(d), where C^(d), D^(d) are
+// built on the fly from the paths that may see old block -d (d <= since[p]) and have an i-th partition.  thread = one
+// layout position, workgroup = (quarter spectrum, block t, stream); every load is an L2 hit (ring + spectra).
+struct ConvTpOldArgs {
+    int n_streams, n_old, Pmax;
+    const float2 *H[4];
+    int P[4];
+    long long since[4];         // blocks processed since that path's last set_ir, BEFORE this call
+    const float2 *hist;         // the ring; old block -d sits in slot (cnt_old - d) & (cap - 1)
+    int cap;
+    unsigned long long cnt_old; // absolute index the call's first block would have had without the zeroed gap
+    float2 *W;                  // [stream][n_mac][1024], accumulated into (M has written it)
+    int n_mac;
+    int fp_mode;
+};
+hipError_t launch_conv_tp_old(const ConvTpOldArgs &a, hipStream_t st);
 int conv_tp_build_pairs(int *out);   // host: fills <= 514 leaders, returns the count
 // CD[i][0] = (A_i - jB_i)/2, CD[i][1] = (A_i + jB_i)/2 for i < Ppad; H_p,i := 0 for i >= P_p
 hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,

@@ -16,8 +16,11 @@
 
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -79,6 +82,58 @@ Rccl &rccl()
 
 }  // namespace
 
+// One host thread per device slot, alive as long as the node batch: it has made its device current once and runs
+// whatever the calling thread posts (issuing a device's dozen launches from a thread of its own keeps the devices'
+// queues filling side by side; the HIP "current device" is per thread, so the caller's own is never touched).
+struct DeviceWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, quit = false;
+    int rc = OHS_OK;
+    std::string err;
+
+    void loop(int device)
+    {
+        hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            lk.unlock();
+            const int r = job();
+            std::string e = r ? ohs_last_error() : "";      // (thread-local in the core library: carried to the caller)
+            lk.lock();
+            rc = r; err.swap(e);
+            has_job = false;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> f)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f); has_job = true;
+        cv.notify_all();
+    }
+    int wait(std::string *e)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !has_job; });
+        if (rc && e) *e = err;
+        return rc;
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct ohs_node_batch {
     int n = 0;
     size_t streams_total = 0, num_bands = 0;
@@ -87,8 +142,11 @@ struct ohs_node_batch {
     std::vector<ohs_batch *> b;
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> st;        // one per device, for the broadcasts
+    std::vector<hipStream_t> pst;       // one per device: what ohs_node_batch_process queues its device's work on
+    std::vector<hipEvent_t> ev0, ev1;   // ohs_node_batch_timer_begin / _end
     std::vector<float *> d_tab;         // broadcast buffer per device
     size_t tab_cap = 0;                 // floats
+    std::vector<std::unique_ptr<DeviceWorker>> worker;
 };
 
 namespace {
@@ -106,6 +164,7 @@ int grow_tables(ohs_node_batch *nb, size_t floats)
     if (floats <= nb->tab_cap) return OHS_OK;
     size_t cap = nb->tab_cap ? nb->tab_cap : 4096;
     while (cap < floats) cap *= 2;
+    nb->tab_cap = 0;        // (a failure half-way leaves buffers of mixed sizes: none of them counts until all are there)
     for (int i = 0; i < nb->n; ++i) {
         NB_HIP(hipSetDevice(nb->dev[(size_t)i]));
         NB_HIP(hipStreamSynchronize(nb->st[(size_t)i]));
@@ -140,6 +199,30 @@ int broadcast_from_host(ohs_node_batch *nb, const float *host, size_t floats)
     return OHS_OK;
 }
 
+// the calling thread's current device is the caller's: entry points that visit the devices themselves put it back
+struct DeviceRestore {
+    int dev = 0;
+    bool ok = false;
+    DeviceRestore() { ok = hipGetDevice(&dev) == hipSuccess; }
+    ~DeviceRestore() { if (ok) hipSetDevice(dev); }
+};
+
+// fn(slot) on every device's worker thread at once; the first failure (by slot) is reported with its slot number
+int run_on_all(ohs_node_batch *nb, const std::function<int(int)> &fn)
+{
+    for (int i = 0; i < nb->n; ++i) nb->worker[(size_t)i]->post([&fn, i] { return fn(i); });
+    int first_rc = OHS_OK;
+    std::string first_err;
+    int first_slot = -1;
+    for (int i = 0; i < nb->n; ++i) {
+        std::string e;
+        const int r = nb->worker[(size_t)i]->wait(&e);
+        if (r && first_rc == OHS_OK) { first_rc = r; first_err = e; first_slot = i; }
+    }
+    if (first_rc) return fail(first_rc, "device slot " + std::to_string(first_slot) + ": " + first_err);
+    return OHS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -168,6 +251,9 @@ int ohs_node_batch_create(int n_devices, const int *devices, size_t streams_tota
     nb->first.resize((size_t)n_devices); nb->count.resize((size_t)n_devices);
     nb->b.assign((size_t)n_devices, nullptr); nb->comm.assign((size_t)n_devices, nullptr);
     nb->st.assign((size_t)n_devices, nullptr); nb->d_tab.assign((size_t)n_devices, nullptr);
+    nb->pst.assign((size_t)n_devices, nullptr);
+    nb->ev0.assign((size_t)n_devices, nullptr); nb->ev1.assign((size_t)n_devices, nullptr);
+    DeviceRestore restore;
     auto body = [&]() -> int {
         for (int i = 0; i < n_devices; ++i) {
             shard_range(streams_total, i, n_devices, &nb->first[(size_t)i], &nb->count[(size_t)i]);
@@ -175,12 +261,24 @@ int ohs_node_batch_create(int n_devices, const int *devices, size_t streams_tota
             if (r) return r;
             NB_HIP(hipSetDevice(dev[(size_t)i]));
             NB_HIP(hipStreamCreateWithFlags(&nb->st[(size_t)i], hipStreamNonBlocking));
+            NB_HIP(hipStreamCreateWithFlags(&nb->pst[(size_t)i], hipStreamNonBlocking));
+            NB_HIP(hipEventCreate(&nb->ev0[(size_t)i]));
+            NB_HIP(hipEventCreate(&nb->ev1[(size_t)i]));
         }
         NB_NCCL(R.CommInitAll(nb->comm.data(), n_devices, dev.data()));
+        for (int i = 0; i < n_devices; ++i) {
+            nb->worker.emplace_back(new DeviceWorker);
+            DeviceWorker *w = nb->worker.back().get();
+            w->th = std::thread([w, d = dev[(size_t)i]] { w->loop(d); });
+        }
         return OHS_OK;
     };
     rc = body();
-    if (rc) { ohs_node_batch_destroy(nb); return rc; }
+    if (rc) {
+        const std::string keep = ohs_last_error();
+        ohs_node_batch_destroy(nb);
+        return fail(rc, keep);
+    }
     *out = nb;
     return OHS_OK;
 }
@@ -188,9 +286,14 @@ int ohs_node_batch_create(int n_devices, const int *devices, size_t streams_tota
 void ohs_node_batch_destroy(ohs_node_batch *nb)
 {
     if (!nb) return;
+    DeviceRestore restore;
     Rccl &R = rccl();
+    for (auto &w : nb->worker) w->stop();
     for (int i = 0; i < nb->n; ++i) {
         hipSetDevice(nb->dev[(size_t)i]);
+        if (nb->pst[(size_t)i]) { hipStreamSynchronize(nb->pst[(size_t)i]); hipStreamDestroy(nb->pst[(size_t)i]); }
+        if (nb->ev0[(size_t)i]) hipEventDestroy(nb->ev0[(size_t)i]);
+        if (nb->ev1[(size_t)i]) hipEventDestroy(nb->ev1[(size_t)i]);
         if (nb->st[(size_t)i]) hipStreamSynchronize(nb->st[(size_t)i]);
         if (nb->comm[(size_t)i] && R.CommDestroy) R.CommDestroy(nb->comm[(size_t)i]);
         if (nb->d_tab[(size_t)i]) hipFree(nb->d_tab[(size_t)i]);
@@ -221,6 +324,7 @@ int ohs_node_batch_set_tables(ohs_node_batch *nb, const float *const irs[4], con
 {
     if (!nb || !irs || !lens) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
     if ((eq_coeffs == nullptr) != (eq_enabled == nullptr)) return fail(OHS_ERR_INVALID_ARG, "eq_coeffs and eq_enabled go together");
+    DeviceRestore restore;
     size_t off[5] = {0, 0, 0, 0, 0};
     for (int p = 0; p < 4; ++p) {
         if (lens[p] && !irs[p]) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
@@ -263,6 +367,7 @@ int ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t 
     if (path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "path must be 0..3");
     if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
+    DeviceRestore restore;
     int rc = broadcast_from_host(nb, ir, len);
     if (rc) return rc;
     for (int i = 0; i < nb->n; ++i) {
@@ -287,27 +392,69 @@ int ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const flo
 }
 int ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable) { NB_FOR_EACH(ohs_batch_set_eq_enabled(h, eq_enable)) }
 int ohs_node_batch_set_gain(ohs_node_batch *nb, float gain) { NB_FOR_EACH(ohs_batch_set_gain(h, gain)) }
-int ohs_node_batch_reset(ohs_node_batch *nb) { NB_FOR_EACH(ohs_batch_reset(h)) }
+int ohs_node_batch_reset(ohs_node_batch *nb)
+{
+    DeviceRestore restore;
+    NB_FOR_EACH(ohs_batch_reset(h))
+}
 
 int ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h_out, size_t n_blocks,
                                 size_t stream_stride, size_t channel_stride, size_t chunk_blocks)
 {
     if (!nb || !h_in || !h_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
-    std::vector<int> rc((size_t)nb->n, OHS_OK);
-    std::vector<std::string> err((size_t)nb->n);
-    auto work = [&](int i) {
+    return run_on_all(nb, [&](int i) {
         const size_t o = nb->first[(size_t)i] * stream_stride;
-        rc[(size_t)i] = ohs_batch_process_host(nb->b[(size_t)i], h_in + o, h_out + o, n_blocks, stream_stride,
-                                               channel_stride, chunk_blocks);
-        if (rc[(size_t)i]) err[(size_t)i] = ohs_last_error();       // (thread-local: carried back to the caller below)
-    };
-    std::vector<std::thread> th;
-    for (int i = 1; i < nb->n; ++i) th.emplace_back(work, i);
-    work(0);
-    for (auto &t : th) t.join();
+        return ohs_batch_process_host(nb->b[(size_t)i], h_in + o, h_out + o, n_blocks, stream_stride, channel_stride,
+                                      chunk_blocks);
+    });
+}
+
+// Device-resident data path: every device's ohs_batch_process is issued by that device's own host thread on that
+// device's own stream; nothing crosses PCIe or xGMI (streams do not interact: convolution.rs:36-42,76-79).
+int ohs_node_batch_process(ohs_node_batch *nb, const float *const d_in[], float *const d_out[], size_t n_blocks,
+                           size_t stream_stride, size_t channel_stride)
+{
+    if (!nb || !d_in || !d_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
     for (int i = 0; i < nb->n; ++i)
-        if (rc[(size_t)i]) return fail(rc[(size_t)i], "device slot " + std::to_string(i) + ": " + err[(size_t)i]);
+        if (!d_in[i] || !d_out[i]) return fail(OHS_ERR_INVALID_ARG, "NULL device pointer for slot " + std::to_string(i));
+    return run_on_all(nb, [&](int i) {
+        return ohs_batch_process(nb->b[(size_t)i], d_in[i], d_out[i], n_blocks, stream_stride, channel_stride,
+                                 nb->pst[(size_t)i]);
+    });
+}
+
+int ohs_node_batch_sync(ohs_node_batch *nb)
+{
+    if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");
+    return run_on_all(nb, [&](int i) { return ohs_batch_sync(nb->b[(size_t)i], nb->pst[(size_t)i]); });
+}
+
+int ohs_node_batch_stream(ohs_node_batch *nb, int slot, void **hip_stream)
+{
+    if (!nb || !hip_stream || slot < 0 || slot >= nb->n) return fail(OHS_ERR_INVALID_ARG, "bad node batch / slot");
+    *hip_stream = (void *)nb->pst[(size_t)slot];
     return OHS_OK;
+}
+
+int ohs_node_batch_timer_begin(ohs_node_batch *nb)
+{
+    if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");
+    return run_on_all(nb, [&](int i) {
+        NB_HIP(hipEventRecord(nb->ev0[(size_t)i], nb->pst[(size_t)i]));
+        return (int)OHS_OK;
+    });
+}
+
+int ohs_node_batch_timer_end(ohs_node_batch *nb, float *ms_per_slot)
+{
+    if (!nb || !ms_per_slot) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    return run_on_all(nb, [&](int i) {
+        NB_HIP(hipEventRecord(nb->ev1[(size_t)i], nb->pst[(size_t)i]));
+        const int r = ohs_batch_sync(nb->b[(size_t)i], nb->pst[(size_t)i]);
+        if (r) return r;
+        NB_HIP(hipEventElapsedTime(&ms_per_slot[i], nb->ev0[(size_t)i], nb->ev1[(size_t)i]));
+        return (int)OHS_OK;
+    });
 }
 
 int ohs_node_batch_rccl_info(const ohs_node_batch *nb, int *comm_size, int *rccl_loaded)

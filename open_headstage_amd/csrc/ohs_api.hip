@@ -506,11 +506,18 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
         const bool since_equal = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3];
         bool since_old = true;
-        for (int p = 0; p < 4; ++p) since_old = since_old && c.since[p] >= Pmax - 1;
+        for (int p = 0; p < 4; ++p) since_old = since_old && c.since[p] >= c.P[p] - 1;
         // gate-free condition of the time-parallel kernels: no path may have blocks in the ring that
-        // it must not see (either every path is older than the longest IR, or all were reset together
-        // -- conv_set_ir zeroed the ring then)
-        const bool tp = allow_fast && n_blocks >= 4 && (since_old || since_equal);
+        // it must not see (either every path is older than its own IR -- path p reads P[p] - 1 blocks back --, or all
+        // were reset together: conv_set_ir zeroed the ring then)
+        const bool gate_free = since_old || since_equal;
+        // Otherwise -- a per-path set_ir in mid-stream -- the same three kernels run on a ring whose old blocks they
+        // cannot reach (the call starts Ppad - 1 zeroed slots further on) and k_conv_tp_old adds what each path may
+        // still see of them to the first Pmax - 1 blocks.  The first segment must reach beyond every old block
+        // (n_blocks >= Pmax): the state it leaves behind is computed gate-free.  Shorter calls take the general kernel
+        // (one wave per stream, blocks in sequence: 290 x slower on BASELINE config 4, which is why long calls do not).
+        const bool tp_gated = allow_fast && !gate_free && n_blocks >= 4 && n_blocks >= Pmax;
+        const bool tp = allow_fast && n_blocks >= 4 && (gate_free || tp_gated);
         auto general = [&](const float *gin, float *gout, int nb, unsigned long long cnt, int since_add,
                            int skip_store, int zero_in, float2 *tails_out) -> int {
             ConvGeneralArgs a;
@@ -534,16 +541,32 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             // segment size: keep the MAC scratch around 128 MiB
             long long SEG = 16384 / (long long)c.S;
             SEG = std::max<long long>(8, std::min<long long>(SEG, 1024));
+            if (tp_gated) SEG = std::max<long long>(SEG, Pmax);
             const long long seg_max = std::min<long long>(SEG, n_blocks);
-            int rc = conv_grow_ring(c, (int)(seg_max + Ppad_for_ring(Pmax) - 1), st);
-            if (rc) return rc;
             const int Ppad = Ppad_for_ring(Pmax);
-            if (!c.cdm_valid || c.cdm_ppad != Ppad) {
+            // (gated: old blocks + the zeroed gap + the segment live in the ring together)
+            int rc = conv_grow_ring(c, (int)(seg_max + (tp_gated ? 2 : 1) * (Ppad - 1) + (tp_gated ? Pmax : 0)), st);
+            if (rc) return rc;
+            const unsigned long long cnt_old = c.cnt;
+            if (tp_gated) {
+                // the zeroed gap: ring slots cnt .. cnt + Ppad - 2 of every stream (two strided memsets when it wraps)
+                const unsigned long long gap = (unsigned long long)(Ppad - 1), cap = (unsigned long long)c.cap;
+                const unsigned long long s0 = c.cnt & (cap - 1), n0 = std::min(gap, cap - s0);
+                const size_t pitch = (size_t)c.cap * NF * sizeof(float2);
+                HIP_TRY(hipMemset2DAsync(c.d_hist + s0 * NF, pitch, 0, (size_t)n0 * NF * sizeof(float2), c.S, st));
+                if (n0 < gap)
+                    HIP_TRY(hipMemset2DAsync(c.d_hist, pitch, 0, (size_t)(gap - n0) * NF * sizeof(float2), c.S, st));
+                c.cnt += gap;
+            }
+            if (!c.d_cdm || c.cdm_ppad != Ppad) {       // (a set_ir that keeps Ppad re-uses the buffer: no wait, no malloc)
                 DeviceWideSection dws;
                 HIP_TRY(hipStreamSynchronize(st));
                 if (c.d_cdm) hipFree(c.d_cdm);
-                c.d_cdm = nullptr;
+                c.d_cdm = nullptr; c.cdm_valid = false;
                 HIP_TRY(hipMalloc(&c.d_cdm, (size_t)Ppad * 2 * NF * sizeof(float2)));
+                c.cdm_ppad = Ppad;
+            }
+            if (!c.cdm_valid) {
                 hipError_t e = launch_build_cd_multi(c.d_H[0], c.d_H[1], c.d_H[2], c.d_H[3], c.P[0], c.P[1],
                                                      c.P[2], c.P[3], Ppad, c.d_cdm, st);
                 if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("build_cd_multi: ") + hipGetErrorString(e));
@@ -572,6 +595,14 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
                 hipError_t e = launch_conv_tp_forward(a, st);
                 if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
+                if (e == hipSuccess && tp_gated && done == 0 && Pmax > 1) {
+                    ConvTpOldArgs o;
+                    o.n_streams = (int)c.S; o.n_old = Pmax - 1; o.Pmax = Pmax;
+                    for (int p = 0; p < 4; ++p) { o.H[p] = c.d_H[p]; o.P[p] = c.P[p]; o.since[p] = c.since[p]; }
+                    o.hist = c.d_hist; o.cap = c.cap; o.cnt_old = cnt_old;
+                    o.W = c.d_W; o.n_mac = seg; o.fp_mode = c.fp_mode;
+                    e = launch_conv_tp_old(o, st);
+                }
                 if (e == hipSuccess) e = launch_conv_tp_inverse(a, st);   // block 0 reads the OLD state; new state -> the other slab
                 if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp: ") + hipGetErrorString(e));
                 std::swap(c.d_tails, c.d_tails_alt);
@@ -1259,6 +1290,16 @@ int ohs_device_count(int *count)
                                            (e != hipSuccess ? hipGetErrorString(e) : "count == 0"));
     }
     *count = c;
+    return OHS_OK;
+}
+
+int ohs_device_pci_bus_id(int device, char *out, size_t capacity)
+{
+    if (!out || capacity < 16) return fail(OHS_ERR_INVALID_ARG, "out is NULL or shorter than 16 bytes");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(OHS_ERR_NO_DEVICE, "no usable HIP device");
+    if (device < 0 || device >= count) return fail(OHS_ERR_INVALID_ARG, "device index out of range");
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)std::min<size_t>(capacity, 64), device));
     return OHS_OK;
 }
 

@@ -47,7 +47,7 @@ def _c_type(t):
     depth = t.count("*")
     t2 = t.replace("*", " ")
     toks = t2.split()
-    const = "const" in toks
+    const = bool(toks) and toks[0] == "const"       # const-ness of the innermost pointee: `float *const d[]` is not
     toks = [k for k in toks if k not in ("const", "struct")]
     return depth, const, " ".join(toks)
 

@@ -74,6 +74,83 @@ def test_node_batch_one_device_bit_identical_to_the_device_batch(ohs, synth, ora
     assert not np.array_equal(y3, y_one)
 
 
+def test_node_batch_device_resident_process_is_the_device_batch_bit_for_bit(ohs, synth):
+    """ohs_node_batch_process: per-device device pointers, each device's launches issued by its own host thread on its
+    own stream, ohs_node_batch_sync, the per-slot device timer -- at one device the bits of ohs_batch_process."""
+    import torch
+    from open_headstage_amd.batch import device_pci_bus_id
+    dev = torch.device("cuda:0")
+    S, n_blocks = 19, 130
+    irs, coeffs, enabled = _tables(ohs, synth, 512)
+    nb = ohs.NodeBatchProcessor(S, num_bands=len(coeffs), n_devices=1)
+    nb.set_tables(irs, coeffs, enabled)
+    nb.set_eq_enabled(True)
+    nb.set_gain(0.8)
+    bp = ohs.BatchProcessor(S, num_bands=len(coeffs))
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i in range(len(coeffs)):
+        bp.set_band_coeffs(i, coeffs[i], bool(enabled[i]))
+    bp.set_eq_enabled(True)
+    bp.set_gain(0.8)
+    assert nb.stream(0) != 0
+    bus = device_pci_bus_id(0)
+    assert bus.count(":") == 2, bus
+    for call in range(3):
+        x = synth.white_noise_torch(50 * call, S, n_blocks * 512, dev)
+        y_node, y_one = torch.empty_like(x), torch.empty_like(x)
+        torch.cuda.synchronize()
+        nb.timer_begin()
+        nb.process([x], [y_node])
+        nb.process([y_node], [y_node])          # calls queue up in order; in place allowed
+        ms = nb.timer_end()
+        assert len(ms) == 1 and ms[0] > 0.0
+        nb.sync()
+        bp.process(x, out=y_one)
+        bp.process(y_one, out=y_one)
+        torch.cuda.synchronize()
+        assert torch.equal(y_node.view(torch.int32), y_one.view(torch.int32)), call
+        if call == 0:       # tables changed between calls: the set_* calls wait for what is queued
+            nb.set_ir(1, irs[1][:300]); bp.set_ir(1, irs[1][:300])
+    with pytest.raises(ohs.OhsError):
+        nb.process_ptrs([0], [0], 4, 4096, 2048)        # NULL device pointers
+
+
+def test_node_batch_without_librccl_fails_with_err_rccl(tmp_path):
+    """OHS_ERR_RCCL when librccl.so cannot be loaded: a child process whose dynamic loader is made to miss it.  The
+    library names it tries are librccl.so.1 / librccl.so by soname and under /opt/rocm/lib; the child pre-loads a
+    dlopen() that refuses every name containing "rccl"."""
+    import os
+    import subprocess
+    import sys
+    src = tmp_path / "nodlopen.c"
+    src.write_text(
+        '#define _GNU_SOURCE\n#include <dlfcn.h>\n#include <string.h>\n#include <stddef.h>\n'
+        'void *dlopen(const char *name, int flags)\n{\n'
+        '    static void *(*real)(const char *, int);\n'
+        '    if (!real) real = (void *(*)(const char *, int))dlsym(RTLD_NEXT, "dlopen");\n'
+        '    if (name && strstr(name, "rccl")) return NULL;\n'
+        '    return real(name, flags);\n}\n')
+    so = tmp_path / "libnodlopen.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", str(so), str(src), "-ldl"], check=True)
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import open_headstage_amd as ohs\n"
+        "from open_headstage_amd import _ffi\n"
+        "try:\n"
+        "    ohs.NodeBatchProcessor(4, n_devices=1)\n"
+        "    print('CREATED')\n"
+        "except ohs.OhsError as e:\n"
+        "    print('STATUS', e.status, str(e))\n"
+        "bp = ohs.BatchProcessor(2)\n"          # the single-device batch does not need RCCL
+        "print('BATCH_OK')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, LD_PRELOAD=str(so))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "STATUS 9" in res.stdout and "librccl" in res.stdout, res.stdout     # OHS_ERR_RCCL
+    assert "BATCH_OK" in res.stdout
+
+
 def test_node_batch_argument_checks(ohs):
     from open_headstage_amd import _ffi
     with pytest.raises(ohs.OhsError) as ei:
