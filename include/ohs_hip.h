@@ -177,6 +177,24 @@ int  ohs_eq_reset(ohs_eq *eq);
  * (|H| of the enabled LEFT bands). */
 int  ohs_eq_frequency_response(const ohs_eq *eq, float fs, const float *freqs, size_t n, float *out);
 
+/* ---- BiquadFilter  (src/dsp/parametric_eq.rs:46-123) as a type of its own ------------------------------------------
+ * The reference exports it (`pub struct`), uses it only inside StereoParametricEQ, and tests it directly
+ * (parametric_eq.rs:218-238).  One DF2T section on one mono chain; the same kernels as the EQ, so the same bits. */
+typedef struct ohs_biquad ohs_biquad;
+/* BiquadFilter::new(initial_sample_rate)  :63-76: PeakingEQ 0 dB @ 20 Hz Q 0.707, DISABLED */
+int  ohs_biquad_create(int device, float initial_sample_rate, ohs_biquad **out);
+int  ohs_biquad_clone(const ohs_biquad *src, ohs_biquad **out);     /* impl Clone  :52-60: coefficients, state, enabled */
+void ohs_biquad_destroy(ohs_biquad *f);
+int  ohs_biquad_reset_state(ohs_biquad *f);                         /* :78-80 */
+int  ohs_biquad_set_enabled(ohs_biquad *f, int enabled);            /* :82-84 */
+/* update_coeffs(filter_type, sample_rate, center_freq, q, gain_db)  :86-114; state kept (:112).  Coefficients by
+ * ohs_biquad_coeffs: the convenience path (see there); ohs_biquad_set_coeffs takes the `biquad` crate's own. */
+int  ohs_biquad_update_coeffs(ohs_biquad *f, int filter_type, float sample_rate, float center_freq, float q, float gain_db);
+int  ohs_biquad_set_coeffs(ohs_biquad *f, const float coeffs[5]);
+/* process_sample(input) -> output  :116-122 over n consecutive samples, in place (n == 1 is the reference's call);
+ * disabled => the samples come back bit for bit (:118-120). */
+int  ohs_biquad_process(ohs_biquad *f, float *samples, size_t n);
+
 /* ---- AutoEQ profile ingestion  (src/autoeq_parser.rs:21-70) -- SURVEY section 8 row f3 ---------- */
 /* BandSetting  autoeq_parser.rs:34-41 */
 typedef struct ohs_band_setting {
@@ -240,6 +258,26 @@ int  ohs_sofa_get_hrtf_irs(const ohs_sofa *s, float az_deg, float el_deg, float 
 int  ohs_sofa_resample_ir(const float *in, size_t n, float fs_in, float fs_out, float *out, size_t capacity,
                           size_t *out_len);
 
+/* ---- speaker angles -> the four paths (the wiring the reference plans but does not have) --------------------------
+ * The plugin's CLAP parameters az_l / el_l / az_r / el_r (src/lib.rs:120-128) are smoothed every callback and then
+ * DISCARDED (src/lib.rs:1170-1173); MySofa::get_hrtf_irs (src/sofa/loader.rs:136-199) and ConvolutionEngine::set_ir are
+ * never connected (github_issues/sofa_implement_logic_select_extract_hrirs.md:5 asks for exactly that: nearest
+ * measurement per speaker, the four HRIRs LSL / LSR / RSL / RSR handed to the engine).  ohs_*_set_speakers is that
+ * connection: two ohs_sofa_get_hrtf_irs, each response resampled to `fs` (fs <= 0, or the file's own rate: untouched),
+ * left speaker -> (OHS_PATH_LSL, OHS_PATH_LSR), right speaker -> (OHS_PATH_RSL, OHS_PATH_RSR), and set_ir ONLY for the
+ * paths whose response differs from what the previous ohs_*_set_speakers call on this handle loaded (a set_ir from
+ * anywhere else makes that path count as changed) -- with nearest-neighbour lookup a small move of a speaker usually
+ * changes nothing, and a path that is not re-loaded keeps its history and overlap (convolution.rs:135-138 resets them).
+ * Angles are the PLUGIN's: degrees, azimuth positive to the RIGHT (src/ui/speaker_visualizer.rs:51-54; defaults
+ * az_l = -30, az_r = +30), elevation up; the SOFA query uses the AES69 azimuth -az.  *changed_mask (may be NULL): bit p
+ * set when path p was re-loaded.  Not for the audio thread: a set_ir allocates and waits for the device. */
+/* the four responses [Lsl, Lsr, Rsl, Rsr] ohs_*_set_speakers would load (no device needed): lens[p] = their lengths,
+ * out[p] (may be NULL, as may out) receives at most `capacity` samples of response p */
+int  ohs_sofa_speaker_irs(const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r, float radius_m, float fs,
+                          float *const out[4], size_t capacity, size_t lens[4]);
+int  ohs_engine_set_speakers(ohs_engine *e, const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r,
+                             float radius_m, float fs, unsigned *changed_mask);
+
 /* ---- Plugin::process DSP chain  (src/lib.rs:1169-1207) ----------------------- */
 /* In place on left/right: bypass => untouched; [eq_enable => EQ in place] ->
  * convolution -> every sample *= gain.  One H2D + one D2H per call; the caller
@@ -259,6 +297,9 @@ int  ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch 
 void ohs_batch_destroy(ohs_batch *b);
 /* set_ir semantics of convolution.rs:111-139 applied to every stream. `ir` is a HOST pointer. */
 int  ohs_batch_set_ir(ohs_batch *b, int path, const float *ir, size_t len);
+/* speaker angles -> the four shared impulse responses, see ohs_engine_set_speakers */
+int  ohs_batch_set_speakers(ohs_batch *b, const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r,
+                            float radius_m, float fs, unsigned *changed_mask);
 int  ohs_batch_set_eq_band_coeffs(ohs_batch *b, size_t band, const float coeffs[5], int enabled);
 /* convenience (coefficients by ohs_biquad_coeffs: not a parity path, see there) */
 int  ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_type, float fc,
@@ -336,6 +377,9 @@ int  ohs_node_batch_set_tables(ohs_node_batch *nb, const float *const irs[4], co
                                const float *eq_coeffs, const int *eq_enabled);
 /* one path in mid-stream (one broadcast of that impulse response) */
 int  ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t len);
+/* speaker angles -> the four shared impulse responses (ohs_engine_set_speakers), one broadcast per path that changed */
+int  ohs_node_batch_set_speakers(ohs_node_batch *nb, const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r,
+                                 float radius_m, float fs, unsigned *changed_mask);
 /* host-side settings, applied to every device's handle (no device traffic: kernel arguments) */
 int  ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const float coeffs[5], int enabled);
 int  ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable);

@@ -6,13 +6,13 @@ kernels behind the C ABI in include/ohs_hip.h.  This package is the host-side
 mirror of the reference's Rust interface plus the many-stream batch mode; it
 contains no CPU compute path.
 """
-from .dsp import (BLOCK_SIZE, FFT_SIZE, NUM_EQ_BANDS, BandConfig, ConvolutionEngine, ConvolutionPath,
+from .dsp import (BLOCK_SIZE, FFT_SIZE, NUM_EQ_BANDS, BandConfig, BiquadFilter, ConvolutionEngine, ConvolutionPath,
                   FilterType, StereoParametricEQ, biquad_coefficients, process_chain)
 from .batch import BatchProcessor, NodeBatchProcessor
 from .autoeq import BandSetting, apply_bands, parse_autoeq_csv, parse_autoeq_csv_text
 from ._ffi import OhsError
 
-__all__ = ["BLOCK_SIZE", "FFT_SIZE", "NUM_EQ_BANDS", "BandConfig", "ConvolutionEngine",
+__all__ = ["BLOCK_SIZE", "FFT_SIZE", "NUM_EQ_BANDS", "BandConfig", "BiquadFilter", "ConvolutionEngine",
            "ConvolutionPath", "FilterType", "StereoParametricEQ", "biquad_coefficients",
            "process_chain", "BatchProcessor", "NodeBatchProcessor", "OhsError", "BandSetting", "apply_bands",
            "parse_autoeq_csv", "parse_autoeq_csv_text"]

@@ -52,6 +52,14 @@ PROTOTYPES = {
     "ohs_engine_silent_frames": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "ohs_engine_debug_rt_stamps": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "ohs_biquad_coeffs": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp]),
+    "ohs_biquad_create": (C.c_int, [C.c_int, C.c_float, vpp]),
+    "ohs_biquad_clone": (C.c_int, [vp, vpp]),
+    "ohs_biquad_destroy": (None, [vp]),
+    "ohs_biquad_reset_state": (C.c_int, [vp]),
+    "ohs_biquad_set_enabled": (C.c_int, [vp, C.c_int]),
+    "ohs_biquad_update_coeffs": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "ohs_biquad_set_coeffs": (C.c_int, [vp, fp]),
+    "ohs_biquad_process": (C.c_int, [vp, vp, C.c_size_t]),
     "ohs_eq_create": (C.c_int, [C.c_int, C.c_size_t, C.c_float, vpp]),
     "ohs_eq_destroy": (None, [vp]),
     "ohs_eq_update_band": (C.c_int, [vp, C.c_size_t, C.c_float, C.c_int, C.c_float, C.c_float,
@@ -85,6 +93,11 @@ PROTOTYPES = {
     "ohs_sofa_get_hrtf_irs": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, fp, fp, C.c_size_t, fp, fp]),
     "ohs_sofa_resample_ir": (C.c_int, [fp, C.c_size_t, C.c_float, C.c_float, fp, C.c_size_t,
                                        C.POINTER(C.c_size_t)]),
+    "ohs_sofa_speaker_irs": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.POINTER(fp), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ohs_engine_set_speakers": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint)]),
+    "ohs_batch_set_speakers": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint)]),
+    "ohs_node_batch_set_speakers": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint)]),
     "ohs_chain_process": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, C.c_size_t]),
     "ohs_batch_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, vpp]),
     "ohs_batch_destroy": (None, [vp]),

@@ -30,6 +30,14 @@ class BatchProcessor:
         ir = np.ascontiguousarray(ir_data, dtype=np.float32).ravel()
         check(lib().ohs_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp), ir.size))
 
+    def set_speakers(self, sofa, az_l: float = -30.0, el_l: float = 0.0, az_r: float = 30.0, el_r: float = 0.0,
+                     radius_m: float = 1.0, fs: float = 0.0) -> int:
+        """speaker angles (the plugin's: degrees, azimuth positive to the right) -> the four shared impulse responses;
+        -> bit mask of the paths that were re-loaded (ohs_batch_set_speakers)"""
+        m = C.c_uint()
+        check(lib().ohs_batch_set_speakers(self._h, sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, C.byref(m)))
+        return int(m.value)
+
     def update_band_coeffs(self, band_idx: int, sample_rate: float, config: BandConfig) -> None:
         check(lib().ohs_batch_update_eq_band(self._h, int(band_idx), sample_rate,
                                              int(config.filter_type), config.center_freq, config.q,
@@ -202,6 +210,14 @@ class NodeBatchProcessor:
     def set_ir(self, path, ir_data) -> None:
         ir = np.ascontiguousarray(ir_data, dtype=np.float32).ravel()
         check(lib().ohs_node_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp) if ir.size else None, ir.size))
+
+    def set_speakers(self, sofa, az_l: float = -30.0, el_l: float = 0.0, az_r: float = 30.0, el_r: float = 0.0,
+                     radius_m: float = 1.0, fs: float = 0.0) -> int:
+        """speaker angles -> the four shared impulse responses, one broadcast per path that changed
+        (ohs_node_batch_set_speakers); -> bit mask of the paths that were re-loaded"""
+        m = C.c_uint()
+        check(lib().ohs_node_batch_set_speakers(self._h, sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, C.byref(m)))
+        return int(m.value)
 
     def set_band_coeffs(self, band_idx: int, coeffs, enabled: bool) -> None:
         c = np.ascontiguousarray(coeffs, dtype=np.float32).ravel()

@@ -50,6 +50,7 @@ def _units():
         ("sofa_conditioning.cpp", ["-x", "hip"]),   # host-only C++ (libmysofa-style loudness / interpolation)
         ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
         ("node_batch.cpp", ["-x", "hip"]),      # host-only C++ (batch mode over the GPUs of a node; RCCL by dlopen)
+        ("speakers.cpp", ["-x", "hip"]),        # host-only C++ (speaker angles -> four HRIRs off a SOFA handle)
         # host-only C++ (RBJ coefficient formulas + the musl restatement of sinf / cosf / powf: every operation rounds
         # by itself)
         ("biquad_coeffs.cpp", ["-x", "hip", "-ffp-contract=off"]),

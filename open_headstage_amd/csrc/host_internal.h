@@ -4,8 +4,11 @@
 
 #include <stddef.h>
 
+#include <vector>
+
 extern "C" void ohs_internal_set_error(const char *msg);     // ohs_api.hip: feeds ohs_last_error()
 struct ohs_batch;
+struct ohs_sofa;
 // ohs_api.hip: ohs_batch_set_ir with the impulse response already in memory of the batch's device
 extern "C" int ohs_internal_batch_set_ir_device(ohs_batch *b, int path, const float *d_ir, size_t len);
 
@@ -14,5 +17,10 @@ namespace ohs_host {
 // biquad 0.4.2 Coefficients::<f32>::from_params restated; out = {b0, b1, b2, a1, a2} / a0.
 // Returns an OHS_* status (OHS_ERR_OUTSIDE_NYQUIST, OHS_ERR_NEGATIVE_Q, OHS_ERR_INVALID_ARG).
 int rbj(int type, float fs, float fc, float q, float gain_db, float out[5]);
+
+// speakers.cpp: the four impulse responses [Lsl, Lsr, Rsl, Rsr] of two virtual speakers at the plugin's angles
+// (degrees, azimuth positive to the right), optionally resampled to fs
+int speaker_irs(const struct ::ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r, float radius_m, float fs,
+                std::vector<float> out[4]);
 
 }  // namespace ohs_host

@@ -147,6 +147,9 @@ struct ohs_node_batch {
     std::vector<float *> d_tab;         // broadcast buffer per device
     size_t tab_cap = 0;                 // floats
     std::vector<std::unique_ptr<DeviceWorker>> worker;
+    // ohs_node_batch_set_speakers: what it last loaded into each path (any other set_ir / set_tables forgets it)
+    std::vector<float> spk_ir[4];
+    bool spk_set[4] = {false, false, false, false};
 };
 
 namespace {
@@ -339,6 +342,7 @@ int ohs_node_batch_set_tables(ohs_node_batch *nb, const float *const irs[4], con
         std::memcpy(pack.data() + off[4] + 6 * i, eq_coeffs + 5 * i, 5 * sizeof(float));
         pack[off[4] + 6 * i + 5] = eq_enabled[i] ? 1.0f : 0.0f;
     }
+    for (int p = 0; p < 4; ++p) nb->spk_set[p] = false;
     int rc = broadcast_from_host(nb, pack.data(), pack.size());
     if (rc) return rc;
     std::vector<float> eq_back(eq_floats);
@@ -368,11 +372,32 @@ int ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t 
     if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     DeviceRestore restore;
+    nb->spk_set[path] = false;
     int rc = broadcast_from_host(nb, ir, len);
     if (rc) return rc;
     for (int i = 0; i < nb->n; ++i) {
         rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], path, nb->d_tab[(size_t)i], len);
         if (rc) return rc;
+    }
+    return OHS_OK;
+}
+
+// speaker angles -> four impulse responses (speakers.cpp), one broadcast per path whose response changed
+int ohs_node_batch_set_speakers(ohs_node_batch *nb, const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r,
+                                float radius_m, float fs, unsigned *changed_mask)
+{
+    if (changed_mask) *changed_mask = 0;
+    if (!nb || !sofa) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    std::vector<float> irs[4];
+    int rc = ohs_host::speaker_irs(sofa, az_l, el_l, az_r, el_r, radius_m, fs, irs);
+    if (rc) return rc;
+    for (int p = 0; p < 4; ++p) {
+        if (nb->spk_set[p] && nb->spk_ir[p] == irs[p]) continue;
+        rc = ohs_node_batch_set_ir(nb, p, irs[p].data(), irs[p].size());
+        if (rc) return rc;
+        nb->spk_ir[p].swap(irs[p]);
+        nb->spk_set[p] = true;
+        if (changed_mask) *changed_mask |= 1u << p;
     }
     return OHS_OK;
 }

@@ -188,6 +188,10 @@ struct ConvState {
     bool lazy_ok = false, tails_lazy = false;
     float2 *d_merged = nullptr, *d_merged_alt = nullptr;    // [S][8][64]
     float *d_last_in = nullptr;                             // [S][2][512]
+    // ohs_*_set_speakers: what it last loaded into each path (a set_ir from anywhere else forgets it), so that a
+    // change of the speaker angles re-loads only the paths whose impulse response really changed
+    std::vector<float> spk_ir[4];
+    bool spk_set[4] = {false, false, false, false};
 };
 
 void conv_free(ConvState &c)
@@ -337,6 +341,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     hipFree(c.d_H[path]);
     c.d_H[path] = nH;
     c.P[path] = P;
+    c.spk_set[path] = false;
     c.cd_valid = false;
     c.cdm_valid = false;
     c.since[path] = 0;      // :135-137 that path's history is "all zero" again
@@ -807,6 +812,15 @@ struct ohs_eq {
     unsigned *h_done = nullptr, *dm_done = nullptr, *d_counter = nullptr;   // completion word (pinned) + its workgroup counter
     unsigned call_seq = 0;
     size_t pin_cap = 0;
+};
+
+struct ohs_biquad {          // BiquadFilter (parametric_eq.rs:46-123): one DF2T section, one (mono) chain
+    int device = 0;
+    DeviceCtx *ctx = nullptr;
+    hipStream_t st = nullptr;
+    EqState eq;                 // one band, one chain
+    float *d_buf = nullptr;
+    size_t cap = 0;
 };
 
 struct ohs_batch {
@@ -1709,6 +1723,158 @@ int ohs_eq_frequency_response(const ohs_eq *q, float fs, const float *freqs, siz
     { DeviceWideSection dws; hipFree(d); }
     if (e != hipSuccess) return fail(OHS_ERR_HIP, hipGetErrorString(e));
     return OHS_OK;
+}
+
+// ---- BiquadFilter as a type of its own (parametric_eq.rs:46-123) -------------------------------
+int ohs_biquad_create(int device, float initial_sample_rate, ohs_biquad **out)
+{
+    if (!out) return fail(OHS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    DeviceCtx *ctx = nullptr;
+    int rc = get_ctx(device, &ctx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    ohs_biquad *f = new (std::nothrow) ohs_biquad();
+    if (!f) return fail(OHS_ERR_ALLOC, "out of host memory");
+    f->device = device; f->ctx = ctx;
+    if (hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) != hipSuccess) {
+        delete f;
+        return fail(OHS_ERR_HIP, "hipStreamCreate failed");
+    }
+    rc = eq_init(f->eq, 1, 1, initial_sample_rate, f->st);        // PeakingEQ 0 dB @ 20 Hz Q 0.707, disabled (:63-76)
+    if (rc == OHS_OK && hipStreamSynchronize(f->st) != hipSuccess) rc = fail(OHS_ERR_HIP, "sync failed");
+    if (rc) { ohs_biquad_destroy(f); return rc; }
+    *out = f;
+    return OHS_OK;
+}
+
+void ohs_biquad_destroy(ohs_biquad *f)
+{
+    if (!f) return;
+    hipSetDevice(f->device);
+    DeviceWideSection dws;
+    if (f->st) hipStreamSynchronize(f->st);
+    if (f->eq.d_state) hipFree(f->eq.d_state);
+    if (f->d_buf) hipFree(f->d_buf);
+    if (f->st) hipStreamDestroy(f->st);
+    delete f;
+}
+
+int ohs_biquad_clone(const ohs_biquad *src, ohs_biquad **out)       // impl Clone :52-60: coefficients, state, enabled
+{
+    if (!src || !out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    ohs_biquad *f = nullptr;
+    int rc = ohs_biquad_create(src->device, 48000.0f, &f);
+    if (rc) return rc;
+    f->eq.coeffs = src->eq.coeffs; f->eq.en = src->eq.en;
+    f->eq.exact_specials = src->eq.exact_specials; f->eq.fp_mode = src->eq.fp_mode;
+    hipStreamSynchronize(src->st);
+    if (hipMemcpyAsync(f->eq.d_state, src->eq.d_state, (size_t)kEqStateSlots * 2 * sizeof(float), hipMemcpyDeviceToDevice,
+                       f->st) != hipSuccess || hipStreamSynchronize(f->st) != hipSuccess) {
+        ohs_biquad_destroy(f);
+        return fail(OHS_ERR_HIP, "state copy failed");
+    }
+    *out = f;
+    return OHS_OK;
+}
+
+int ohs_biquad_reset_state(ohs_biquad *f)
+{
+    if (!f) return fail(OHS_ERR_INVALID_ARG, "filter is NULL");
+    HIP_TRY(hipSetDevice(f->device));
+    int rc = eq_reset(f->eq, f->st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(f->st));
+    return OHS_OK;
+}
+
+int ohs_biquad_set_enabled(ohs_biquad *f, int enabled)
+{
+    if (!f) return fail(OHS_ERR_INVALID_ARG, "filter is NULL");
+    f->eq.en[0] = enabled != 0;
+    return OHS_OK;
+}
+
+int ohs_biquad_update_coeffs(ohs_biquad *f, int filter_type, float sample_rate, float center_freq, float q, float gain_db)
+{
+    if (!f) return fail(OHS_ERR_INVALID_ARG, "filter is NULL");
+    float c[5];
+    int rc = rbj(filter_type, sample_rate, center_freq, q, gain_db, c);
+    if (rc) return rc;
+    std::memcpy(&f->eq.coeffs[0], c, sizeof(c));        // the state is kept (update_coefficients, :112)
+    return OHS_OK;
+}
+
+int ohs_biquad_set_coeffs(ohs_biquad *f, const float coeffs[5])
+{
+    if (!f || !coeffs) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    std::memcpy(&f->eq.coeffs[0], coeffs, 5 * sizeof(float));
+    return OHS_OK;
+}
+
+int ohs_biquad_process(ohs_biquad *f, float *samples, size_t n)
+{
+    if (!f) return fail(OHS_ERR_INVALID_ARG, "filter is NULL");
+    if (n == 0) return OHS_OK;
+    if (!samples) return fail(OHS_ERR_INVALID_ARG, "samples is NULL");
+    if (!f->eq.en[0]) return OHS_OK;                    // disabled: the input sample, bit for bit (:118-120)
+    HIP_TRY(hipSetDevice(f->device));
+    if (n > f->cap) {
+        DeviceWideSection dws;
+        size_t ncap = f->cap ? f->cap : 4 * BS;
+        while (ncap < n) ncap *= 2;
+        if (f->d_buf) hipFree(f->d_buf);
+        f->d_buf = nullptr; f->cap = 0;
+        HIP_TRY(hipMalloc(&f->d_buf, ncap * sizeof(float)));
+        f->cap = ncap;
+    }
+    HIP_TRY(hipMemcpyAsync(f->d_buf, samples, n * sizeof(float), hipMemcpyHostToDevice, f->st));
+    int rc = eq_launch(f->eq, f->d_buf, f->d_buf, 0, 0, (long long)n, f->st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(samples, f->d_buf, n * sizeof(float), hipMemcpyDeviceToHost, f->st));
+    HIP_TRY(hipStreamSynchronize(f->st));
+    return OHS_OK;
+}
+
+// ---- speaker angles -> four set_ir (the wiring the reference leaves open; speakers.cpp) ---------
+}  // extern "C"
+namespace {
+template <class SetIr>
+int set_speakers_impl(ConvState &c, const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r, float radius_m,
+                      float fs, unsigned *changed_mask, SetIr set_ir)
+{
+    if (changed_mask) *changed_mask = 0;
+    if (!sofa) return fail(OHS_ERR_INVALID_ARG, "sofa is NULL");
+    std::vector<float> irs[4];
+    int rc = ohs_host::speaker_irs(sofa, az_l, el_l, az_r, el_r, radius_m, fs, irs);
+    if (rc) return rc;
+    for (int p = 0; p < 4; ++p) {
+        if (c.spk_set[p] && c.spk_ir[p] == irs[p]) continue;        // same nearest measurement as before: nothing to do
+        rc = set_ir(p, irs[p].data(), irs[p].size());
+        if (rc) return rc;
+        c.spk_ir[p].swap(irs[p]);
+        c.spk_set[p] = true;
+        if (changed_mask) *changed_mask |= 1u << p;
+    }
+    return OHS_OK;
+}
+}  // namespace
+extern "C" {
+
+int ohs_engine_set_speakers(ohs_engine *e, const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r,
+                            float radius_m, float fs, unsigned *changed_mask)
+{
+    if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
+    return set_speakers_impl(e->conv, sofa, az_l, el_l, az_r, el_r, radius_m, fs, changed_mask,
+                             [&](int p, const float *ir, size_t n) { return ohs_engine_set_ir(e, p, ir, n); });
+}
+
+int ohs_batch_set_speakers(ohs_batch *b, const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r,
+                           float radius_m, float fs, unsigned *changed_mask)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    return set_speakers_impl(b->conv, sofa, az_l, el_l, az_r, el_r, radius_m, fs, changed_mask,
+                             [&](int p, const float *ir, size_t n) { return ohs_batch_set_ir(b, p, ir, n); });
 }
 
 // ---- chain -----------------------------------------------------------------------------

@@ -105,6 +105,15 @@ class ConvolutionEngine:
         ir = _in(ir_data)
         check(lib().ohs_engine_set_ir(self._h, int(path), _ptr(ir), ir.size))
 
+    def set_speakers(self, sofa, az_l: float = -30.0, el_l: float = 0.0, az_r: float = 30.0, el_r: float = 0.0,
+                     radius_m: float = 1.0, fs: float = 0.0) -> int:
+        """The plugin's speaker angles (CLAP az_l / el_l / az_r / el_r, degrees, azimuth positive to the right;
+        src/lib.rs:120-128) -> two get_hrtf_irs -> set_ir of the paths whose response changed
+        (ohs_engine_set_speakers).  Returns the bit mask of the paths that were re-loaded."""
+        m = C.c_uint()
+        check(lib().ohs_engine_set_speakers(self._h, sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, C.byref(m)))
+        return int(m.value)
+
     def num_partitions(self, path) -> int:
         n = C.c_size_t()
         check(lib().ohs_engine_num_partitions(self._h, int(path), C.byref(n)))
@@ -154,6 +163,61 @@ def biquad_coefficients(filter_type, sample_rate: float, center_freq: float, q: 
     out = np.zeros(5, np.float32)
     check(lib().ohs_biquad_coeffs(int(filter_type), sample_rate, center_freq, q, gain_db, _ptr(out)))
     return out
+
+
+class BiquadFilter:
+    """`BiquadFilter` (parametric_eq.rs:46-123) over ohs_biquad_*: one DF2T section, disabled until set_enabled(True)."""
+
+    def __init__(self, initial_sample_rate: float, device: int = 0, _handle=None):
+        self.device = device
+        if _handle is None:
+            h = C.c_void_p()
+            check(lib().ohs_biquad_create(device, initial_sample_rate, C.byref(h)))
+            _handle = h
+        self._h = _handle
+
+    @classmethod
+    def new(cls, initial_sample_rate: float, device: int = 0) -> "BiquadFilter":
+        return cls(initial_sample_rate, device)
+
+    def clone(self) -> "BiquadFilter":
+        h = C.c_void_p()
+        check(lib().ohs_biquad_clone(self._h, C.byref(h)))
+        return BiquadFilter(0.0, self.device, h)
+
+    def reset_state(self) -> None:
+        check(lib().ohs_biquad_reset_state(self._h))
+
+    def set_enabled(self, enabled: bool) -> None:
+        check(lib().ohs_biquad_set_enabled(self._h, int(bool(enabled))))
+
+    def update_coeffs(self, filter_type, sample_rate: float, center_freq: float, q: float, gain_db: float) -> None:
+        check(lib().ohs_biquad_update_coeffs(self._h, int(filter_type), sample_rate, center_freq, q, gain_db))
+
+    def set_coeffs(self, coeffs) -> None:
+        c = _in(coeffs)
+        if c.size != 5:
+            raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
+        check(lib().ohs_biquad_set_coeffs(self._h, _ptr(c)))
+
+    def process_sample(self, input_sample: float) -> float:
+        a = np.array([input_sample], np.float32)
+        check(lib().ohs_biquad_process(self._h, _addr(a), 1))
+        return float(a[0])
+
+    def process(self, samples: np.ndarray) -> None:
+        """n consecutive process_sample calls, in place"""
+        if not (isinstance(samples, np.ndarray) and samples.dtype == np.float32 and samples.flags.c_contiguous and samples.ndim == 1):
+            raise TypeError("samples must be a contiguous 1-D float32 ndarray")
+        check(lib().ohs_biquad_process(self._h, _addr(samples), samples.size))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().ohs_biquad_destroy(h)
+            except Exception:
+                pass
 
 
 class StereoParametricEQ:

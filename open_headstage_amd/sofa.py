@@ -124,6 +124,18 @@ def speaker_hrirs(sofa: MySofa, az_left: float = 30.0, el_left: float = 0.0, az_
     return [lsl, lsr, rsl, rsr]
 
 
+def speaker_irs_plugin_angles(sofa: MySofa, az_l: float = -30.0, el_l: float = 0.0, az_r: float = 30.0, el_r: float = 0.0,
+                              radius_m: float = 1.0, fs: float = 0.0):
+    """[lsl, lsr, rsl, rsr] as ohs_*_set_speakers computes them inside the library (ohs_sofa_speaker_irs): the PLUGIN's
+    angles (degrees, azimuth positive to the right -- lib.rs:120-128), resampled to fs when fs > 0."""
+    lens = (C.c_size_t * 4)()
+    check(lib().ohs_sofa_speaker_irs(sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, None, 0, lens))
+    outs = [np.zeros(int(n), np.float32) for n in lens]
+    ptrs = (fp * 4)(*[o.ctypes.data_as(fp) for o in outs])
+    check(lib().ohs_sofa_speaker_irs(sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, ptrs, max(int(n) for n in lens), lens))
+    return outs
+
+
 def load_into(target, irs) -> None:
     """get_hrtf_irs -> set_ir wiring: target is a ConvolutionEngine or a BatchProcessor."""
     for p, h in zip((ConvolutionPath.Lsl, ConvolutionPath.Lsr, ConvolutionPath.Rsl, ConvolutionPath.Rsr), irs):

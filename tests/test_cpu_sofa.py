@@ -209,3 +209,64 @@ def test_open_like_mysofa_resamples_everything_to_the_target_rate():
     assert all(h.size == 218 for h in irs)
     with pytest.raises(Exception):
         sofa.MySofa(SOFA, 64)                                               # unknown flag
+
+
+# ---- a SOFA file written from scratch (tests/util.py) + the speaker wiring's impulse responses (no device needed) -----
+def test_minimal_sofa_written_from_scratch_reads_back(tmp_path):
+    """The reader against an independent WRITER: superblock v2, version-2 object headers, compact links, contiguous f64
+    datasets -- spherical and cartesian SourcePosition, Data.Delay as [1][R] and [M][R]."""
+    from open_headstage_amd.sofa import MySofa
+    from tests.util import write_minimal_sofa
+    rng = np.random.default_rng(5)
+    M, R, N = 14, 2, 37
+    ir = rng.standard_normal((M, R, N))
+    pos = np.stack([rng.uniform(0, 360, M), rng.uniform(-40, 80, M), rng.uniform(0.5, 2.0, M)], 1)
+    for delay in (None, rng.uniform(0, 5, (1, R)), rng.uniform(0, 5, (M, R))):
+        s = MySofa(write_minimal_sofa(str(tmp_path / "a.sofa"), ir, pos, 44100.0, delay=delay))
+        assert (s.num_measurements, s.num_receivers, s.filter_length, s.source_samplerate) == (M, R, N, 44100.0)
+        for m in range(M):
+            assert np.array_equal(s.position(m), pos[m].astype(np.float32))
+            for r in range(R):
+                assert np.array_equal(s.ir(m, r), ir[m, r].astype(np.float32))
+    a, e = np.radians(pos[:, 0]), np.radians(pos[:, 1])
+    xyz = pos[:, 2:3] * np.stack([np.cos(e) * np.cos(a), np.cos(e) * np.sin(a), np.sin(e)], 1)
+    s = MySofa(write_minimal_sofa(str(tmp_path / "c.sofa"), ir, xyz, 48000.0, position_type="cartesian"))
+    for m in range(M):
+        assert np.allclose(s.position(m), pos[m], atol=1e-3)
+
+
+def _speaker_cases():
+    return [(-30.0, 0.0, 30.0, 0.0, 48000.0), (-30.0, 0.0, 30.0, 0.0, 0.0), (-75.0, 20.0, 10.0, -15.0, 48000.0),
+            (12.5, 44.0, 88.0, -44.0, 44100.0), (-90.0, 0.0, 90.0, 0.0, 96000.0)]
+
+
+def _check_speaker_irs(s):
+    from open_headstage_amd import sofa
+    for az_l, el_l, az_r, el_r, fs in _speaker_cases():
+        got = sofa.speaker_irs_plugin_angles(s, az_l, el_l, az_r, el_r, 1.0, fs)
+        want = sofa.speaker_hrirs(s, -az_l, el_l, -az_r, el_r, 1.0, fs if fs > 0 else None)      # AES69: positive = left
+        assert len(got) == 4
+        for p in range(4):
+            assert got[p].dtype == np.float32 and np.array_equal(got[p], want[p]), (az_l, az_r, fs, p)
+
+
+def test_speaker_irs_of_the_c_abi_equal_the_python_wiring_on_a_synthetic_file(tmp_path):
+    """ohs_sofa_speaker_irs (what ohs_*_set_speakers loads) = two get_hrtf_irs + resampling, left speaker -> (Lsl, Lsr),
+    right -> (Rsl, Rsr); the plugin's azimuth is positive to the RIGHT (speaker_visualizer.rs:51-54), AES69's to the left."""
+    from open_headstage_amd.sofa import MySofa
+    from tests.util import write_minimal_sofa
+    rng = np.random.default_rng(8)
+    az, el = np.meshgrid(np.arange(0.0, 360.0, 15.0), np.array([-30.0, 0.0, 30.0]))
+    pos = np.stack([az.ravel(), el.ravel(), np.ones(az.size)], 1)
+    ir = rng.standard_normal((len(pos), 2, 64))
+    _check_speaker_irs(MySofa(write_minimal_sofa(str(tmp_path / "g.sofa"), ir, pos, 44100.0)))
+
+
+@need_asset
+def test_speaker_irs_of_the_c_abi_equal_the_python_wiring_on_cipic_subject_003():
+    from open_headstage_amd import sofa
+    s = sofa.MySofa(SOFA)
+    _check_speaker_irs(s)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cipic003_pm30.npz"))
+    assert np.array_equal(np.stack(sofa.speaker_irs_plugin_angles(s, fs=48000.0)), g["irs_48000"])      # the plugin's default angles
+    assert np.array_equal(np.stack(sofa.speaker_irs_plugin_angles(s, fs=0.0)), g["irs_44100"])
