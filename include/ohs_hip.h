@@ -102,13 +102,19 @@ int  ohs_engine_num_partitions(const ohs_engine *e, int path, size_t *out);
  * which serves every other call.  The kernel leaves the GPU when real-time mode is switched off, on set_ir /
  * clone / destroy / any call it cannot serve (it is restarted by the next call it can), and by itself after
  * ~2 s without a call.  It holds one CU while it lives: a device runs at most num_CUs / 4 of them
- * (OHS_RT_MAX_RESIDENT), further engines in real-time mode are served launch per call until a slot frees up.
+ * (ohs_rt_configure), further engines in real-time mode are served launch per call until a slot frees up.
  * Whenever ANY handle of this library on the same device is about to free device memory or wait for the whole
  * device (set_ir, destroy, reset, buffer growth), it asks the device's resident kernels to leave first and holds new
  * ones off until it is done -- a resident kernel would otherwise stall such a wait for as long as it lives; a call
  * arriving meanwhile is served launch per call, the next one restarts the kernel.
  * Same threading rule as every handle: one thread at a time. */
 int  ohs_engine_set_realtime(ohs_engine *e, int enable);
+/* The two deployment options of the resident kernels, process-wide, for kernels started afterwards:
+ * max_resident_per_device (< 0: the default, a quarter of the device's CUs; 0: none -- every engine in real-time mode
+ * is served launch per call) and idle_polls, the doorbell polls (~0.6 us each) after which an idle kernel leaves
+ * (0: keep the current value; default 3 000 000 ~ 2 s).  The library reads NO environment variable: these are the only
+ * run-time settings that are not per handle. */
+int  ohs_rt_configure(int max_resident_per_device, unsigned long long idle_polls);
 /* Delay the FIFO adapter of process_block adds for a constant host block size n (convolution.rs:163-181):
  * 0 when n is a multiple of 512; otherwise the frames answered with silence before the output FIFO can
  * serve every call (e.g. 256 for n = 256).  What a plugin host reports as its latency for compensation. */
@@ -309,7 +315,10 @@ int  ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable);
 int  ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable);    /* see ohs_eq_set_exact_specials */
 int  ohs_batch_set_flush_denormals(ohs_batch *b, int mode);         /* see ohs_engine_set_flush_denormals (EQ and convolution) */
 int  ohs_batch_set_gain(ohs_batch *b, float gain);
-/* zero every stream's EQ state, history and overlap (IRs and EQ table kept) */
+/* zero every stream's EQ state, history and overlap (IRs and EQ table kept).  Also the way back from a failed handle:
+ * a HIP failure in the middle of a processing call leaves the per-stream state advanced for some time chunks only, so
+ * the call joins its internal stream, returns OHS_ERR_HIP, and every later processing call on the handle returns
+ * OHS_ERR_HIP as well until ohs_batch_reset. */
 int  ohs_batch_reset(ohs_batch *b);
 /* Process n_blocks * 512 frames of every stream: [EQ] -> convolution -> gain.
  * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).

@@ -9,8 +9,12 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# OHS_LIB: load an experiment variant built by `OHS_BUILD_TAG=... python -m open_headstage_amd.build`
-LIB_PATH = os.environ.get("OHS_LIB") or os.path.join(HERE, "libohs_hip.so")
+EXP_LIB_PATH = os.path.join(HERE, "libohs_hip_exp.so")
+# The product library reads no environment variable.  This LOADER does, for the lab: OHS_LIB=<path> (or OHS_LIB=exp for
+# libohs_hip_exp.so) makes the whole package run on an experiments build (`python -m open_headstage_amd.build
+# --experiments`, or an OHS_BUILD_TAG / OHS_EXTRA_DEFS variant of it) -- what tools/ and LABNOTES.md's A/B runs use.
+_env_lib = os.environ.get("OHS_LIB")
+LIB_PATH = EXP_LIB_PATH if _env_lib == "exp" else (_env_lib or os.path.join(HERE, "libohs_hip.so"))
 
 OHS_OK = 0
 OHS_ERR_INVALID_ARG = 1
@@ -48,6 +52,7 @@ PROTOTYPES = {
     "ohs_engine_process_block": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t]),     # audio pointers as plain addresses (hot call)
     "ohs_engine_num_partitions": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
     "ohs_engine_set_realtime": (C.c_int, [vp, C.c_int]),
+    "ohs_rt_configure": (C.c_int, [C.c_int, C.c_ulonglong]),
     "ohs_engine_latency_samples": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ohs_engine_silent_frames": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "ohs_engine_debug_rt_stamps": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
@@ -146,34 +151,63 @@ class OhsError(RuntimeError):
         super().__init__(f"{lib().ohs_status_string(status).decode()} ({status}): {detail}")
 
 
+# experiments build only (not in include/ohs_hip.h, not exported by the product library)
+DEBUG_PROTOTYPES = {
+    "ohs_debug_set_tuning": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "ohs_debug_inject_batch_failure": (C.c_int, [C.c_int]),
+}
+
 _lib = None
+_exp = None
+
+
+def _load(path: str, extra=None) -> C.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -m open_headstage_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and the
+    # dynamic loader de-duplicates by SONAME only when torch's copy is loaded FIRST (torch's
+    # libs ask for "libamdhip64.so", ours for "libamdhip64.so.7").  Two runtimes in one
+    # process leave the second one without a device.  torch is plumbing here (device
+    # tensors, streams, torch.distributed); without it the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(path)
+    for name, (res, args) in {**PROTOTYPES, **(extra or {})}.items():
+        fn = getattr(L, name)     # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return L
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} not found: build it with `python -m open_headstage_amd.build` "
-                "(hipcc, gfx950). There is no CPU fallback.")
-        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and the
-        # dynamic loader de-duplicates by SONAME only when torch's copy is loaded FIRST (torch's
-        # libs ask for "libamdhip64.so", ours for "libamdhip64.so.7").  Two runtimes in one
-        # process leave the second one without a device.  torch is plumbing here (device
-        # tensors, streams, torch.distributed); without it the system ROCm runtime is used.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(L, name)     # AttributeError if the library does not export it
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
 
 
-def check(status: int) -> None:
+def experiments_lib() -> C.CDLL:
+    """libohs_hip_exp.so, loaded BESIDE the product library: a second copy of the code with its own state, whose launch
+    plans ohs_debug_set_tuning can edit.  Handles belong to the library that made them -- pass `library=` to
+    BatchProcessor."""
+    global _exp
+    if _exp is None:
+        _exp = _load(EXP_LIB_PATH, DEBUG_PROTOTYPES)
+    return _exp
+
+
+def set_tuning(key: str, value) -> None:
+    """experiments build: edit one launch-plan constant (csrc/tuning.h) of libohs_hip_exp.so"""
+    L = experiments_lib()
+    rc = L.ohs_debug_set_tuning(key.encode(), str(value).encode())
+    if rc != OHS_OK:
+        raise OhsError(rc, L.ohs_last_error().decode(errors="replace"))
+
+
+def check(status: int, library=None) -> None:
     if status != OHS_OK:
-        raise OhsError(status, lib().ohs_last_error().decode(errors="replace"))
+        raise OhsError(status, (library or lib()).ohs_last_error().decode(errors="replace"))

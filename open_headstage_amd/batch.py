@@ -17,29 +17,39 @@ from .dsp import BLOCK_SIZE, BandConfig
 
 
 class BatchProcessor:
-    def __init__(self, n_streams: int, num_bands: int = 10, device: int = 0):
+    def __init__(self, n_streams: int, num_bands: int = 10, device: int = 0, library=None):
+        """library: the CDLL the handle lives in (default: the product library; _ffi.experiments_lib() for plan
+        overrides through _ffi.set_tuning)"""
         self.n_streams = int(n_streams)
         self.num_bands = int(num_bands)
         self.device = int(device)
+        self._L = library
         h = C.c_void_p()
-        check(lib().ohs_batch_create(self.device, self.n_streams, self.num_bands, C.byref(h)))
+        self._check(self._lib.ohs_batch_create(self.device, self.n_streams, self.num_bands, C.byref(h)))
         self._h = h
+
+    @property
+    def _lib(self):
+        return getattr(self, "_L", None) or lib()
+
+    def _check(self, status: int) -> None:
+        check(status, self._lib)
 
     # -- shared tables -----------------------------------------------------------
     def set_ir(self, path, ir_data) -> None:
         ir = np.ascontiguousarray(ir_data, dtype=np.float32).ravel()
-        check(lib().ohs_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp), ir.size))
+        self._check(self._lib.ohs_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp), ir.size))
 
     def set_speakers(self, sofa, az_l: float = -30.0, el_l: float = 0.0, az_r: float = 30.0, el_r: float = 0.0,
                      radius_m: float = 1.0, fs: float = 0.0) -> int:
         """speaker angles (the plugin's: degrees, azimuth positive to the right) -> the four shared impulse responses;
         -> bit mask of the paths that were re-loaded (ohs_batch_set_speakers)"""
         m = C.c_uint()
-        check(lib().ohs_batch_set_speakers(self._h, sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, C.byref(m)))
+        self._check(self._lib.ohs_batch_set_speakers(self._h, sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, C.byref(m)))
         return int(m.value)
 
     def update_band_coeffs(self, band_idx: int, sample_rate: float, config: BandConfig) -> None:
-        check(lib().ohs_batch_update_eq_band(self._h, int(band_idx), sample_rate,
+        self._check(self._lib.ohs_batch_update_eq_band(self._h, int(band_idx), sample_rate,
                                              int(config.filter_type), config.center_freq, config.q,
                                              config.gain_db, int(bool(config.enabled))))
 
@@ -47,30 +57,30 @@ class BatchProcessor:
         c = np.ascontiguousarray(coeffs, dtype=np.float32).ravel()
         if c.size != 5:
             raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
-        check(lib().ohs_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp),
+        self._check(self._lib.ohs_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp),
                                                  int(bool(enabled))))
 
     def set_eq_enabled(self, eq_enable: bool) -> None:
-        check(lib().ohs_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
+        self._check(self._lib.ohs_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
 
     def set_eq_exact_specials(self, enable: bool) -> None:
-        check(lib().ohs_batch_set_eq_exact_specials(self._h, int(bool(enable))))
+        self._check(self._lib.ohs_batch_set_eq_exact_specials(self._h, int(bool(enable))))
 
     def set_flush_denormals(self, mode: int) -> None:
         """0 = IEEE (default), 1 = FTZ, 2 = FTZ | DAZ for the EQ and the convolution (ohs_batch_set_flush_denormals)"""
-        check(lib().ohs_batch_set_flush_denormals(self._h, int(mode)))
+        self._check(self._lib.ohs_batch_set_flush_denormals(self._h, int(mode)))
 
     def set_gain(self, gain: float) -> None:
-        check(lib().ohs_batch_set_gain(self._h, float(gain)))
+        self._check(self._lib.ohs_batch_set_gain(self._h, float(gain)))
 
     def reset(self) -> None:
-        check(lib().ohs_batch_reset(self._h))
+        self._check(self._lib.ohs_batch_reset(self._h))
 
     # -- processing --------------------------------------------------------------
     def process_ptr(self, d_in: int, d_out: int, n_blocks: int, stream_stride: int,
                     channel_stride: int, hip_stream: int = 0, deferred: bool = False) -> None:
-        fn = lib().ohs_batch_process_deferred if deferred else lib().ohs_batch_process
-        check(fn(self._h, C.c_void_p(d_in), C.c_void_p(d_out), int(n_blocks), int(stream_stride),
+        fn = self._lib.ohs_batch_process_deferred if deferred else self._lib.ohs_batch_process
+        self._check(fn(self._h, C.c_void_p(d_in), C.c_void_p(d_out), int(n_blocks), int(stream_stride),
                  int(channel_stride), C.c_void_p(hip_stream) if hip_stream else None))
 
     def join(self, hip_stream: int | None = None) -> None:
@@ -78,7 +88,7 @@ class BatchProcessor:
         if hip_stream is None:
             import torch
             hip_stream = torch.cuda.current_stream(self.device).cuda_stream
-        check(lib().ohs_batch_join(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+        self._check(self._lib.ohs_batch_join(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def process(self, x, out=None, hip_stream: int | None = None, deferred: bool = False):
         """x, out: torch.float32 CUDA tensors [n_streams, 2, frames], frames % 512 == 0.
@@ -121,38 +131,38 @@ class BatchProcessor:
             if x.is_cuda or out.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or not out.is_contiguous():
                 raise TypeError("x / out must be contiguous float32 HOST tensors")
             pi, po = x.data_ptr(), out.data_ptr()
-        check(lib().ohs_batch_process_host(self._h, C.c_void_p(pi), C.c_void_p(po), frames // BLOCK_SIZE,
+        self._check(self._lib.ohs_batch_process_host(self._h, C.c_void_p(pi), C.c_void_p(po), frames // BLOCK_SIZE,
                                            2 * frames, frames, int(chunk_blocks)))
         return out
 
     def sync(self, hip_stream: int = 0) -> None:
-        check(lib().ohs_batch_sync(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+        self._check(self._lib.ohs_batch_sync(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def set_profiling(self, enable: bool) -> None:
-        check(lib().ohs_batch_set_profiling(self._h, int(bool(enable))))
+        self._check(self._lib.ohs_batch_set_profiling(self._h, int(bool(enable))))
 
     def profile_read(self):
         """(eq_ms, conv_ms, n_calls, eq_launches, conv_launches) since the last read; waits for the events."""
         a, b, n, ne, nc = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
-        check(lib().ohs_batch_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n), C.byref(ne),
+        self._check(self._lib.ohs_batch_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n), C.byref(ne),
                                            C.byref(nc)))
         return a.value, b.value, int(n.value), int(ne.value), int(nc.value)
 
     def kernel_bytes(self, n_blocks: int):
         a, b = C.c_uint64(), C.c_uint64()
-        check(lib().ohs_batch_kernel_bytes(self._h, int(n_blocks), C.byref(a), C.byref(b)))
+        self._check(self._lib.ohs_batch_kernel_bytes(self._h, int(n_blocks), C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     def algorithmic_bytes(self, n_blocks: int) -> int:
         v = C.c_uint64()
-        check(lib().ohs_batch_algorithmic_bytes(self._h, int(n_blocks), C.byref(v)))
+        self._check(self._lib.ohs_batch_algorithmic_bytes(self._h, int(n_blocks), C.byref(v)))
         return int(v.value)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h and getattr(self, "_borrowed", None) is None:
             try:
-                lib().ohs_batch_destroy(h)
+                self._lib.ohs_batch_destroy(h)
             except Exception:
                 pass
 
@@ -247,6 +257,7 @@ class NodeBatchProcessor:
         h = C.c_void_p()
         check(lib().ohs_node_batch_device_batch(self._h, int(slot), C.byref(h)))
         v = BatchProcessor.__new__(BatchProcessor)
+        v._L = None
         v.n_streams, v.num_bands, v.device = cnt, self.num_bands, dev
         v._h = h
         v._borrowed = self         # keeps the owner alive; __del__ must not destroy the handle

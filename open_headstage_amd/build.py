@@ -20,12 +20,23 @@ import shutil
 import subprocess
 import sys
 
+# (TAG / EXPERIMENTS below read sys.argv: `python -m open_headstage_amd.build --experiments`)
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # Experiment variants: OHS_BUILD_TAG=name OHS_EXTRA_DEFS="-DFOO=1 ..." builds libohs_hip_name.so beside the
 # product library (objects under build/name/); OHS_LIB=<path> makes _ffi.py load it.  Not used in production.
+#
+# Two libraries come out of this file:
+#   libohs_hip.so       the PRODUCT: reads no environment variable, no experiment variant compiled in (csrc/experiments.h)
+#   libohs_hip_exp.so   the EXPERIMENTS build (-DOHS_EXPERIMENTS): the same code plus the OHS_* environment knobs, the debug
+#                       entry points (ohs_debug_set_tuning ...) and round 2's EQ kernel; `--experiments`, or
+#                       OHS_BUILD_TAG=exp.  Other tags (OHS_BUILD_TAG=name OHS_EXTRA_DEFS="-DFOO") are variants OF the
+#                       experiments build: every tagged library is compiled with -DOHS_EXPERIMENTS.
 TAG = os.environ.get("OHS_BUILD_TAG", "")
-EXTRA_DEFS = os.environ.get("OHS_EXTRA_DEFS", "").split()
+if "--experiments" in sys.argv and not TAG:
+    TAG = "exp"
+EXPERIMENTS = bool(TAG)
+EXTRA_DEFS = os.environ.get("OHS_EXTRA_DEFS", "").split() + (["-DOHS_EXPERIMENTS=1"] if EXPERIMENTS else [])
 OBJ = os.path.join(HERE, "build", TAG) if TAG else os.path.join(HERE, "build")
 LIB = os.path.join(HERE, f"libohs_hip_{TAG}.so" if TAG else "libohs_hip.so")
 STAMP = os.path.join(HERE, f"libohs_hip_{TAG}.stamp" if TAG else "libohs_hip.stamp")
@@ -42,8 +53,9 @@ def _units():
         # FFT kernels: no SLP vectoriser (see conv_mac_kernels.hip); no implicit FMA contraction -- the fused
         # operations are written out (wave_fft.hpp), so that every kernel inlining them rounds alike
         ("conv_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
-        ("conv_mac_kernels.hip", [f"-DOHS_MAC_TB={os.environ.get('OHS_MAC_TB', '0')}",
-                                  f"-DOHS_MAC_PI={os.environ.get('OHS_MAC_PI', '16')}"]),
+        # (experiments builds only: OHS_MAC_TB / OHS_MAC_PI fix the MAC's register tile)
+        ("conv_mac_kernels.hip", [f"-D{k}={os.environ[k]}" for k in ("OHS_MAC_TB", "OHS_MAC_PI")
+                                  if EXPERIMENTS and k in os.environ]),
         ("eq_kernels.hip", ["-ffp-contract=off"]),
         ("ohs_api.hip", []),
         ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
@@ -51,6 +63,7 @@ def _units():
         ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
         ("node_batch.cpp", ["-x", "hip"]),      # host-only C++ (batch mode over the GPUs of a node; RCCL by dlopen)
         ("speakers.cpp", ["-x", "hip"]),        # host-only C++ (speaker angles -> four HRIRs off a SOFA handle)
+        ("tuning.cpp", ["-x", "hip"]),          # host-only C++ (launch-plan constants; environment knobs in experiments builds)
         # host-only C++ (RBJ coefficient formulas + the musl restatement of sinf / cosf / powf: every operation rounds
         # by itself)
         ("biquad_coeffs.cpp", ["-x", "hip", "-ffp-contract=off"]),
@@ -201,6 +214,21 @@ def _read_obj_hash(obj: str) -> str:
             return f.read().strip()
     except Exception:
         return ""
+
+
+def build_experiments(force: bool = False) -> str:
+    """libohs_hip_exp.so beside the product library (a child process: this module's paths are fixed at import)"""
+    env = dict(os.environ, OHS_BUILD_TAG="exp")
+    env.pop("OHS_EXTRA_DEFS", None)
+    cmd = [sys.executable, "-m", "open_headstage_amd.build"] + (["--force"] if force else [])
+    subprocess.run(cmd, check=True, cwd=os.path.dirname(HERE), env=env, stdout=subprocess.DEVNULL)
+    return os.path.join(HERE, "libohs_hip_exp.so")
+
+
+def experiments_is_current() -> bool:
+    r = subprocess.run([sys.executable, "-c", "import sys; from open_headstage_amd import build as b; sys.exit(0 if b.is_current() else 1)"],
+                       cwd=os.path.dirname(HERE), env=dict(os.environ, OHS_BUILD_TAG="exp"))
+    return r.returncode == 0
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@
 //   * all global traffic is lane-contiguous ([reg][lane] images, 512 B per wave load).
 #include "kernels.h"
 #include "wave_fft.hpp"
-#include "eq_ring_body.hpp"     // the resident kernel runs the chain's EQ; this file is built -ffp-contract=off too
+#include "eq_ring2_body.hpp"    // the resident kernel runs the chain's EQ; this file is built -ffp-contract=off too
 
 #include <atomic>
 
@@ -551,10 +551,22 @@ __device__ __forceinline__ void uniform_copy(T &dst, const T &src_lds)
     __builtin_memcpy(&dst, w, sizeof(T));
 }
 
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p)      // a wave-uniform pointer the compiler can keep in SGPRs
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+// (a function's arguments arrive in VGPRs; the ring body addresses its samples as SGPR base + per-lane offset)
 __device__ __attribute__((noinline)) void rt_eq_call(float *buf, long long stride, long long n, int nb,
                                                      const EqPassTable *tab, float *state)
 {
-    eq_ring_wave(buf, buf, 0, stride, n, 2, nb, *tab, state, 0);
+    float *ubuf = uniform_ptr(buf);
+    const long long ustride = (long long)__builtin_amdgcn_readfirstlane((int)stride);        // (< 2^31: the staging buffer's)
+    const long long un = (long long)__builtin_amdgcn_readfirstlane((int)n);
+    eq_ring2_wave(ubuf, ubuf, 0, ustride, un, 2, __builtin_amdgcn_readfirstlane(nb), *uniform_ptr(tab), uniform_ptr(state), 0);
 }
 
 constexpr unsigned kRtPollBurst = 32;     // pairs of polls per asm statement of the resident kernel's doorbell loop
@@ -879,12 +891,8 @@ __device__ __forceinline__ void p1_spectral_product(const float2 (&z)[16], float
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float2 zz = z[r], m = w[r];
-#ifdef OHS_KO_CD
-        const float2 c = make_float2(0.5f, 0.001f * (float)lane), d = make_float2(0.25f, 0.002f * (float)lane);
-#else
         float2 c, d;        // interleaved in LDS: one ds_read_b128 per register instead of two ds_read_b64
         lds_ld2(reinterpret_cast<const float4 *>(cd) + r * 64 + lane, c, d);
-#endif
         w[r].x = fmaf(m.y, d.y, fmaf(m.x, d.x, fmaf(-zz.y, c.y, zz.x * c.x)));
         w[r].y = fmaf(-m.y, d.x, fmaf(m.x, d.y, fmaf(zz.y, c.x, zz.x * c.y)));
     }
@@ -1103,7 +1111,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     // every level a quarter of the time and all sixteen finish together.
     const int age_rank = wave >> 2;
     int prio_phase = age_rank;
-#if !defined(OHS_P1_BPERMUTE_MIRROR) && !defined(OHS_P1_NATURAL)
+#if !defined(OHS_P1_NATURAL)
     const PairedPlan plan = paired_plan(lane);
 #endif
     for (int t = t_first; t < b1; ++t) {
@@ -1129,11 +1137,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
             v[a + 8] = make_float2(0.0f, 0.0f);
         }
         float2 w[16];
-#if defined(OHS_P1_BPERMUTE_MIRROR)
-        wave_fft_fwd_zpad(v, lds, tab, lane);
-        wave_mirror(v, w, lane);
-        p1_spectral_product(v, w, cd, lane);
-#elif defined(OHS_P1_NATURAL)
+#if defined(OHS_P1_NATURAL)
         wave_fft_fwd_mirror(v, w, lds, tab, lane);
         p1_spectral_product(v, w, cd, lane);
 #else
@@ -1144,31 +1148,19 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
         // block (its own frames: in bounds; the values are never used)
         const int adv = (t + 1 < A.n_blocks) ? kBlock : 0;
         pl += adv; pr += adv;
-#if defined(OHS_P1_BPERMUTE_MIRROR) || defined(OHS_P1_NATURAL)
+#if defined(OHS_P1_NATURAL)
 #define OHS_P1_INV(w) wave_fft_inv(w, lds, tab, lane)
 #else
 #define OHS_P1_INV(w) wave_fft_inv_paired(w, lds, tab, lane, plan)
 #endif
-#ifdef OHS_P1_PREFETCH_EARLY
-#pragma unroll
-        for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
-        OHS_P1_INV(w);
-#else
         OHS_P1_INV(w);
 #pragma unroll
         for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
-#endif
         if (!dry) {
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-#ifdef OHS_KO_STORE
-                if (w[a].x == 123.456f) {       // never true: the stores stay in the code, none is executed
-#endif
                 OHS_P1_ST(&ql[64 * a], (w[a].x + tail[a].x) * A.gain);         // (1/N is in C and D)
                 OHS_P1_ST(&qr[64 * a], (w[a].y + tail[a].y) * A.gain);
-#ifdef OHS_KO_STORE
-                }
-#endif
             }
         }
 #pragma unroll
@@ -1274,7 +1266,8 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1_edges(const ConvP1Arg
     const int e = 1 + (int)(gw % (A.chunks - 1));
     const float *in_l = A.in + (size_t)s * A.in_stream_stride;
     const float *in_r = in_l + A.in_ch_stride;
-    // host: chunks <= n_blocks, and weights other than {1,1,1,1} only with >= 8 blocks per chunk on average: b0 >= 1
+    // host (conv_launch): chunks <= n_blocks, and weights other than {1,1,1,1} only when even a stream whose chunks all
+    // sit on the heaviest ranks keeps >= 2 blocks in its shortest chunk (n_blocks * wmin >= 2 * chunks * wmax): b0 >= 1
     const int b0 = __builtin_amdgcn_readfirstlane(p1_chunk_begin(s, e, A.n_blocks, A.chunks, A.weights));
     const unsigned base = (unsigned)(b0 - 1) * kBlock + lane;
     float2 v[16], w[16];

@@ -5,8 +5,7 @@
 // pays for it with ~30 % register moves (k_conv_p1: 168 -> 124 VGPRs, 0.97 -> 0.87 ms without it).
 #include "kernels.h"
 #include "wave_fft.hpp"
-
-#include <cstdlib>
+#include "tuning.h"
 
 namespace ohs {
 
@@ -74,7 +73,7 @@ __global__ __launch_bounds__(256) void k_conv_tp_mac(const ConvTpArgs A)
         const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
         s = (size_t)(slot / wps) * 8 + xcd;
         widx = slot % wps;
-    } else {                    // plain stream-major order (OHS_MAC_NO_XCD=1, for comparison)
+    } else {                    // plain stream-major order (experiments: mac_no_xcd, for comparison)
         s = blockIdx.x / wps;
         widx = blockIdx.x % wps;
     }
@@ -175,7 +174,7 @@ hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
     m.mac_tiles = (a.n_mac + kTB - 1) / kTB;
     const unsigned wps = (unsigned)(kFft / 256) * (unsigned)m.mac_tiles;
     const unsigned groups = ((unsigned)a.n_streams + 7u) / 8u;
-    const bool xcd_map = getenv("OHS_MAC_NO_XCD") == nullptr;       // tuning experiments
+    const bool xcd_map = !tuning().mac_no_xcd;
     if (!xcd_map) m.mac_tiles = -m.mac_tiles;
     m.main_wgs = (int)(groups * 8u * wps);
     const unsigned w1_wgs = (unsigned)((a.n_pairs + 255) / 256) * (unsigned)a.n_streams;

@@ -1,0 +1,16 @@
+// experiments.h -- the fence between the product library and the laboratory.
+//
+// The product build (no -DOHS_EXPERIMENTS) reads no environment variable, carries no alternative kernel generation and
+// honours none of the compile-time variants below: defining one without OHS_EXPERIMENTS is a build error.  The
+// experiments build (`python -m open_headstage_amd.build --experiments` -> libohs_hip_exp.so, or OHS_BUILD_TAG /
+// OHS_EXTRA_DEFS variants of it) adds the environment knobs, the debug entry points (ohs_debug_set_tuning, stamps) and
+// round 2's EQ kernel for A/B runs; LABNOTES.md lists them.  Knock-out variants that computed wrong results on
+// purpose (round 2-3 timing experiments) are gone from the tree; git history and LABNOTES.md keep their numbers.
+#pragma once
+
+#ifndef OHS_EXPERIMENTS
+#if defined(OHS_P1_NATURAL) || defined(OHS_P1_STAMPS) || defined(OHS_EQ_STAMPS) || defined(OHS_P1_NO_NT) || \
+    defined(OHS_P1_WAVES) || defined(OHS_TP_WAVES) || defined(OHS_MAC_TB) || defined(OHS_MAC_PI)
+#error "compile-time experiment variants need -DOHS_EXPERIMENTS (python -m open_headstage_amd.build --experiments)"
+#endif
+#endif

@@ -1,5 +1,6 @@
 // kernels.h -- host-callable launchers of the gfx950 kernels (internal to the library).
 #pragma once
+#include "experiments.h"
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>

@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "wave_fft.hpp"
 #include "host_internal.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <array>
@@ -32,6 +33,11 @@ constexpr int BS = OHS_BLOCK_SIZE;
 constexpr int NF = OHS_FFT_SIZE;
 
 thread_local std::string g_err;
+#ifdef OHS_EXPERIMENTS
+// experiments build: the k-th chunk launch sequence of ohs_batch_process from now fails as if HIP had refused it
+// (ohs_debug_inject_batch_failure); the product build has no such path
+std::atomic<int> g_inject_batch_failure{0};
+#endif
 
 int fail(int status, const std::string &msg)
 {
@@ -239,11 +245,10 @@ int conv_init(ConvState &c, size_t S, hipStream_t st)
 // Batch objects let the P = 1 fast path leave its state behind lazily: a k_conv_p1 launch then ends with the merged
 // overlap of its last block and a copy of that block's input instead of a k_conv_p1_state launch (9 us + a launch gap
 // per call, hidden nowhere when the convolution runs alone); the next fast launch starts from the merged overlap -- which
-// also makes a call boundary invisible in the output bits.  OHS_P1_LAZY_STATE=0: the per-path state after every launch.
+// also makes a call boundary invisible in the output bits.  (Tuning::p1_lazy_state = 0: the per-path state after every launch.)
 int conv_enable_lazy_state(ConvState &c)
 {
-    const char *e = getenv("OHS_P1_LAZY_STATE");
-    if (e && e[0] == '0') return OHS_OK;
+    if (!tuning().p1_lazy_state) return OHS_OK;
     HIP_TRY(hipMalloc(&c.d_merged, c.S * 8 * 64 * sizeof(float2)));
     HIP_TRY(hipMalloc(&c.d_merged_alt, c.S * 8 * 64 * sizeof(float2)));
     HIP_TRY(hipMalloc(&c.d_last_in, c.S * 2 * BS * sizeof(float)));
@@ -362,7 +367,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
 // K = ceil(2 R / S) ran at 71 % for that reason).  K is the smallest value from ceil(R / S) upwards whose last round is
 // >= 97 % full.  (Rounds 1 and 2 asked for two rounds; since the chunk lengths follow the waves' age ranks one exact
 // round is the faster plan -- config 3 without EQ: 4096 waves 0.537-0.541 ms, 8192 waves 0.549-0.555, 3840 0.563,
-// 4352 0.81 -- and the pre-pass has half the boundary tails to compute.  OHS_P1_ROUNDS=2 restores the old rule.)
+// 4352 0.81 -- and the pre-pass has half the boundary tails to compute.  Tuning::p1_rounds = 2 restores the old rule.)
 long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override, int xcd_n = 8)
 {
     const long long R = (long long)ctx->num_cus * xcd_n / 8 * conv_p1_waves_per_cu();
@@ -370,11 +375,7 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
     if (target_override > 0) {
         K = (target_override + (long long)S - 1) / (long long)S;
     } else {
-        static const long long rounds = [] {
-            const char *e = getenv("OHS_P1_ROUNDS");        // tuning experiments
-            const long long v = e ? atoll(e) : 1;
-            return v >= 1 && v <= 4 ? v : 1;
-        }();
+        const long long rounds = tuning().p1_rounds;
         const long long k0 = std::max<long long>(1, (rounds * R + (long long)S - 1) / (long long)S);
         K = k0;
         double best = 0.0;
@@ -435,16 +436,10 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("build_cd: ") + hipGetErrorString(e));
             c.cd_valid = true;
         }
-        // block ranges per stream: waves for exactly two full rounds of (CUs x resident waves per CU) --
-        // measured on config 3 without EQ: 1.7 rounds 0.847 ms, 2.0 rounds 0.794 ms, 2.5 rounds 0.892 ms
-        // tuning experiments (read per call so that one process can sweep them: tools/tune_p1.py)
-        const char *env_tw = getenv("OHS_P1_TARGET_WAVES");
-        const long long target_override = env_tw ? atoll(env_tw) : 0LL;
+        const Tuning &tn = tuning();
+        const long long target_override = tn.p1_target_waves;
         int xcd_lo = c.xcd_lo, xcd_n = c.xcd_n;
-        if (const char *env_x = getenv("OHS_P1_XCD")) {         // tuning experiments: "lo,n" for every P = 1 launch
-            int lo = 0, n = 8;
-            if (sscanf(env_x, "%d,%d", &lo, &n) == 2 && n >= 1 && lo >= 0 && lo + n <= 8) { xcd_lo = lo; xcd_n = n; }
-        }
+        if (tn.p1_xcd_n > 0) { xcd_lo = tn.p1_xcd_lo; xcd_n = tn.p1_xcd_n; }
         const long long K = conv_p1_chunks(ctx, c.S, n_blocks, target_override, xcd_n);
         if ((size_t)K > c.chunk_tails_cap) {
             DeviceWideSection dws;
@@ -467,31 +462,21 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         a.last_in = c.lazy_ok ? c.d_last_in : nullptr;
         a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
         a.xcd_lo = xcd_lo; a.xcd_n = xcd_n;
-        {   // boundary tails by the chunks' own waves where a stream's chunks share a workgroup (OHS_P1_OWN_TAILS=0: pre-pass)
-            const char *env_ot = getenv("OHS_P1_OWN_TAILS");    // tuning experiments, read per call
+        {   // boundary tails by the chunks' own waves where a stream's chunks share a workgroup (else: the pre-pass)
             const bool allowed = conv_p1_waves_per_cu() == 16 && (K == 2 || K == 4 || K == 8 || K == 16);
-            a.own_tails = (allowed && !(env_ot && env_ot[0] == '0')) ? 1 : 0;
+            a.own_tails = (allowed && tn.p1_own_tails) ? 1 : 0;
         }
-        const char *env_sg = getenv("OHS_P1_STAGGER");          // tuning experiments
-        a.stagger = env_sg ? atoi(env_sg) : 0;
-        const char *env_pr = getenv("OHS_P1_PRIO");             // tuning experiments: 1 = rotate the issue priority per block
-        a.prio_mode = env_pr ? atoi(env_pr) : 0;
-        // chunk lengths by age rank of the wave (p1_chunk_begin); equal lengths when chunks are short
-        static const std::array<int, 4> kWeights = [] {
-            std::array<int, 4> w = {1425, 1128, 825, 622};
-            if (const char *e = getenv("OHS_P1_WEIGHTS")) {     // tuning experiments: "w0,w1,w2,w3"
-                int v[4];
-                if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 &&
-                    v[3] > 0 && v[0] < 100000 && v[1] < 100000 && v[2] < 100000 && v[3] < 100000)
-                    w = {v[0], v[1], v[2], v[3]};
-            }
-            return w;
-        }();
-        const int wmin = std::min(std::min(kWeights[0], kWeights[1]), std::min(kWeights[2], kWeights[3]));
-        const int wsum = kWeights[0] + kWeights[1] + kWeights[2] + kWeights[3];
-        // every chunk must keep >= 2 blocks: mean length x (smallest weight / mean weight) >= 2
-        const bool weighted = (long long)n_blocks * 4 * wmin >= 2ll * K * wsum;
-        for (int g = 0; g < 4; ++g) a.weights[g] = weighted ? kWeights[(size_t)g] : 1;
+        a.stagger = tn.p1_stagger;
+        a.prio_mode = tn.p1_prio;
+        // Chunk lengths by the age rank of the wave that runs a chunk (p1_chunk_begin), equal lengths when chunks are
+        // short.  In the plans that do not spread a stream's chunks over the ranks, ALL of a stream's chunks can sit on
+        // heavy ranks: its shortest chunk is then n * wmin / (K * wmax) blocks, and that one must keep >= 2 blocks (a
+        // chunk of zero blocks would make the boundary-tail code index block b0 - 1 = -1).
+        const int *kw = tn.p1_weights;
+        const int wmin = std::min(std::min(kw[0], kw[1]), std::min(kw[2], kw[3]));
+        const int wmax = std::max(std::max(kw[0], kw[1]), std::max(kw[2], kw[3]));
+        const bool weighted = (long long)n_blocks * wmin >= 2ll * K * wmax;
+        for (int g = 0; g < 4; ++g) a.weights[g] = weighted ? kw[g] : 1;
         hipError_t e = launch_conv_p1(a, st, ev_start, ev_stop);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
         if (c.lazy_ok) {
@@ -702,10 +687,7 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
             }
         }
         int xcd_lo = e.xcd_lo, xcd_n = e.xcd_n;
-        if (const char *env_x = getenv("OHS_EQ_XCD")) {         // tuning experiments: "lo,n" for every ring launch
-            int lo = 0, n = 8;
-            if (sscanf(env_x, "%d,%d", &lo, &n) == 2 && n >= 1 && lo >= 0 && lo + n <= 8) { xcd_lo = lo; xcd_n = n; }
-        }
+        if (tuning().eq_xcd_n > 0) { xcd_lo = tuning().eq_xcd_lo; xcd_n = tuning().eq_xcd_n; }
         const bool first = p0 == 0, last = p0 + 16 >= on.size();
         hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials, e.fp_mode,
                                         xcd_lo, xcd_n, first ? ev_start : nullptr, last ? ev_stop : nullptr);
@@ -792,6 +774,8 @@ struct ohs_engine {
     uint64_t silent_frames = 0;                   // frames answered with the zero fill of convolution.rs:176-181
     // resident real-time kernel (ohs_engine_set_realtime): mailbox in pinned mapped memory, its own stream
     bool rt_enabled = false, rt_running = false, rt_slot = false;   // rt_slot: counted in the device's resident-kernel cap
+    bool rt_wedged = false;         // a resident kernel did not leave within 5 s of its stop request and may still be alive:
+                                    // it holds pointers to this engine's state, its mailbox and its stream (rt_stop)
     RtMailbox *mb = nullptr, *mb_dev = nullptr;
     hipStream_t rt_st = nullptr;
     unsigned rt_seq = 0;
@@ -831,6 +815,11 @@ struct ohs_batch {
     EqState eq;
     int eq_enable = 0;
     float gain = 1.0f;
+    // A HIP failure in the middle of a processing call leaves the per-stream state advanced for some time chunks only:
+    // the handle is marked failed and every later processing call is refused until ohs_batch_reset (which zeroes the
+    // state) -- never a continuation on half-advanced state.
+    bool failed = false;
+    std::string fail_msg;
     hipStream_t st2 = nullptr;  // convolution of time chunk i runs here while the EQ of chunk i+1 runs on the caller's stream
     bool overlap = true;
     int xcd_split = 0;          // x > 0: overlapped calls run the EQ on XCDs [0, x) and the convolution on [x, 8)
@@ -988,15 +977,15 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
 
 // ---- resident real-time kernel: host side of the mailbox protocol (k_engine_resident) --------------------
 // A resident kernel holds one CU (149 KiB of LDS) for as long as it lives, so their number per device is capped:
-// a quarter of the CUs by default (OHS_RT_MAX_RESIDENT).  Engines in real-time mode beyond the cap are served by
+// a quarter of the CUs by default (ohs_rt_configure).  Engines in real-time mode beyond the cap are served by
 // the launch-per-call path until a slot frees up -- same results, never a wait for a CU that is not coming.
 constexpr int OHS_RT_NO_SLOT = 1000;     // internal: rt_start found the device's cap reached (never crosses the C ABI)
 static std::atomic<int> g_rt_resident[kMaxDevices];
 static bool rt_slot_acquire(ohs_engine *e)
 {
     if (e->rt_slot) return true;
-    static const int env_cap = [] { const char *v = getenv("OHS_RT_MAX_RESIDENT"); return v ? atoi(v) : -1; }();
-    const int cap = env_cap >= 0 ? env_cap : std::max(1, e->ctx->num_cus / 4);
+    const int conf = tuning().rt_max_resident;
+    const int cap = conf >= 0 ? conf : std::max(1, e->ctx->num_cus / 4);
     std::atomic<int> &c = g_rt_resident[e->device % kMaxDevices];
     if (c.fetch_add(1, std::memory_order_acq_rel) >= cap) { c.fetch_sub(1, std::memory_order_acq_rel); return false; }
     e->rt_slot = true;
@@ -1027,20 +1016,34 @@ void rt_stop(ohs_engine *e)
     if (!e->rt_running) return;
     __atomic_store_n(&e->mb->call_word[3], 1u, __ATOMIC_RELEASE);
     // the kernel sees `stop` at its next poll (~1 us) and every wave leaves.  Bounded: a kernel that does not leave
-    // within 5 s is wedged, and an unbounded wait here would hang the audio thread with it -- the engine is taken out
-    // of real-time mode and carries on launch per call (whatever the device still does for it)
+    // within 5 s is wedged, and an unbounded wait here would hang the audio thread with it.  A wedged kernel may
+    // still be alive: it keeps its slot in the device's count and its place in the registry, the engine refuses
+    // further calls (engine_process: the launch-per-call path would mutate state the kernel holds pointers to) and
+    // its destruction leaks the mailbox and the stream instead of waiting on them -- until hipStreamQuery reports
+    // that the kernel has gone after all (rt_wedged_recovered).
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipStreamQuery(e->rt_st);
         if (q != hipErrorNotReady) break;
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
             e->rt_enabled = false;
-            ohs_internal_set_error("resident kernel did not leave within 5 s of its stop request; real-time mode switched off for this engine");
-            break;
+            e->rt_wedged = true;
+            ohs_internal_set_error("resident kernel did not leave within 5 s of its stop request; the engine is unusable until it has");
+            return;
         }
         std::this_thread::yield();
     }
     rt_mark_stopped(e);
+}
+
+// a wedged kernel that has left after all: the engine is usable again (launch per call; real-time mode stays off)
+bool rt_wedged_recovered(ohs_engine *e)
+{
+    if (!e->rt_wedged) return true;
+    if (hipStreamQuery(e->rt_st) == hipErrorNotReady) return false;
+    e->rt_wedged = false;
+    rt_mark_stopped(e);
+    return true;
 }
 
 int rt_start(ohs_engine *e)
@@ -1080,14 +1083,8 @@ int rt_start(ohs_engine *e)
     mb->call_word[0] = e->rt_seq; mb->call_word[1] = 0; mb->call_word[2] = 0; mb->call_word[3] = 0;
     mb->done = e->rt_seq; mb->alive = 1;
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    static const unsigned long long idle_limit = [] {
-        const char *v = getenv("OHS_RT_IDLE_POLLS");        // polls without a doorbell before the kernel leaves (~2 s)
-        return v ? strtoull(v, nullptr, 10) : 3000000ull;      // two reads in flight: one poll per ~0.6 us
-    }();
-    static const unsigned sleep_arg = [] {
-        const char *v = getenv("OHS_RT_POLL_SLEEP");
-        return v ? (unsigned)atoi(v) : 0u;      // no pause between poll bursts: 0.3 us less per call than one s_sleep(16)
-    }();
+    const unsigned long long idle_limit = tuning().rt_idle_polls;   // two reads in flight: one poll per ~0.6 us
+    const unsigned sleep_arg = tuning().rt_poll_sleep;              // no pause between poll bursts: 0.3 us less per call
     {
         // launch and registration are one step under the registry's mutex: a DeviceWideSection either finds this
         // kernel in the list (and asks it to leave) or has raised `hold` before (and no kernel is started)
@@ -1155,10 +1152,11 @@ int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r,
                 // the kernel left by its idle limit just as this call rang: start it again (from the state before
                 // this call -- the host's counters have not been advanced yet), it then serves `seq`
                 hipStreamSynchronize(e->rt_st);
-                e->rt_running = false;            // (the slot stays with this engine: it restarts at once)
+                rt_mark_stopped(e);               // (off the registry, slot released: rt_start takes both again -- or
+                                                  // answers OHS_RT_NO_SLOT / hold, and no stale entry stays behind)
                 --e->rt_seq;                      // rt_start arms the mailbox with the last SERVED sequence number
                 rc = rt_start(e);
-                if (rc) return rc;
+                if (rc) return rc;                // (OHS_RT_NO_SLOT included: the caller serves this call launch per call)
                 ++e->rt_seq;
                 ring();
             }
@@ -1195,6 +1193,8 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     if (n == 0) return OHS_OK;
     if (!in_l || !in_r || !out_l || !out_r) return fail(OHS_ERR_INVALID_ARG, "NULL audio pointer");
     HIP_TRY(hipSetDevice(e->device));
+    if (!rt_wedged_recovered(e))
+        return fail(OHS_ERR_HIP, "a resident kernel of this engine did not leave and may still hold its state; the engine is unusable until it has");
     hipStream_t st = e->st;
     // real-time sized calls: the resident kernel's mailbox (real-time mode, no EQ in the chain) or everything in
     // one launch; long offline calls: the multi-kernel path below
@@ -1307,6 +1307,31 @@ int ohs_device_count(int *count)
     return OHS_OK;
 }
 
+// the two deployment options of the resident real-time kernels (include/ohs_hip.h)
+int ohs_rt_configure(int max_resident_per_device, unsigned long long idle_polls)
+{
+    Tuning &t = tuning_rt();
+    t.rt_max_resident = max_resident_per_device;        // < 0: the default, a quarter of the device's CUs
+    if (idle_polls) t.rt_idle_polls = idle_polls;
+    return OHS_OK;
+}
+
+#ifdef OHS_EXPERIMENTS
+// ---- experiments build only: not declared in include/ohs_hip.h, not exported by the product library ----
+int ohs_debug_set_tuning(const char *key, const char *value)
+{
+    if (!key || !value) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    (void)tuning();        // (the environment first, so that it cannot overwrite this edit later)
+    if (!tuning_set(key, value)) return fail(OHS_ERR_INVALID_ARG, std::string("unknown tuning key or bad value: ") + key + "=" + value);
+    return OHS_OK;
+}
+int ohs_debug_inject_batch_failure(int kth_chunk)
+{
+    g_inject_batch_failure.store(kth_chunk);
+    return OHS_OK;
+}
+#endif
+
 int ohs_device_pci_bus_id(int device, char *out, size_t capacity)
 {
     if (!out || capacity < 16) return fail(OHS_ERR_INVALID_ARG, "out is NULL or shorter than 16 bytes");
@@ -1364,6 +1389,19 @@ void ohs_engine_destroy(ohs_engine *e)
     if (!e) return;
     hipSetDevice(e->device);
     rt_stop(e);
+    const bool wedged = !rt_wedged_recovered(e);
+    if (wedged) {
+        // the kernel may still poll its mailbox and write this engine's state: neither may be freed or waited for
+        // (hipStreamDestroy / hipHostFree / hipFree wait for it).  Leak what it holds; the handle itself goes.
+        {
+            RtRegistry &r = g_rt_reg[e->device % kMaxDevices];
+            std::lock_guard<std::mutex> lk(r.mu);
+            r.running.erase(std::remove(r.running.begin(), r.running.end(), e), r.running.end());
+        }
+        ohs_internal_set_error("ohs_engine_destroy: a resident kernel never left; its mailbox, stream and device state were leaked");
+        delete e;
+        return;
+    }
     rt_mark_stopped(e);     // (a slot taken by a start that then failed; also takes the engine off the registry)
     DeviceWideSection dws;  // (frees below: no resident kernel of another engine may be in their way)
     if (e->rt_st) hipStreamDestroy(e->rt_st);
@@ -1393,6 +1431,8 @@ int ohs_engine_clone(const ohs_engine *src, ohs_engine **out)
     const ConvState &s = src->conv;
     ConvState &d = e->conv;
     rt_stop(const_cast<ohs_engine *>(src));      // state at rest (the clone itself starts outside real-time mode)
+    if (!rt_wedged_recovered(const_cast<ohs_engine *>(src)))
+        return bail(fail(OHS_ERR_HIP, "a resident kernel of the source engine did not leave; its state cannot be copied"));
     DeviceWideSection dws;
     hipStreamSynchronize(src->st);
     e->silent_frames = src->silent_frames;
@@ -1431,6 +1471,7 @@ int ohs_engine_set_ir(ohs_engine *e, int path, const float *ir, size_t len)
     if (!e) return fail(OHS_ERR_INVALID_ARG, "engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
     rt_stop(e);         // the resident kernel holds pointers to the spectra and the ring; the next call restarts it
+    if (!rt_wedged_recovered(e)) return fail(OHS_ERR_HIP, "a resident kernel of this engine did not leave; the engine is unusable until it has");
     int rc = conv_set_ir(e->conv, e->ctx, path, ir, len, e->st);
     if (rc) return rc;
     // k_engine_call runs the (up to 8) blocks of a call side by side: the ring must hold the P - 1
@@ -1906,21 +1947,11 @@ int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch *
         return fail(OHS_ERR_HIP, "hipStreamCreate failed");
     }
     {
-        // experiment: OHS_CONV_CU_MASK="w0,w1,..." (hex words, bit i = CU i) confines the overlapped convolution's
-        // stream to a CU set (hipExtStreamCreateWithCUMask)
         hipError_t se = hipErrorUnknown;
-        if (const char *m = getenv("OHS_CONV_CU_MASK")) {
-            std::vector<uint32_t> mask;
-            const char *p = m;
-            while (*p) {
-                char *end = nullptr;
-                const unsigned long v = strtoul(p, &end, 16);
-                if (end == p) break;
-                mask.push_back((uint32_t)v);
-                p = (*end == ',') ? end + 1 : end;
-            }
-            if (!mask.empty()) se = hipExtStreamCreateWithCUMask(&b->st2, (uint32_t)mask.size(), mask.data());
-            if (se != hipSuccess) fprintf(stderr, "[ohs] OHS_CONV_CU_MASK ignored: %s\n", hipGetErrorString(se));
+        const Tuning &tn = tuning();
+        if (!tn.conv_cu_mask.empty()) {      // (experiments: the overlapped convolution's stream confined to a CU set)
+            se = hipExtStreamCreateWithCUMask(&b->st2, (uint32_t)tn.conv_cu_mask.size(), tn.conv_cu_mask.data());
+            if (se != hipSuccess) fprintf(stderr, "[ohs] conv_cu_mask ignored: %s\n", hipGetErrorString(se));
         }
         if (se != hipSuccess) se = hipStreamCreateWithFlags(&b->st2, hipStreamNonBlocking);
         if (se != hipSuccess) {
@@ -1928,27 +1959,20 @@ int ohs_batch_create(int device, size_t n_streams, size_t num_bands, ohs_batch *
             delete b;
             return fail(OHS_ERR_HIP, "hipStreamCreate failed");
         }
-    }
-    {
         // EQ || convolution overlap policy.  An EQ wave saturates the vector unit of its SIMD (every instruction of
         // the ring form is a 4-cycle DPP / packed operation: two EQ waves on one SIMD take 1.82x the time of one,
         // four 3.47x -- profiles/r03_eq_share.txt), so the convolution only makes progress on CUs that host no EQ
         // wave; from one EQ wave per SIMD on (almost) every CU upwards the two kernels merely get in each other's
         // way (2048 streams: 13.7-16.1 ms overlapped, 11.5 ms one after the other).  Overlap while at least an
-        // eighth of the CUs stays free of EQ waves, serialise beyond.  OHS_NO_OVERLAP=1 / OHS_FORCE_OVERLAP=1 override.
-        const char *e = getenv("OHS_NO_OVERLAP"), *f = getenv("OHS_FORCE_OVERLAP");
+        // eighth of the CUs stays free of EQ waves, serialise beyond.
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         const size_t eq_waves = (2 * n_streams + 3) / 4;            // 4 chains per wave
         const size_t eq_cus = (eq_waves + 3) / 4;                   // one wave per SIMD once there is a wave per CU
         b->overlap = eq_cus * 8 <= (size_t)cus * 7;
-        if (e && e[0] == '1') b->overlap = false;
-        if (f && f[0] == '1') b->overlap = true;
-        // experiment: OHS_XCD_SPLIT=x gives the EQ launches XCDs [0, x) and the overlapped convolution [x, 8)
-        if (const char *x = getenv("OHS_XCD_SPLIT")) {
-            const int v = atoi(x);
-            if (v >= 1 && v <= 7) b->xcd_split = v;
-        }
+        if (tn.no_overlap) b->overlap = false;
+        if (tn.force_overlap) b->overlap = true;
+        b->xcd_split = tn.xcd_split;        // (experiments: EQ launches on XCDs [0, x), overlapped convolution on [x, 8))
     }
     rc = conv_init(b->conv, n_streams, b->st);
     if (rc == OHS_OK) rc = conv_enable_lazy_state(b->conv);
@@ -2074,10 +2098,48 @@ int ohs_batch_reset(ohs_batch *b)
     return OHS_OK;
 }
 
+static int batch_process_body(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                              size_t stream_stride, size_t channel_stride, void *hip_stream, bool deferred);
+
 static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
                               size_t stream_stride, size_t channel_stride, void *hip_stream, bool deferred)
 {
     if (!b || !d_in || !d_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (b->failed)
+        return fail(OHS_ERR_HIP, "this batch failed in the middle of an earlier call (" + b->fail_msg +
+                                     "): its per-stream state is half-advanced; ohs_batch_reset starts it afresh");
+    const size_t spans_before = b->spans.size();
+    const int rc = batch_process_body(b, d_in, d_out, n_blocks, stream_stride, channel_stride, hip_stream, deferred);
+    if (rc == OHS_OK || rc == OHS_ERR_INVALID_ARG) return rc;      // (argument errors are found before anything is queued)
+    // A HIP call failed with part of the work queued.  Keep the message, then leave nothing dangling:
+    const std::string why = g_err;
+    //  * the caller's stream must not run ahead of what this call put on the second stream
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventRecord(ev, b->st2) != hipSuccess || hipStreamWaitEvent(st, ev, 0) != hipSuccess)
+            hipStreamSynchronize(b->st2);
+        b->ev_inflight.push_back(ev);
+    } else {
+        hipStreamSynchronize(b->st2);
+    }
+    b->join_pending = false;
+    //  * timing spans opened by this call may hold events that were never recorded: drop them
+    while (b->spans.size() > spans_before) {
+        ohs_batch::Span sp = b->spans.back();
+        b->spans.pop_back();
+        if (sp.a) hipEventDestroy(sp.a);
+        if (sp.b) hipEventDestroy(sp.b);
+    }
+    //  * some time chunks have advanced the per-stream state, others have not
+    b->failed = true;
+    b->fail_msg = why;
+    return fail(rc, why);
+}
+
+static int batch_process_body(ohs_batch *b, const float *d_in, float *d_out, size_t n_blocks,
+                              size_t stream_stride, size_t channel_stride, void *hip_stream, bool deferred)
+{
     if (n_blocks == 0) return OHS_OK;
     if (n_blocks > (size_t)1 << 24) return fail(OHS_ERR_INVALID_ARG, "n_blocks too large");
     const size_t frames = n_blocks * BS;
@@ -2134,6 +2196,10 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
         }
     }
     if (!eq_active) {     // lib.rs:1179 eq_enable false (or every band disabled: identity)
+#ifdef OHS_EXPERIMENTS
+        if (g_inject_batch_failure.load() > 0 && g_inject_batch_failure.fetch_sub(1) == 1)
+            return fail(OHS_ERR_HIP, "injected failure (ohs_debug_inject_batch_failure)");
+#endif
         rc = span_begin(st, 1); if (rc) return rc;
         rc = conv_launch(b->conv, b->ctx, d_in, ss, cs, d_out, ss, cs, (int)n_blocks, b->gain, st);
         if (rc) return rc;
@@ -2145,24 +2211,7 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
     // Uneven chunks: only the LAST chunk's convolution is not hidden under an EQ launch, so it is short
     // (2 % of the frames; six chunks measure 6.00-6.02 ms per headline step, the four of {0.34, 0.66, 0.92} 6.05,
     // seven 6.03-6.04: every extra EQ launch costs its ramp).
-    // OHS_OVERLAP_CUTS="0.3,0.6,0.9" overrides the interior cut points (tuning experiments, tools/ab_cuts.sh).
-    static const std::vector<double> kCut = [] {
-        std::vector<double> c = {0.0, 0.25, 0.5, 0.75, 0.92, 0.98, 1.0};
-        if (const char *e = getenv("OHS_OVERLAP_CUTS")) {
-            std::vector<double> v = {0.0};
-            const char *p = e;
-            while (*p && v.size() < 16) {
-                char *end = nullptr;
-                const double x = strtod(p, &end);
-                if (end == p) break;
-                if (x > v.back() && x < 1.0) v.push_back(x);
-                p = (*end == ',') ? end + 1 : end;
-            }
-            v.push_back(1.0);
-            if (v.size() >= 3) c = v;
-        }
-        return c;
-    }();
+    const std::vector<double> &kCut = tuning().overlap_cuts;
     const int nch = (b->overlap && n_blocks >= 64) ? (int)kCut.size() - 1 : 1;
     // XCD partition of the overlapped launches: the EQ on XCDs [0, x), the convolution on [x, 8)
     struct XcdScope {
@@ -2194,6 +2243,10 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
             continue;
         }
         if (chunk_waits) HIP_TRY(hipStreamWaitEvent(st, b->chunk_done[(size_t)i], 0));
+#ifdef OHS_EXPERIMENTS
+        if (g_inject_batch_failure.load() > 0 && g_inject_batch_failure.fetch_sub(1) == 1)
+            return fail(OHS_ERR_HIP, "injected failure (ohs_debug_inject_batch_failure)");
+#endif
         // The EQ launch carries its own events (start / completion of the dispatch: no marker packets between the
         // back-to-back EQ launches of a step); the completion event is what the convolution's stream waits for.
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -2308,8 +2361,7 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
         // priority levels of their own, where nothing else of this process lives.
         int pr_least = 0, pr_greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-        const char *flat = getenv("OHS_HOST_PIPE_FLAT_PRIORITIES");      // experiment: the old behaviour
-        if (flat && flat[0] == '1') pr_least = pr_greatest = 0;
+        if (tuning().host_pipe_flat_priorities) pr_least = pr_greatest = 0;     // (experiments: the old behaviour)
         // (the pipeline's compute stream too: which normal-priority stream it would share a queue with depends on how
         // many streams the process has created before -- bench.py measured 21.7 or 25.6 ms depending on its step count)
         HIP_TRY(hipStreamCreateWithPriority(&b->st_h2d, hipStreamNonBlocking, pr_greatest));
@@ -2364,9 +2416,9 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
         HIP_TRY(hipStreamWaitEvent(b->st_comp, b->chunk_done[(size_t)b->chunk_done_n - 1], 0));
         b->join_pending = false;
     }
-    // OHS_HOST_PIPE_TRACE=1: device timestamps around every stage of every chunk, printed after the call
-    // (diagnostic; it adds six event records per chunk)
-    static const bool trace = [] { const char *v = getenv("OHS_HOST_PIPE_TRACE"); return v && v[0] == '1'; }();
+    // (experiments build, host_pipe_trace: device timestamps around every stage of every chunk, printed after the call;
+    // it adds six event records per chunk)
+    const bool trace = tuning().host_pipe_trace != 0;
     std::vector<hipEvent_t> tev;
     auto mark = [&](hipStream_t st) {
         if (!trace) return;

@@ -1,0 +1,54 @@
+// tuning.h -- every launch-plan constant of the host layer in one place.
+//
+// Product build: tuning() is a constant object -- the measured best of rounds 1-3 -- and nothing can change it.
+// Experiments build (-DOHS_EXPERIMENTS): the same object starts from the OHS_* environment variables of LABNOTES.md
+// and ohs_debug_set_tuning(key, value) edits it in a running process (the tests' plan overrides, the sweep tools).
+// The two options a deployment may legitimately set -- how many resident real-time kernels a device hosts and how long
+// an idle one stays -- are arguments of the public ohs_rt_configure, not knobs.
+#pragma once
+#include "experiments.h"
+
+#include <string>
+#include <vector>
+
+namespace ohs {
+
+struct Tuning {
+    // k_conv_p1 wave plan
+    long long p1_target_waves = 0;          // > 0: chunks per stream = ceil(target / streams) instead of the round rule
+    int p1_rounds = 1;                      // rounds of resident waves a launch is cut for
+    int p1_own_tails = 1;                   // boundary tails by the chunks' own waves where a stream's chunks share a workgroup
+    int p1_stagger = 0;                     // per-wave start offset, x 64 cycles
+    int p1_prio = 0;                        // 1: rotate the issue priority per block
+    int p1_weights[4] = {1425, 1128, 825, 622};     // chunk length by the age rank of the wave that runs it
+    int p1_lazy_state = 1;                  // batch objects leave the merged overlap + last input block behind
+    int p1_xcd_lo = 0, p1_xcd_n = 0;        // n > 0: every P = 1 launch confined to XCDs [lo, lo + n)
+    // EQ launches
+    int eq_xcd_lo = 0, eq_xcd_n = 0;        // n > 0: every ring launch confined to XCDs [lo, lo + n)
+    int eq_conveyor = 0;                    // k_eq_pass also for <= 12 bands
+    int eq_ring_v1 = 0;                     // round 2's 114-VGPR ring kernel (experiments build only)
+    int eq_no_prio = 0;                     // no s_setprio 3 in k_eq_ring
+    int eq_wg_waves = 0;                    // 0: 1 wave per workgroup below one wave per CU, else 4
+    int eq_lds = 0;                         // LDS reservation per EQ workgroup, bytes
+    // ohs_batch_process
+    int no_overlap = 0, force_overlap = 0;  // EQ || convolution overlap policy overrides
+    int xcd_split = 0;                      // x > 0: overlapped calls run the EQ on XCDs [0, x), the convolution on [x, 8)
+    std::vector<double> overlap_cuts = {0.0, 0.25, 0.5, 0.75, 0.92, 0.98, 1.0};
+    std::vector<unsigned> conv_cu_mask;     // non-empty: the overlapped convolution's stream gets this CU mask
+    int mac_no_xcd = 0;                     // plain stream-major workgroup order in k_conv_tp_mac
+    // ohs_batch_process_host
+    int host_pipe_trace = 0, host_pipe_flat_priorities = 0;
+    // resident real-time kernels: set through ohs_rt_configure in either build
+    int rt_max_resident = -1;               // per device; < 0: a quarter of the CUs
+    unsigned long long rt_idle_polls = 3000000ull;      // polls without a doorbell before the kernel leaves (~2 s)
+    unsigned rt_poll_sleep = 0;             // pause between poll bursts, x s_sleep 16
+};
+
+const Tuning &tuning();
+Tuning &tuning_rt();        // the three rt_* fields only (ohs_rt_configure); everything else stays constant in the product
+#ifdef OHS_EXPERIMENTS
+// "key=value" edits; returns false for an unknown key or an unparsable value
+bool tuning_set(const std::string &key, const std::string &value);
+#endif
+
+}  // namespace ohs

@@ -93,18 +93,10 @@ __device__ __forceinline__ void wave_lds_sync()
 // ds_read_b64 (MI355X: 2 x 32-lane groups per b64 read, 4 x 16 per half of a read2; measured by
 // tools/ubench_lds.py).  A volatile access is left alone by that pass; program order among them is what the
 // exchanges want anyway.
-// timing experiments only (wrong results): OHS_KO_TW replaces every twiddle-table read by a register value
-#ifdef OHS_KO_TW
-#define OHS_TW_LD(p) make_float2(0.99f, 0.01f * (float)lane)
-#else
+// OHS_TW_LD: a twiddle-table read; OHS_TW_PIN: the 15 reads of a stage stay one burst in front of their products
+// (hipcc put each read in front of its multiplication and waited for it: eight exposed LDS round trips per stage)
 #define OHS_TW_LD(p) lds_ld(p)
-#endif
-#ifdef OHS_TW_UNPINNED      // experiment: the table reads where hipcc puts them
-#define OHS_TW_PIN() do { } while (0)
-#else
 #define OHS_TW_PIN() __builtin_amdgcn_sched_barrier(0)
-#endif
-#ifndef OHS_LDS_MERGE
 // (accessed as one 64-bit integer, not as a <2 x float> vector: with a vector type in play hipcc packs the
 // following complex arithmetic into v_pk_* instructions and pays for it in register moves)
 __device__ __forceinline__ float2 lds_ld(const float2 *p)
@@ -125,15 +117,6 @@ __device__ __forceinline__ void lds_ld2(const float4 *p, float2 &a, float2 &b)
     a = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
     b = make_float2(__uint_as_float(t.z), __uint_as_float(t.w));
 }
-#else
-__device__ __forceinline__ void lds_ld2(const float4 *p, float2 &a, float2 &b)
-{
-    const float4 t = *p;
-    a = make_float2(t.x, t.y); b = make_float2(t.z, t.w);
-}
-__device__ __forceinline__ float2 lds_ld(const float2 *p) { return *p; }
-__device__ __forceinline__ void lds_st(float2 *p, float2 v) { *p = v; }
-#endif
 
 // 4-point DFT in place: (a,b,c,d) = inputs 0..3 -> outputs 0..3
 template <bool INV>
@@ -267,14 +250,12 @@ __device__ __forceinline__ void wave_fft_fwd_head(float2 (&v)[16], float2 *lds, 
     }
     const int pp = lane >> 2, c = lane & 3;
     const int t1r = t1_index(pp, c);                        // t1_index(pp, 4b + c) = t1r + 4b
-#ifndef OHS_KO_T1       // timing experiment (wrong results): the transform without its T1 exchanges
 #pragma unroll
     for (int p = 0; p < 16; ++p) lds_st(&lds[t1_index(p, lane)], v[p]);  // T1
     wave_lds_sync();
 #pragma unroll
     for (int b = 0; b < 16; ++b) v[b] = lds_ld(&lds[t1r + 4 * b]);
     wave_lds_sync();
-#endif
     dft16<false>(v);                                        // over b -> q
     {
         float2 tw[16];
@@ -300,12 +281,6 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) v[rr] = lds_ld(&lds[t2_index(rr, rbase)]);   // rr = 4 p_lo + c
     float2 m[16];
-#ifdef OHS_KO_MIRROR    // timing experiment (wrong results): no mirror reads, no mirror DFT4s
-    if constexpr (MIRROR) {
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) m[rr] = v[15 - rr];
-    }
-#else
     if constexpr (MIRROR) {
         const int la = 63 - lane, lb = (64 - lane) & 63;
         const int rbA = t2_sigma(la >> 2, la & 3), rbB = t2_sigma(lb >> 2, lb & 3);
@@ -314,7 +289,6 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
 #pragma unroll
         for (int rr = 4; rr < 16; ++rr) m[rr] = lds_ld(&lds[t2_index(rr, rbA)]);              // groups j' = 1..3 of lane 63 - L
     }
-#endif
     wave_lds_sync();
     // DFT4 over c for each j = p_lo; result to reg 4 r + j
 #pragma unroll
@@ -327,10 +301,8 @@ __device__ __forceinline__ void wave_fft_fwd_impl(float2 (&v)[16], float2 (&zm)[
     t = v[7];  v[7] = v[13];  v[13] = t;
     t = v[11]; v[11] = v[14]; v[14] = t;
     if constexpr (MIRROR) {
-#ifndef OHS_KO_MIRROR
 #pragma unroll
         for (int j = 0; j < 4; ++j) dft4<false>(m[4 * j], m[4 * j + 1], m[4 * j + 2], m[4 * j + 3]);   // m[4 j' + r']
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -376,17 +348,9 @@ __device__ __forceinline__ void wave_fft_inv(float2 (&v)[16], float2 *lds, const
     for (int j = 0; j < 4; ++j) dft4<true>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);  // r -> c
 #pragma unroll
     for (int c = 1; c < 4; ++c) {
-#ifdef OHS_KO_MIRROR_TW   // timing experiment: one w64 read per (j, c) as a paired bin layout would need
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float2 w = OHS_TW_LD(&tab[tabB_index((lane >> 2) ^ (3 * j), c)]);
-            v[4 * j + c] = cmulc(v[4 * j + c], w);
-        }
-#else
         const float2 w = OHS_TW_LD(&tab[tabB_index(lane >> 2, c)]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * j + c] = cmulc(v[4 * j + c], w);
-#endif
     }
     const int rbase = t2_sigma(lane >> 2, lane & 3);
 #pragma unroll
@@ -414,14 +378,12 @@ __device__ __forceinline__ void wave_fft_inv_tail(float2 (&v)[16], float2 *lds, 
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = cmulc(v[b], tw[b]);   // w1024^((4b+c) p), conj
     }
-#ifndef OHS_KO_T1
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds_st(&lds[t1r + 4 * b], v[b]);    // T1'
     wave_lds_sync();
 #pragma unroll
     for (int p = 0; p < 16; ++p) v[p] = lds_ld(&lds[t1_index(p, lane)]);
     wave_lds_sync();
-#endif
     dft16<true>(v);                                         // over p -> a
 }
 

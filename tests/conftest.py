@@ -29,6 +29,42 @@ def pytest_sessionstart(session):
         if not _build.is_current():
             pytest.exit(f"conftest: libohs_hip.so is missing or stale and could not be rebuilt: {e}", returncode=3)
         print(f"conftest: build step failed ({e}); the existing library matches the sources", file=sys.stderr)
+    # the experiments build (libohs_hip_exp.so): the tests that override a launch plan, or inject a failure, use its
+    # debug entry points -- never environment variables on the product library
+    try:
+        _build.build_experiments()
+    except Exception as e:      # noqa: BLE001
+        if not _build.experiments_is_current():
+            pytest.exit(f"conftest: libohs_hip_exp.so is missing or stale and could not be rebuilt: {e}", returncode=3)
+
+
+class _ExpTuning:
+    """set a tuning key of the experiments library for one test; every key goes back to its default afterwards"""
+    DEFAULTS = {"p1_target_waves": "0", "p1_rounds": "1", "p1_own_tails": "1", "p1_stagger": "0", "p1_prio": "0",
+                "p1_weights": "1425,1128,825,622", "p1_xcd": "off", "eq_xcd": "off", "eq_conveyor": "0", "eq_ring_v1": "0",
+                "eq_no_prio": "0", "eq_wg_waves": "0", "eq_lds": "0", "mac_no_xcd": "0"}
+
+    def __init__(self):
+        from open_headstage_amd import _ffi
+        self._ffi = _ffi
+        self.lib = _ffi.experiments_lib()
+        self.touched = set()
+
+    def __call__(self, key, value):
+        self._ffi.set_tuning(key, value)
+        self.touched.add(key)
+
+    def restore(self):
+        for k in self.touched:
+            self._ffi.set_tuning(k, self.DEFAULTS[k])
+        self.lib.ohs_debug_inject_batch_failure(0)
+
+
+@pytest.fixture
+def exp_tuning():
+    t = _ExpTuning()
+    yield t
+    t.restore()
 
 
 @pytest.fixture(scope="session")

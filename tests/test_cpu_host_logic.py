@@ -236,3 +236,19 @@ def test_bench_self_launch_plumbing_without_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-streams", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "a rank would have no stream" in r.stderr
+
+
+def test_the_product_library_has_no_debug_entry_points_and_reads_no_environment():
+    import ctypes as C
+    import os
+    import subprocess
+    from open_headstage_amd import _ffi
+    prod = C.CDLL(os.path.join(_ffi.HERE, "libohs_hip.so"))
+    for name in _ffi.DEBUG_PROTOTYPES:
+        assert not hasattr(prod, name), name
+    # the only strings of the product library that start with OHS_ are the status names of ohs_status_string
+    out = subprocess.run(["strings", os.path.join(_ffi.HERE, "libohs_hip.so")], capture_output=True, text=True).stdout
+    names = sorted({l for l in out.splitlines() if l.startswith("OHS_")})
+    assert names and all(n == "OHS_OK" or n.startswith("OHS_ERR_") for n in names), names
+    assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(_ffi.HERE, "libohs_hip.so")],
+                                          capture_output=True, text=True).stdout

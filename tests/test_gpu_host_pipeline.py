@@ -115,8 +115,9 @@ def test_host_pipeline_irregular_strides_and_errors():
 
 
 def test_host_pipeline_stage_trace_diagnostic_runs():
-    """OHS_HOST_PIPE_TRACE=1 (read once per process -> child process): the per-chunk stage table is printed and the
-    results are unchanged."""
+    """The stage trace is a diagnostic of the EXPERIMENTS build (libohs_hip_exp.so, OHS_HOST_PIPE_TRACE=1; the product
+    library reads no environment variable): a child process runs the package on that build -- the per-chunk stage table
+    is printed and the results are unchanged."""
     import os
     import subprocess
     import sys
@@ -142,7 +143,7 @@ b = make().process_host(x.copy(), chunk_blocks=32)
 assert np.array_equal(a, b)
 print("trace ok")
 """ % root
-    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OHS_HOST_PIPE_TRACE="1"),
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OHS_HOST_PIPE_TRACE="1", OHS_LIB="exp"),
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "trace ok" in res.stdout, (res.stdout[-300:], res.stderr[-1500:])
     assert "[ohs host pipeline] 3 chunks of 32 blocks" in res.stderr, res.stderr[-1500:]

@@ -375,7 +375,8 @@ def test_batch_p1_output_bits_are_those_of_the_natural_bin_layout(ohs, synth):
     natural-layout build (-DOHS_P1_NATURAL) produced: tests/golden/p1_output_sha256.txt, written by tools/p1_hash.py
     with that build.  A deliberate change of the kernel's arithmetic needs the file regenerated (and says so here):
     last done when batch objects began to carry the MERGED overlap across call boundaries (lazy state) -- the
-    multi-call shapes changed, the single-call ones did not; OHS_P1_LAZY_STATE=0 still reproduces the older file."""
+    multi-call shapes changed, the single-call ones did not; the experiments build's p1_lazy_state=0 still reproduces the
+    older file."""
     import hashlib
     import os
     import torch
@@ -404,21 +405,19 @@ def test_batch_p1_output_bits_are_those_of_the_natural_bin_layout(ohs, synth):
 
 
 @pytest.mark.parametrize("S,n_blocks", [(512, 64), (1024, 32), (2048, 16), (1000, 40), (4100, 16)])
-def test_batch_p1_many_streams_chunk_plans_agree_bit_for_bit(ohs, synth, monkeypatch, S, n_blocks):
+def test_batch_p1_many_streams_chunk_plans_agree_bit_for_bit(ohs, synth, exp_tuning, S, n_blocks):
     """From 512 streams up a stream has 8, 4 or 2 chunks and k_conv_p1 deals a workgroup's waves out across its streams
     (p1_wave_job: every stream owns waves of all age ranks).  Where a stream is cut does not change a bit of the result,
-    so the default plan must equal a plan of three chunks per stream (consecutive waves, OHS_P1_TARGET_WAVES) and one
-    without any cut, over two calls that chain the state."""
+    so the PRODUCT library's plan must equal a plan of three chunks per stream (consecutive waves; the experiments
+    build's p1_target_waves) and one without any cut, over two calls that chain the state."""
     import torch
     dev = torch.device("cuda:0")
     irs = synth.hrir_set(512)
     outs = []
     for target in (None, 3 * S, S):
-        if target is None:
-            monkeypatch.delenv("OHS_P1_TARGET_WAVES", raising=False)
-        else:
-            monkeypatch.setenv("OHS_P1_TARGET_WAVES", str(target))
-        bp = ohs.BatchProcessor(S, num_bands=10)
+        if target is not None:
+            exp_tuning("p1_target_waves", target)
+        bp = ohs.BatchProcessor(S, num_bands=10, library=None if target is None else exp_tuning.lib)
         for p in range(4):
             bp.set_ir(p, irs[p])
         bp.set_eq_enabled(False)
@@ -482,10 +481,10 @@ def test_batch_p1_call_boundaries_are_invisible_in_the_output_bits(ohs, synth, e
     assert torch.equal(z1.view(torch.int32), z2.view(torch.int32))
 
 
-def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, monkeypatch):
+def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, exp_tuning):
     """The XCD partition experiment (kernels.h: xcd_grid -- workgroups on XCDs outside the launch's set return at once, the
-    others renumber themselves) must leave results untouched: EQ on XCDs [0, 2), P = 1 convolution on [2, 5), against the
-    unpartitioned launches."""
+    others renumber themselves) must leave results untouched: EQ on XCDs [0, 2), P = 1 convolution on [2, 5) in the
+    experiments build, against the product library's unpartitioned launches."""
     import torch
     dev = torch.device("cuda:0")
     S, n_blocks = 37, 70
@@ -493,12 +492,9 @@ def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, monkeypa
     outs = []
     for part in (False, True):
         if part:
-            monkeypatch.setenv("OHS_P1_XCD", "2,3")
-            monkeypatch.setenv("OHS_EQ_XCD", "0,2")
-        else:
-            monkeypatch.delenv("OHS_P1_XCD", raising=False)
-            monkeypatch.delenv("OHS_EQ_XCD", raising=False)
-        bp = ohs.BatchProcessor(S, num_bands=10)
+            exp_tuning("p1_xcd", "2,3")
+            exp_tuning("eq_xcd", "0,2")
+        bp = ohs.BatchProcessor(S, num_bands=10, library=exp_tuning.lib if part else None)
         for p in range(4):
             bp.set_ir(p, irs[p])
         for i, b in enumerate(synth.eq_table()):
@@ -517,7 +513,7 @@ def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, monkeypa
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
 
 
-def test_batch_p1_random_shapes_default_plan_equals_one_chunk_per_stream(ohs, synth, monkeypatch):
+def test_batch_p1_random_shapes_default_plan_equals_one_chunk_per_stream(ohs, synth, exp_tuning):
     """Seeded sweep over stream counts, block counts and call sequences: the launch plan conv_p1_chunks picks (chunk count
     by rounds / cost rule, waves dealt out across streams, boundary tails by the chunks' own waves or by the pre-pass,
     lazy state across calls) against the plainest plan there is -- one wave per stream, no cut -- bit for bit, in place."""
@@ -532,10 +528,8 @@ def test_batch_p1_random_shapes_default_plan_equals_one_chunk_per_stream(ohs, sy
         outs = []
         for plain in (False, True):
             if plain:
-                monkeypatch.setenv("OHS_P1_TARGET_WAVES", str(S))
-            else:
-                monkeypatch.delenv("OHS_P1_TARGET_WAVES", raising=False)
-            bp = ohs.BatchProcessor(S, num_bands=10)
+                exp_tuning("p1_target_waves", S)
+            bp = ohs.BatchProcessor(S, num_bands=10, library=exp_tuning.lib if plain else None)
             for p in range(4):
                 bp.set_ir(p, irs[p])
             bp.set_eq_enabled(False)

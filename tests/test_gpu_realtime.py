@@ -82,7 +82,7 @@ def test_realtime_mode_against_the_oracle_with_restarts(ohs, synth, oracle):
 
 
 def test_resident_kernel_leaves_by_itself_when_idle_and_is_restarted(ohs, synth):
-    """OHS_RT_IDLE_POLLS is read once per process, so the idle exit is exercised in a child process."""
+    """ohs_rt_configure(idle_polls) is process-wide, so the idle exit is exercised in a child process."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -90,7 +90,8 @@ def test_resident_kernel_leaves_by_itself_when_idle_and_is_restarted(ohs, synth)
 import sys, time, numpy as np
 sys.path.insert(0, %r)
 import open_headstage_amd as ohs
-from open_headstage_amd import synth
+from open_headstage_amd import synth, _ffi
+_ffi.check(_ffi.lib().ohs_rt_configure(-1, 20000))       # ~30 ms at ~1.5 us per poll
 irs = synth.hrir_set(512)
 a, b = ohs.ConvolutionEngine.new(), ohs.ConvolutionEngine.new()
 for p in range(4):
@@ -105,15 +106,14 @@ for i in range(8):
     assert np.array_equal(g[0], e[0]) and np.array_equal(g[1], e[1]), i
 print("idle-exit ok")
 """ % root
-    env = dict(os.environ, OHS_RT_IDLE_POLLS="20000")       # ~30 ms at ~1.5 us per poll
-    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "idle-exit ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
 
 
 def test_resident_kernels_are_capped_per_device_and_the_rest_falls_back(ohs, synth):
-    """A resident kernel holds a CU for good, so their number per device is capped (OHS_RT_MAX_RESIDENT, read once per
-    process -> child process): engines beyond the cap run launch per call with the same bits, and get a resident kernel
-    once another engine leaves real-time mode."""
+    """A resident kernel holds a CU for good, so their number per device is capped (ohs_rt_configure, process-wide ->
+    child process): engines beyond the cap run launch per call with the same bits, and get a resident kernel once
+    another engine leaves real-time mode."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -122,6 +122,7 @@ import ctypes as C, sys, numpy as np
 sys.path.insert(0, %r)
 import open_headstage_amd as ohs
 from open_headstage_amd import synth, _ffi
+_ffi.check(_ffi.lib().ohs_rt_configure(2, 0))
 irs = synth.hrir_set(512)
 rt = [ohs.ConvolutionEngine.new() for _ in range(4)]
 ref = [ohs.ConvolutionEngine.new() for _ in range(4)]
@@ -156,8 +157,7 @@ for i in range(8, 12):
 assert resident(rt[2])               # the former rt[3]
 print("cap ok")
 """ % root
-    env = dict(os.environ, OHS_RT_MAX_RESIDENT="2")
-    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "cap ok" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
 
 
