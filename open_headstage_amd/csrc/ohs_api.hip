@@ -2095,6 +2095,8 @@ int ohs_batch_reset(ohs_batch *b)
     int rc = eq_reset(b->eq, b->st);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(b->st));
+    b->failed = false;          // (zeroed state is consistent state)
+    b->fail_msg.clear();
     return OHS_OK;
 }
 
