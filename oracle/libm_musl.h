@@ -13,13 +13,44 @@
  *     powf        msun e_powf.c (the fdlibm algorithm: log2(x) to ~32 bits as t1 + t2, y * log2(x) split in two,
  *                 2^z by a degree-5 Remez rational)
  * PARITY UNPINNED: neither the crate nor musl is on this machine; the constants and operation order below are from
- * the published sources as the author knows them, checked here only against glibc (<= 1 ulp, tests/test_cpu_libm.py).
+ * the published sources as the author knows them, checked here against glibc (<= 1 ulp, tests/test_cpu_libm.py) and
+ * against correctly rounded results over > 10^6 arguments of the coefficient domain (<= 1 ulp,
+ * tests/test_cpu_coeff_pins.py).
  * Arguments outside what the coefficient code produces (|x| > 9 pi / 4 for sinf / cosf; x <= 0, non-finite or
  * subnormal cases of powf) fall through to the platform's libm.
  *
  * Plain C99, no dependencies: the same text builds into the library (hipcc, host side) and is held, as a separate
  * copy, by the CPU oracle (oracle/libm_musl.h) -- test infrastructure shares no file with the product.
  * Build WITHOUT fused contraction (-ffp-contract=off or the pragmas below): every operation rounds by itself.
+ *
+ * UPSTREAM NOTICES.  The constants, the argument-reduction scheme and the operation order restated below are those of
+ * FreeBSD msun (s_sinf.c, s_cosf.c, k_sinf.c, k_cosf.c, e_powf.c) as carried by musl libc and by the Rust `libm` crate;
+ * this file is a derived work of them and carries their notices:
+ *
+ *   ====================================================
+ *   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ *   Developed at SunPro, a Sun Microsystems, Inc. business.
+ *   Permission to use, copy, modify, and distribute this
+ *   software is freely granted, provided that this notice
+ *   is preserved.
+ *   ====================================================
+ *   (msun: "Conversion to float by Ian Lance Taylor, Cygnus Support, ian@cygnus.com.  Optimized by Bruce D. Evans.")
+ *
+ *   musl libc -- Copyright (c) 2005-2020 Rich Felker, et al.  Licensed under the MIT license:
+ *   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+ *   documentation files (the "Software"), to deal in the Software without restriction, including without limitation
+ *   the rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and
+ *   to permit persons to whom the Software is furnished to do so, subject to the following conditions: The above
+ *   copyright notice and this permission notice shall be included in all copies or substantial portions of the
+ *   Software.  THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT
+ *   LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT
+ *   SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF
+ *   CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS
+ *   IN THE SOFTWARE.
+ *
+ *   `libm` crate 0.1.4 (rust-lang/libm) -- dual-licensed MIT / Apache-2.0, Copyright (c) 2018 Jorge Aparicio; its
+ *   sinf / cosf / powf are ports of the musl files above and keep the Sun notice.
  */
 #ifndef OHS_LIBM_MUSL_H
 #define OHS_LIBM_MUSL_H

@@ -230,18 +230,16 @@ def test_eq_more_than_16_bands(ohs, synth, oracle):
     assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32))
 
 
-def test_eq_coefficients_match_oracle_restatement(ohs, synth, oracle):
-    """Both sides restate biquad 0.4.2 from_params; they must agree bit for bit on this host."""
-    from open_headstage_amd import FilterType, biquad_coefficients
-    for t in range(8):
-        for fc, q, g in [(20.0, 0.707, 0.0), (105.0, 0.7, 4.0), (1000.0, 1.41, -3.0), (19999.0, 10.0, 16.0)]:
-            a = biquad_coefficients(FilterType(t), 48000.0, fc, q, g)
-            b = oracle.biquad_coeffs(t, 48000.0, fc, q, g)
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (t, fc, q, g)
-    with pytest.raises(ohs.OhsError):            # the reference unwrap()s (panics) here
+def test_eq_coefficient_errors_are_the_biquad_crates(ohs):
+    """(What the coefficient values ARE is pinned on the CPU, independently of the oracle: tests/test_cpu_coeff_pins.py.)
+    The error cases of biquad::Coefficients::from_params, which the reference unwrap()s (parametric_eq.rs:111):"""
+    from open_headstage_amd import FilterType, _ffi, biquad_coefficients
+    with pytest.raises(ohs.OhsError) as ei:
         biquad_coefficients(FilterType.Peak, 48000.0, 30000.0, 1.0, 0.0)
-    with pytest.raises(ohs.OhsError):
+    assert ei.value.status == _ffi.OHS_ERR_OUTSIDE_NYQUIST
+    with pytest.raises(ohs.OhsError) as ei:
         biquad_coefficients(FilterType.Peak, 48000.0, 1000.0, -1.0, 0.0)
+    assert ei.value.status == _ffi.OHS_ERR_NEGATIVE_Q
 
 
 def test_eq_one_ulp_in_one_coefficient_moves_the_output_beyond_1e_6(ohs, synth, oracle):
@@ -479,6 +477,50 @@ def test_batch_p1_call_boundaries_are_invisible_in_the_output_bits(ohs, synth, e
     torch.cuda.synchronize()
     assert torch.isfinite(z1).all()
     assert torch.equal(z1.view(torch.int32), z2.view(torch.int32))
+
+
+@pytest.mark.parametrize("lazy", [True, False])
+def test_batch_p1_midstream_set_ir_vs_oracle(ohs, synth, oracle, exp_tuning, lazy):
+    """The P = 1 batch path across per-path set_ir calls in mid-stream, against the ORACLE (not against itself): the lazy
+    state (merged overlap + the last input block) is turned back into per-path overlaps by conv_materialise_state with
+    the OLD spectra before they are replaced (convolution.rs:135-138 resets only that path's overlap).  A shorter
+    response, a mute and a full-length one; product library (lazy state) and the experiments build with
+    p1_lazy_state = 0 (per-path state after every launch)."""
+    import torch
+    S, n_blocks = 5, 9
+    irs = synth.hrir_set(512)
+    lib = None
+    if not lazy:
+        exp_tuning("p1_lazy_state", 0)
+        exp_tuning.touched.discard("p1_lazy_state")      # (read when a batch is created; put back by hand below)
+        lib = exp_tuning.lib
+    try:
+        bp = ohs.BatchProcessor(S, num_bands=10, library=lib)
+    finally:
+        if not lazy:
+            exp_tuning._ffi.set_tuning("p1_lazy_state", 1)
+    engs = [oracle.ConvolutionEngine() for _ in range(S)]
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+        for e in engs:
+            e.set_ir(p, irs[p])
+    edits = {1: (2, irs[2][:100]), 2: (1, np.zeros(0, np.float32)), 3: (0, synth.hrir_set(512)[3] * np.float32(0.7)),
+             4: (1, irs[1])}
+    got, ref = [], []
+    for call in range(6):
+        if call in edits:
+            path, h = edits[call]
+            bp.set_ir(path, h)
+            for e in engs:
+                e.set_ir(path, h)
+        x = synth.white_noise(range(30 * call, 30 * call + S), n_blocks * 512)
+        got.append(bp.process(torch.from_numpy(x).cuda()).cpu().numpy())
+        ref.append(np.stack([np.stack(engs[s].process_block(x[s, 0], x[s, 1])) for s in range(S)]))
+    for call in range(6):       # call by call: an error confined to the block after a reset cannot hide in an average
+        for s in range(S):
+            assert_parity(got[call][s], ref[call][s], f"lazy={lazy}, call {call}, stream {s}")
+            assert_parity(got[call][s][:, :512], ref[call][s][:, :512], f"lazy={lazy}, call {call}, stream {s}, first block",
+                          tol=2e-6)
 
 
 def test_batch_xcd_partition_of_the_launches_changes_no_bit(ohs, synth, exp_tuning):

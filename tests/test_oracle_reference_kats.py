@@ -53,6 +53,25 @@ def test_delay_ir(oracle):
     _assert_approx(out_l[delay:], expected[delay:], "Delayed signal")
 
 
+def test_delay_ir_at_the_tolerance_f32_allows(oracle):
+    """the same ramp at 5e-4 absolute / 1e-6 relative RMS (the reference's 1e-3 cannot tell a correct FFT from a sloppy
+    one): the checker itself must meet what the HIP path is held to"""
+    e = oracle.ConvolutionEngine()
+    delay = 5
+    ir = np.zeros(delay + 1, np.float32)
+    ir[delay] = 1.0
+    e.set_ir(oracle.LSL, ir)
+    for p in (oracle.LSR, oracle.RSL, oracle.RSR):
+        e.set_ir(p, [0.0])
+    in_l = np.arange(BLOCK_SIZE * 2, dtype=np.float32)
+    out_l, out_r = e.process_block(in_l, np.zeros(BLOCK_SIZE * 2, np.float32))
+    expected = np.zeros(BLOCK_SIZE * 2)
+    expected[delay:] = in_l[: BLOCK_SIZE * 2 - delay]
+    err = np.abs(out_l - expected)
+    assert err.max() <= 5e-4 and np.abs(out_r).max() <= 5e-4
+    assert np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(expected ** 2)) <= 1e-6
+
+
 def test_long_ir_partitioning(oracle):
     e = oracle.ConvolutionEngine()
     ir_len = BLOCK_SIZE + BLOCK_SIZE // 2

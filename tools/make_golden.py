@@ -49,7 +49,46 @@ def eq_case(name, frames, sid):
                         y_f32=np.stack([l, r]), y_f64=y64)
 
 
+def eq_ftz_case(name):
+    """The EQ in the three denormal modes (ohs_*_set_flush_denormals; tests/test_gpu_ftz.py): states decaying through the
+    denormal range, excited again later, plus denormal INPUT samples -- the oracle's f32 DF2T run under MXCSR = IEEE /
+    FTZ / FTZ | DAZ on the authoring machine.  Committed so that the GPU test does not depend on how the test box's CPU
+    (or its libc) treats MXCSR."""
+    from open_headstage_amd import BandConfig, FilterType, biquad_coefficients
+    bands = [BandConfig(FilterType.LowPass, 900.0, 0.6, 0.0, True), BandConfig(FilterType.Peak, 300.0, 2.0, 6.0, True),
+             BandConfig(FilterType.HighShelf, 6000.0, 0.7, -4.0, True)]
+    coeffs = np.stack([biquad_coefficients(b.filter_type, 48000.0, b.center_freq, b.q, b.gain_db) for b in bands])
+    n = 6000
+    x = np.zeros((2, n), np.float32)
+    x[0, 0], x[1, 3] = 3e-33, -7e-34
+    x[0, 3000:3010] = 1e-36
+    xin = np.zeros((2, 2000), np.float32)           # denormal input samples
+    xin[0, ::7] = np.float32(1.1e-38)
+    xin[1, ::5] = np.float32(-9e-39)
+    coeffs_in = coeffs.copy()
+    coeffs_in[1] = biquad_coefficients(FilterType.Peak, 48000.0, 300.0, 2.0, 12.0)
+    out = {"coeffs": coeffs, "coeffs_in": coeffs_in, "x": x, "x_in": xin, "call": np.int64(1000)}
+    for tag, xx, cc in (("y", x, coeffs), ("y_in", xin, coeffs_in)):
+        for mode in (0, 1, 2):
+            eq = orc.StereoParametricEQ(len(bands), 48000.0)
+            for i in range(len(bands)):
+                eq.set_band_coeffs(i, cc[i], True)
+            l, r = xx[0].copy(), xx[1].copy()
+            with orc.flush_denormals(mode):
+                for pos in range(0, xx.shape[1], 1000):         # state carried across calls, as in the test
+                    a, b = l[pos:pos + 1000].copy(), r[pos:pos + 1000].copy()
+                    eq.process_block(a, b)
+                    l[pos:pos + 1000], r[pos:pos + 1000] = a, b
+            out[f"{tag}_mode{mode}"] = np.stack([l, r])
+    # sanity of the generator itself: the modes really differ, IEEE really walks through denormals, FTZ never emits one
+    den = lambda y: int(((np.abs(y) > 0) & (np.abs(y) < np.float32(1.1754944e-38))).sum())      # noqa: E731
+    assert den(out["y_mode0"]) > 100 and den(out["y_mode1"]) == 0 and den(out["y_mode2"]) == 0
+    assert not np.array_equal(out["y_mode0"], out["y_mode1"]) and np.count_nonzero(out["y_in_mode2"]) == 0
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
 if __name__ == "__main__":
+    eq_ftz_case("eq_ftz_modes.npz")
     conv_case("conv_c1_128taps_1024.npz", 128, 1024, 100)      # BASELINE configs[0]
     conv_case("conv_c2_512taps_4096.npz", 512, 4096, 101)      # configs[1] shape
     conv_case("conv_p3_1300taps_4096.npz", 1300, 4096, 102)    # three partitions
