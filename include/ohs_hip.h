@@ -315,6 +315,15 @@ int  ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable);
 int  ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable);    /* see ohs_eq_set_exact_specials */
 int  ohs_batch_set_flush_denormals(ohs_batch *b, int mode);         /* see ohs_engine_set_flush_denormals (EQ and convolution) */
 int  ohs_batch_set_gain(ohs_batch *b, float gain);
+/* Which kernel plan serves calls in which every path has ONE partition (taps <= 512, BASELINE configs[2] / [4]):
+ *   1  block 512 / FFT 1024, overlap-add -- the reference's own blocking (convolution.rs:22-23); output bits do not depend
+ *      on where a signal is cut into calls, and are the ones tests/golden/p1_output_sha256.txt records
+ *   2  hop 1536 / FFT 2048, overlap-save -- a third less transform and product work per frame; equal to plan 1 up to f32
+ *      rounding (2-3e-7 relative RMS against the oracle, like every FFT path), not bit for bit, and the rounding depends
+ *      on where the calls cut the signal
+ *   0  the library's choice (default).
+ * Longer impulse responses, odd strides and the single-stream engine are not affected. */
+int  ohs_batch_set_conv_plan(ohs_batch *b, int plan);
 /* zero every stream's EQ state, history and overlap (IRs and EQ table kept).  Also the way back from a failed handle:
  * a HIP failure in the middle of a processing call leaves the per-stream state advanced for some time chunks only, so
  * the call joins its internal stream, returns OHS_ERR_HIP, and every later processing call on the handle returns
@@ -393,6 +402,7 @@ int  ohs_node_batch_set_speakers(ohs_node_batch *nb, const ohs_sofa *sofa, float
 int  ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const float coeffs[5], int enabled);
 int  ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable);
 int  ohs_node_batch_set_gain(ohs_node_batch *nb, float gain);
+int  ohs_node_batch_set_conv_plan(ohs_node_batch *nb, int plan);       /* see ohs_batch_set_conv_plan */
 int  ohs_node_batch_reset(ohs_node_batch *nb);
 /* ohs_batch_process_host for the whole job: h_in / h_out hold ALL streams_total streams (same planar layout and
  * strides); every device runs the three-stage host pipeline on its shard from a thread of its own.  Blocking.

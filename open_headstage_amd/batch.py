@@ -73,6 +73,11 @@ class BatchProcessor:
     def set_gain(self, gain: float) -> None:
         self._check(self._lib.ohs_batch_set_gain(self._h, float(gain)))
 
+    def set_conv_plan(self, plan: int) -> None:
+        """taps <= 512: 1 = block 512 / FFT 1024 (bit-stable), 2 = hop 1536 / FFT 2048, 0 = the library's choice
+        (ohs_batch_set_conv_plan)"""
+        self._check(self._lib.ohs_batch_set_conv_plan(self._h, int(plan)))
+
     def reset(self) -> None:
         self._check(self._lib.ohs_batch_reset(self._h))
 
@@ -240,6 +245,9 @@ class NodeBatchProcessor:
 
     def set_gain(self, gain: float) -> None:
         check(lib().ohs_node_batch_set_gain(self._h, float(gain)))
+
+    def set_conv_plan(self, plan: int) -> None:
+        check(lib().ohs_node_batch_set_conv_plan(self._h, int(plan)))
 
     def reset(self) -> None:
         check(lib().ohs_node_batch_reset(self._h))

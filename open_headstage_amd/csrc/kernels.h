@@ -171,6 +171,33 @@ int conv_p1_waves_per_cu();      // resident waves of k_conv_p1 per CU (one work
 hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
                            float2 *cd, hipStream_t st);
 
+// ---- P = 1, batch objects: overlap-save with a 2048-point window, hop 1536 (conv_os_kernels.hip) ------------------
+// Same inputs, outputs and state hand-over (merged overlap + last input block, the lazy state above) as k_conv_p1; a third
+// less transform and product work per output frame.  Results equal k_conv_p1's up to f32 rounding, not bit for bit.
+struct ConvOsArgs {
+    const float *in;
+    float *out;
+    long long in_stream_stride, in_ch_stride;       // floats; even (8-byte accesses)
+    long long out_stream_stride, out_ch_stride;
+    int n_blocks;               // 512-frame blocks of the call
+    int n_streams;
+    int chunks;                 // contiguous hop ranges per stream: 1, 2, 4 or 8 (all of a stream's in one workgroup)
+    const float4 *CD;           // [2 lo/hi][16][64] (C, D), paired layout, 1/2048 folded in (launch_os_tables)
+    const float2 *tw2048;       // [16][64] w2048^bin, paired layout
+    const float2 *tails;        // state in, per-path form (used when merged_in == nullptr)
+    const float2 *merged_in;    // state in, merged form
+    float2 *merged_out;         // state out
+    float *last_in;             // state out: the call's last 512 input frames
+    const float2 *tw;
+    float gain;
+    int fp_mode;
+};
+hipError_t launch_conv_p1_os(const ConvOsArgs &a, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// (C, D) lo / hi from the four impulse responses in the time domain: d_irt [4][512] floats, zero-padded
+hipError_t launch_os_tables(const float *d_irt, const float2 *tw, const float2 *tw2048, float4 *cd_out, hipStream_t st);
+void os_build_twiddles(float2 *out);    // host: [16][64]
+int conv_os_waves_per_cu();
+
 // ---- time-parallel long-IR path (any P, no per-path gating needed) ----------------------------
 // F: Z_t = FFT(x_l + j x_r) for every (stream, block) of the segment -> history ring
 // M: W_t = sum_i Z_{t-i} C_i + conj(Z_{t-i}[N-k]) D_i, register-tiled over (time x partition)

@@ -417,6 +417,7 @@ int ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const flo
 }
 int ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable) { NB_FOR_EACH(ohs_batch_set_eq_enabled(h, eq_enable)) }
 int ohs_node_batch_set_gain(ohs_node_batch *nb, float gain) { NB_FOR_EACH(ohs_batch_set_gain(h, gain)) }
+int ohs_node_batch_set_conv_plan(ohs_node_batch *nb, int plan) { NB_FOR_EACH(ohs_batch_set_conv_plan(h, plan)) }
 int ohs_node_batch_reset(ohs_node_batch *nb)
 {
     DeviceRestore restore;

@@ -56,6 +56,7 @@ int fail(int status, const std::string &msg)
 struct DeviceCtx {
     int device = -1;
     float2 *d_tw = nullptr;
+    float2 *d_tw2048 = nullptr; // k_conv_p1_os: w2048^bin in the paired layout
     int *d_pairs = nullptr;     // k_conv_tp_mac: leaders of the spectrum position pairs {b, mirror(b)}
     int n_pairs = 0;
     int num_cus = 256;
@@ -101,6 +102,16 @@ int get_ctx(int device, DeviceCtx **out)
         hipFree(c->d_tw);
         delete c;
         return fail(OHS_ERR_HIP, "hipMemcpy(twiddles) failed");
+    }
+    {
+        std::vector<float2> t2(NF);
+        os_build_twiddles(t2.data());
+        if (hipMalloc(&c->d_tw2048, NF * sizeof(float2)) != hipSuccess ||
+            hipMemcpy(c->d_tw2048, t2.data(), NF * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(c->d_tw);
+            delete c;
+            return fail(OHS_ERR_HIP, "w2048 table upload failed");
+        }
     }
     {
         int pairs[NF];
@@ -194,6 +205,12 @@ struct ConvState {
     bool lazy_ok = false, tails_lazy = false;
     float2 *d_merged = nullptr, *d_merged_alt = nullptr;    // [S][8][64]
     float *d_last_in = nullptr;                             // [S][2][512]
+    // overlap-save plan of the P = 1 path (conv_os_kernels.hip; batch objects): the impulse responses in the time domain
+    // (512 floats per path, zero-padded; valid while that path has one partition) and the (C, D) tables built from them
+    float *d_irt = nullptr;         // [4][512]
+    float4 *d_cd_os = nullptr;      // [2][1024]
+    bool cd_os_valid = false;
+    int conv_plan = 0;              // ohs_batch_set_conv_plan: 0 = the library's choice, 1 = block 512 / FFT 1024, 2 = hop 1536 / FFT 2048
     // ohs_*_set_speakers: what it last loaded into each path (a set_ir from anywhere else forgets it), so that a
     // change of the speaker angles re-loads only the paths whose impulse response really changed
     std::vector<float> spk_ir[4];
@@ -215,6 +232,9 @@ void conv_free(ConvState &c)
     if (c.d_merged) hipFree(c.d_merged);
     if (c.d_merged_alt) hipFree(c.d_merged_alt);
     if (c.d_last_in) hipFree(c.d_last_in);
+    if (c.d_irt) hipFree(c.d_irt);
+    if (c.d_cd_os) hipFree(c.d_cd_os);
+    c.d_irt = nullptr; c.d_cd_os = nullptr; c.cd_os_valid = false;
     c.d_merged = nullptr; c.d_merged_alt = nullptr; c.d_last_in = nullptr; c.tails_lazy = false; c.lazy_ok = false;
     c.d_cdm = nullptr; c.d_W = nullptr; c.d_W1 = nullptr;
     c.d_hist = nullptr; c.d_tails = nullptr; c.d_tails_alt = nullptr; c.d_cd = nullptr; c.d_chunk_tails = nullptr;
@@ -252,6 +272,10 @@ int conv_enable_lazy_state(ConvState &c)
     HIP_TRY(hipMalloc(&c.d_merged, c.S * 8 * 64 * sizeof(float2)));
     HIP_TRY(hipMalloc(&c.d_merged_alt, c.S * 8 * 64 * sizeof(float2)));
     HIP_TRY(hipMalloc(&c.d_last_in, c.S * 2 * BS * sizeof(float)));
+    HIP_TRY(hipMalloc(&c.d_irt, 4 * BS * sizeof(float)));
+    HIP_TRY(hipMemset(c.d_irt, 0, 4 * BS * sizeof(float)));        // (default paths: one all-zero partition)
+    HIP_TRY(hipMalloc(&c.d_cd_os, 2 * NF * sizeof(float4)));
+    c.cd_os_valid = false;
     c.lazy_ok = true;
     c.tails_lazy = false;
     return OHS_OK;
@@ -332,7 +356,12 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
                 src = d_ir;
             }
             HIP_TRY(launch_ir_spectrum(src, (int)len, P, nH, ctx->d_tw, st));
+            if (c.d_irt && P == 1) {        // the overlap-save plan builds its 2048-point tables from the taps themselves
+                HIP_TRY(hipMemsetAsync(c.d_irt + path * BS, 0, BS * sizeof(float), st));
+                HIP_TRY(hipMemcpyAsync(c.d_irt + path * BS, src, len * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
         }
+        if (c.d_irt && len == 0) HIP_TRY(hipMemsetAsync(c.d_irt + path * BS, 0, BS * sizeof(float), st));
         int rc = conv_grow_ring(c, P, st);
         if (rc) return rc;
         // one wait: the spectrum kernel has read d_ir, and nothing queued earlier on `st` still reads the
@@ -347,6 +376,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     c.d_H[path] = nH;
     c.P[path] = P;
     c.spk_set[path] = false;
+    c.cd_os_valid = false;
     c.cd_valid = false;
     c.cdm_valid = false;
     c.since[path] = 0;      // :135-137 that path's history is "all zero" again
@@ -414,6 +444,13 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
     return K;
 }
 
+// ohs_batch_set_conv_plan(0): which P = 1 plan the library picks by itself
+bool conv_plan_auto_is_os(size_t S, long long n_blocks)
+{
+    (void)S; (void)n_blocks;
+    return false;
+}
+
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
                 float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
                 bool allow_fast = true, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
@@ -437,6 +474,46 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             c.cd_valid = true;
         }
         const Tuning &tn = tuning();
+        // Two plans for this case (ohs_batch_set_conv_plan): block 512 / FFT 1024 overlap-add (k_conv_p1: the plan whose
+        // output bits tests/golden/p1_output_sha256.txt holds) and hop 1536 / FFT 2048 overlap-save (k_conv_p1_os: a third
+        // less transform and product work per frame; batch objects only -- it hands the lazy state over).
+        const bool os_ok = c.lazy_ok && c.d_irt && n_blocks >= 3 && c.xcd_n == 8 && tn.p1_xcd_n == 0 &&
+                           ((in_ss | in_cs | out_ss | out_cs) & 1) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7) == 0 &&
+                           (unsigned long long)n_blocks * BS + 1536ull < (1ull << 31);
+        const bool use_os = os_ok && (c.conv_plan == 2 || (c.conv_plan == 0 && conv_plan_auto_is_os(c.S, n_blocks)));
+        if (use_os) {
+            if (!c.cd_os_valid) {
+                hipError_t e = launch_os_tables(c.d_irt, ctx->d_tw, ctx->d_tw2048, c.d_cd_os, st);
+                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("os tables: ") + hipGetErrorString(e));
+                c.cd_os_valid = true;
+            }
+            // hop ranges per stream: 1, 2, 4 or 8 (all of a stream's in one workgroup of 8 waves); rounds of resident waves
+            // x hops per wave (+ 1: the tables and the first window), the smallest count of minimal cost
+            const long long R = (long long)ctx->num_cus * conv_os_waves_per_cu();
+            const long long H = ((long long)n_blocks * BS + 1535) / 1536;
+            int K = 1;
+            long long best = -1;
+            for (int k = 1; k <= 8 && k <= H; k *= 2) {
+                const long long cost = (((long long)c.S * k + R - 1) / R) * ((H + k - 1) / k + 1);
+                if (best < 0 || cost < best) { best = cost; K = k; }
+            }
+            ConvOsArgs o;
+            o.in = in; o.out = out;
+            o.in_stream_stride = in_ss; o.in_ch_stride = in_cs; o.out_stream_stride = out_ss; o.out_ch_stride = out_cs;
+            o.n_blocks = n_blocks; o.n_streams = (int)c.S; o.chunks = K;
+            o.CD = c.d_cd_os; o.tw2048 = ctx->d_tw2048;
+            o.tails = c.d_tails; o.merged_in = c.tails_lazy ? c.d_merged : nullptr;
+            o.merged_out = c.d_merged_alt; o.last_in = c.d_last_in;
+            o.tw = ctx->d_tw; o.gain = gain; o.fp_mode = c.fp_mode;
+            hipError_t e = launch_conv_p1_os(o, st, ev_start, ev_stop);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1_os launch: ") + hipGetErrorString(e));
+            std::swap(c.d_merged, c.d_merged_alt);
+            c.tails_lazy = true;
+            c.cnt += (unsigned long long)n_blocks;
+            for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;
+            return OHS_OK;
+        }
         const long long target_override = tn.p1_target_waves;
         int xcd_lo = c.xcd_lo, xcd_n = c.xcd_n;
         if (tn.p1_xcd_n > 0) { xcd_lo = tn.p1_xcd_lo; xcd_n = tn.p1_xcd_n; }
@@ -2070,6 +2147,14 @@ int ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     b->eq.exact_specials = enable != 0;
+    return OHS_OK;
+}
+
+int ohs_batch_set_conv_plan(ohs_batch *b, int plan)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    if (plan < 0 || plan > 2) return fail(OHS_ERR_INVALID_ARG, "plan must be 0 (library's choice), 1 (block 512) or 2 (hop 1536)");
+    b->conv.conv_plan = plan;
     return OHS_OK;
 }
 

@@ -1,0 +1,122 @@
+"""The overlap-save plan of the one-partition batch path (ohs_batch_set_conv_plan(2): hop 1536 / FFT 2048,
+csrc/conv_os_kernels.hip) against the oracle, the f64 ground truth and the block-512 plan: every hop-count remainder (the
+last window holds 512, 1024 or 1536 new frames), every chunk count the launcher picks (1, 2, 4, 8 hop ranges per stream),
+in place, with the EQ in front, across calls that alternate between the two plans (they hand the same state over: the
+merged overlap and the last input block), and across a per-path set_ir in mid-stream."""
+import numpy as np
+import pytest
+
+from tests.util import assert_parity, rms_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(ohs, synth, S, plan, taps=512, eq=False, gain=1.0):
+    bp = ohs.BatchProcessor(S, num_bands=10)
+    irs = synth.hrir_set(taps)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    if eq:
+        for i, b in enumerate(synth.eq_table()):
+            bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(eq)
+    bp.set_gain(gain)
+    bp.set_conv_plan(plan)
+    return bp, irs
+
+
+@pytest.mark.parametrize("n_blocks", [3, 4, 5, 6, 7, 8, 9, 31, 66])
+def test_overlap_save_plan_matches_the_oracle_and_f64(oracle, n_blocks):
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    S, calls = 5, 3
+    bp, irs = _make(ohs, synth, S, 2, gain=0.9)
+    x = synth.white_noise(range(S), n_blocks * 512 * calls)
+    outs = []
+    for c in range(calls):
+        xt = torch.from_numpy(np.ascontiguousarray(x[:, :, c * n_blocks * 512:(c + 1) * n_blocks * 512])).cuda()
+        bp.process(xt, out=xt)          # in place
+        outs.append(xt.cpu().numpy())
+    g = np.concatenate(outs, axis=2)
+    for s in range(S):
+        eo = oracle.ConvolutionEngine()
+        for p in range(4):
+            eo.set_ir(p, irs[p])
+        ref = np.stack(eo.process_block(x[s, 0], x[s, 1])) * np.float32(0.9)
+        assert_parity(g[s], ref, f"{n_blocks} blocks x {calls} calls, stream {s}")
+    yl, yr = oracle.binaural_f64(x[0, 0], x[0, 1], irs)
+    a, r = rms_err(g[0], 0.9 * np.stack([yl, yr])[:, :g.shape[2]])
+    print(f"hop-1536 plan vs f64 direct convolution: {r:.2e}")
+    assert r <= 1e-6
+
+
+@pytest.mark.parametrize("S,n_blocks,want_chunks", [(2048, 12, 1), (600, 40, 2), (300, 60, 4), (37, 100, 8)])
+def test_every_chunk_count_of_the_launcher(S, n_blocks, want_chunks):
+    """against the block-512 plan on all streams (both are 2-3e-7 from the truth), in place and out of place"""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    dev = torch.device("cuda:0")
+    a, _ = _make(ohs, synth, S, 1)
+    b, _ = _make(ohs, synth, S, 2)
+    for call in range(2):
+        x = synth.white_noise_torch(9 * call, S, n_blocks * 512, dev)
+        ya = torch.empty_like(x)
+        a.process(x, out=ya)
+        yb = x.clone()
+        b.process(yb, out=yb)
+        torch.cuda.synchronize()
+        d = (ya - yb).double()
+        rel = float(torch.sqrt((d * d).mean()) / torch.sqrt((ya.double() ** 2).mean()))
+        per_stream = torch.sqrt((d * d).mean(dim=(1, 2))) / torch.sqrt((ya.double() ** 2).mean(dim=(1, 2)))
+        assert rel <= 6e-7 and float(per_stream.max()) <= 1e-6, (call, rel, float(per_stream.max()))
+
+
+def test_the_two_plans_hand_the_same_state_over_and_a_midstream_set_ir(oracle):
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    S = 4
+    bp, irs = _make(ohs, synth, S, 0, eq=True, gain=0.7)
+    bands = synth.eq_table()
+    engs, eqs = [], []
+    for s in range(S):
+        eo = oracle.ConvolutionEngine()
+        for p in range(4):
+            eo.set_ir(p, irs[p])
+        qo = oracle.StereoParametricEQ(len(bands), synth.FS)
+        for i, b in enumerate(bands):
+            qo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), b.enabled)
+        engs.append(eo); eqs.append(qo)
+    seq = [(2, 7), (1, 5), (2, 4), (2, 10), (1, 3), (2, 68)]       # (plan, blocks)
+    for k, (plan, nb) in enumerate(seq):
+        if k == 3:      # a shorter response on one path in mid-stream: the lazy state is materialised with the OLD spectra
+            h = irs[1][:200]
+            bp.set_ir(1, h)
+            for e in engs:
+                e.set_ir(1, h)
+        bp.set_conv_plan(plan)
+        x = synth.white_noise(range(10 * k, 10 * k + S), nb * 512)
+        y = bp.process(torch.from_numpy(x).cuda()).cpu().numpy()
+        for s in range(S):
+            l, r = x[s, 0].copy(), x[s, 1].copy()
+            oracle.chain_process(engs[s], eqs[s], l, r, eq_enable=True, gain=0.7)
+            assert_parity(y[s], np.stack([l, r]), f"call {k} (plan {plan}, {nb} blocks), stream {s}")
+
+
+def test_plan_argument_and_fallbacks():
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    bp, irs = _make(ohs, synth, 2, 2)
+    with pytest.raises(ohs.OhsError):
+        bp.set_conv_plan(3)
+    # two blocks are fewer than a hop needs, odd strides cannot take 8-byte accesses: the block-512 kernel serves them
+    ref, _ = _make(ohs, synth, 2, 1)
+    x = torch.from_numpy(synth.white_noise(range(2), 2 * 512)).cuda()
+    assert torch.equal(bp.process(x).view(torch.int32), ref.process(x).view(torch.int32))
+    # longer responses are not this plan's business
+    bp.set_ir(0, synth.hrir_set(1300)[0]); ref.set_ir(0, synth.hrir_set(1300)[0])
+    x = torch.from_numpy(synth.white_noise(range(5, 7), 12 * 512)).cuda()
+    assert torch.equal(bp.process(x).view(torch.int32), ref.process(x).view(torch.int32))
