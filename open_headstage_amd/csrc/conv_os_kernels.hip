@@ -39,7 +39,11 @@ namespace ohs {
 #undef OHS_OS_PREFETCH
 #define OHS_OS_PREFETCH 1
 #endif
-constexpr int kOsWaves = 8;             // waves per workgroup = per CU, two per SIMD
+#if !defined(OHS_OS_WAVES) || !defined(OHS_EXPERIMENTS)
+#undef OHS_OS_WAVES
+#define OHS_OS_WAVES 8
+#endif
+constexpr int kOsWaves = OHS_OS_WAVES;  // waves per workgroup = per CU (8: two per SIMD, 12: three)
 constexpr int kOsHop = 1536;
 // LDS: twiddle tables + (C, D) lo / hi [2][16][64] float4 + w2048 [16][64] float2 + one FFT slab per wave
 constexpr size_t kOsCdComplex = 2 * 2 * kFft;      // float4 = 2 float2
@@ -228,46 +232,53 @@ __device__ __forceinline__ void os_hop(const ConvOsArgs &A, const OsWave &w, int
     os_fft_fwd(O, w.lds, w.tab, lane, plan);
     __builtin_amdgcn_sched_barrier(0);
 
-    // radix-2 step, spectral product, radix-2 step back -- per paired register, mirrors from the lane's own registers.
-    // The 1024-mirror of a register of slots {0, 1} lies in slots {0, 1}, of {2, 3} in {2, 3} (wave_fft.hpp:
-    // paired_mirror_reg), so the 16 registers go through in two halves of 8: the 2048-point spectrum is never alive
-    // as a whole (64 VGPRs less).
+    // radix-2 step, spectral product, radix-2 step back -- per paired register, mirrors from the lane's own registers
+    // (wave_fft.hpp: paired_mirror_reg).  The 2048-point spectrum is never alive as a whole: slots {0, 1} mirror each
+    // other register by register (r <-> 7 - r), so they go through as four pairs; slots {2, 3} mirror among themselves
+    // (lane 32 holds the self-mirrored groups there) and go through as one set of eight.
     const bool lane32 = lane == 32;
+    auto product = [&](int i, float2 xl, float2 xh, float2 ml, float2 mh, float2 tw) {
+        float2 c, d;
+        lds_ld2(w.cd + i * 64 + lane, c, d);
+        float2 wl, wh;
+        wl.x = fmaf(ml.y, d.y, fmaf(ml.x, d.x, fmaf(-xl.y, c.y, xl.x * c.x)));
+        wl.y = fmaf(-ml.y, d.x, fmaf(ml.x, d.y, fmaf(xl.y, c.x, xl.x * c.y)));
+        lds_ld2(w.cd + kFft + i * 64 + lane, c, d);
+        wh.x = fmaf(mh.y, d.y, fmaf(mh.x, d.x, fmaf(-xh.y, c.y, xh.x * c.x)));
+        wh.y = fmaf(-mh.y, d.x, fmaf(mh.x, d.y, fmaf(xh.y, c.x, xh.x * c.y)));
+        E[i] = cadd(wl, wh);
+        O[i] = cmulc(csub(wl, wh), tw);
+    };
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        float2 Xl[8], Xh[8], tw[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tw[j] = lds_ld(&w.tw2[(8 * hf + j) * 64 + lane]);
+    for (int r = 0; r < 4; ++r) {
+        const int i = r, m = 7 - r;
+        const float2 twi = lds_ld(&w.tw2[i * 64 + lane]), twm = lds_ld(&w.tw2[m * 64 + lane]);
+        const float2 ti = cmul(O[i], twi), tm = cmul(O[m], twm);
+        const float2 xli = cadd(E[i], ti), xhi = csub(E[i], ti), xlm = cadd(E[m], tm), xhm = csub(E[m], tm);
+        // Z[2048 - k] = hi at the 1024-mirror of k;  Z[2048 - (k + 1024)] = lo at the 1024-mirror of k
+        product(i, xli, xhi, xhm, xlm, twi);
+        product(m, xlm, xhm, xhi, xli, twm);
+    }
+    {
+        float2 Xl[8], Xh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float2 t = cmul(O[8 * hf + j], tw[j]);
-            Xl[j] = cadd(E[8 * hf + j], t);
-            Xh[j] = csub(E[8 * hf + j], t);
+            const float2 t = cmul(O[8 + j], lds_ld(&w.tw2[(8 + j) * 64 + lane]));
+            Xl[j] = cadd(E[8 + j], t);
+            Xh[j] = csub(E[8 + j], t);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int i = 8 * hf + j, g = i >> 2, r = i & 3;
-            const int mo = paired_mirror_reg(g, r, false) - 8 * hf, ms = paired_mirror_reg(g, r, true) - 8 * hf;
-            // Z[2048 - k] = hi at the 1024-mirror of k;  Z[2048 - (k + 1024)] = lo at the 1024-mirror of k
-            float2 ml = Xh[mo], mh = Xl[mo];
-            if (g >= 2) {       // lane 32's slots 2, 3 hold self-mirrored groups (bins 128 + 256 r; 0, 256, 512, 768)
-                ml = make_float2(lane32 ? Xh[ms].x : ml.x, lane32 ? Xh[ms].y : ml.y);
-                mh = make_float2(lane32 ? Xl[ms].x : mh.x, lane32 ? Xl[ms].y : mh.y);
-            }
+            const int i = 8 + j, g = i >> 2, r = i & 3;
+            const int mo = paired_mirror_reg(g, r, false) - 8, ms = paired_mirror_reg(g, r, true) - 8;
+            // lane 32's slots 2, 3 hold self-mirrored groups (bins 128 + 256 r; 0, 256, 512, 768)
+            float2 ml = make_float2(lane32 ? Xh[ms].x : Xh[mo].x, lane32 ? Xh[ms].y : Xh[mo].y);
+            float2 mh = make_float2(lane32 ? Xl[ms].x : Xl[mo].x, lane32 ? Xl[ms].y : Xl[mo].y);
             if (i == 12) {      // bin 0 (lane 32): bins 0 and 1024 mirror themselves
                 ml = make_float2(lane32 ? Xl[j].x : ml.x, lane32 ? Xl[j].y : ml.y);
                 mh = make_float2(lane32 ? Xh[j].x : mh.x, lane32 ? Xh[j].y : mh.y);
             }
-            float2 c, d;
-            lds_ld2(w.cd + i * 64 + lane, c, d);
-            float2 wl, wh;
-            wl.x = fmaf(ml.y, d.y, fmaf(ml.x, d.x, fmaf(-Xl[j].y, c.y, Xl[j].x * c.x)));
-            wl.y = fmaf(-ml.y, d.x, fmaf(ml.x, d.y, fmaf(Xl[j].y, c.x, Xl[j].x * c.y)));
-            lds_ld2(w.cd + kFft + i * 64 + lane, c, d);
-            wh.x = fmaf(mh.y, d.y, fmaf(mh.x, d.x, fmaf(-Xh[j].y, c.y, Xh[j].x * c.x)));
-            wh.y = fmaf(-mh.y, d.x, fmaf(mh.x, d.y, fmaf(Xh[j].y, c.x, Xh[j].x * c.y)));
-            E[i] = cadd(wl, wh);
-            O[i] = cmulc(csub(wl, wh), tw[j]);
+            product(i, Xl[j], Xh[j], ml, mh, lds_ld(&w.tw2[i * 64 + lane]));
         }
     }
 #if OHS_OS_PREFETCH == 0
@@ -404,7 +415,7 @@ int conv_os_waves_per_cu() { return kOsWaves; }
 hipError_t launch_conv_p1_os(const ConvOsArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (a.n_blocks <= 0 || a.n_streams <= 0) return hipErrorInvalidValue;
-    if (!(a.chunks == 1 || a.chunks == 2 || a.chunks == 4 || a.chunks == 8)) return hipErrorInvalidValue;
+    if (a.chunks < 1 || kOsWaves % a.chunks != 0) return hipErrorInvalidValue;      // all of a stream's chunks in one workgroup
     if ((unsigned long long)a.n_blocks * kBlock + kOsHop >= (1ull << 31)) return hipErrorInvalidValue;     // 32-bit frame offsets
     if (!a.merged_out || !a.last_in) return hipErrorInvalidValue;       // batch objects only: the lazy state
     // 8-byte accesses: even strides, 8-byte aligned bases

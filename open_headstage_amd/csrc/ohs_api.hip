@@ -488,13 +488,14 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("os tables: ") + hipGetErrorString(e));
                 c.cd_os_valid = true;
             }
-            // hop ranges per stream: 1, 2, 4 or 8 (all of a stream's in one workgroup of 8 waves); rounds of resident waves
+            // hop ranges per stream: a divisor of the workgroup's wave count (all of a stream's in one workgroup); rounds of resident waves
             // x hops per wave (+ 1: the tables and the first window), the smallest count of minimal cost
             const long long R = (long long)ctx->num_cus * conv_os_waves_per_cu();
             const long long H = ((long long)n_blocks * BS + 1535) / 1536;
             int K = 1;
             long long best = -1;
-            for (int k = 1; k <= 8 && k <= H; k *= 2) {
+            for (int k = 1; k <= conv_os_waves_per_cu() && k <= H; ++k) {
+                if (conv_os_waves_per_cu() % k) continue;       // (all of a stream's chunks in one workgroup)
                 const long long cost = (((long long)c.S * k + R - 1) / R) * ((H + k - 1) / k + 1);
                 if (best < 0 || cost < best) { best = cost; K = k; }
             }
