@@ -849,7 +849,24 @@ def main() -> int:
             torch.cuda.synchronize()
             dt = sa.elapsed_time(sb) * 1e-3 / 6
             eb2, cb2 = bp2.kernel_bytes(n_blocks)
+            # the same with the overlap-save plan of the one-partition convolution (ohs_batch_set_conv_plan(2); not bit-stable
+            # across call boundaries, hence opt-in): profiles/r04_conv_plan_ab_*.txt
+            dt_os = None
+            try:
+                bp2.set_conv_plan(2)
+                for _ in range(2):
+                    bp2.process(x2, out=y2)
+                torch.cuda.synchronize()
+                sa.record()
+                for _ in range(6):
+                    bp2.process(x2, out=y2)
+                sb.record()
+                torch.cuda.synchronize()
+                dt_os = sa.elapsed_time(sb) * 1e-3 / 6
+            except Exception:       # noqa: BLE001
+                pass
             sat.append({"streams": S2, "ms_per_step": round(dt * 1e3, 4), "how": "6 steps after 3, HIP events",
+                        "ms_per_step_conv_plan_2": None if dt_os is None else round(dt_os * 1e3, 4),
                         "Msamples_s": round(S2 * frames / dt / 1e6, 1),
                         "hbm_frac_8d_model": round(bp2.algorithmic_bytes(n_blocks) / dt / 1e9 / HBM_PEAK_GBS, 5),
                         "hbm_frac_design_bytes": round((eb2 + cb2) / dt / 1e9 / HBM_PEAK_GBS, 5)})

@@ -312,6 +312,12 @@ __device__ __forceinline__ void conv_general_body(const ConvGeneralArgs &A, cons
     }
 }
 
+// (256 VGPRs + 44 AGPRs, one wave per SIMD: the accumulators of both ear pairs, the block's spectrum, its mirror and four
+// spectra of a partition are alive together, and hipcc parks some of them in accumulation registers -- register moves, no
+// scratch memory.  Since round 4 this kernel is a FALLBACK: long batch calls behind a per-path set_ir go through the
+// time-parallel kernels + k_conv_tp_old, real-time sized calls through k_engine_call / k_engine_resident; it serves
+// engine calls of a few blocks on the multi-kernel path and batch calls too short for the other plans, and it remains
+// the on-GPU cross-check of the fast paths.  Its time is not on any measured path.)
 __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
 {
     ohs_set_fp_mode(A.fp_mode);
@@ -337,6 +343,14 @@ __global__ __launch_bounds__(64) void k_conv_general(const ConvGeneralArgs A)
 //   k_engine_resident : 4 hand-over areas (it serves calls of up to kResidentMaxBlocks blocks, each with a pair of
 //                       waves) + the overlaps + partition 0 of the four paths' spectra
 constexpr size_t kEngineLdsBytes = (kTabComplex + 8 * (size_t)kWaveLdsComplex + 9 * (size_t)kFft) * sizeof(float2);
+// a value the compiler must (re)compute where it is used: keeps loop-invariant per-thread addresses of the resident
+// kernel's cold paths from being hoisted out of the call loop, where they would sit in scratch memory across the body
+template <class T>
+__device__ __forceinline__ T here(T v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
 #define OHS_DBG_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // RESIDENT (k_engine_resident): `cache` holds, across calls, the overlaps the engine carries ([16][64], kept up to
 // date here) and partition 0 of the four paths' spectra ([4][1024], filled when the kernel starts): the 34 loads
@@ -352,12 +366,12 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     // 1. frames already waiting in the output FIFO: pop what this call takes, slide the rest down
     if (wave == 0 && E.out_len > 0 && E.emit) {
         const int take = E.out_len < E.n ? E.out_len : E.n;
-        for (int i = lane; i < take; i += 64) {
+        for (int i = here(lane); i < take; i += 64) {
             IO::st(E.host_l + i, E.out_fifo[i] * E.gain_pop);
             IO::st(E.host_r + i, E.out_fifo[E.out_cap + i] * E.gain_pop);
         }
         for (int base = E.n; base < E.out_len; base += 64) {      // ascending, read-then-write per 64
-            const int i = base + lane;
+            const int i = base + here(lane);
             float l = 0.f, r = 0.f;
             if (i < E.out_len) { l = E.out_fifo[i]; r = E.out_fifo[E.out_cap + i]; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -584,6 +598,12 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     __shared__ unsigned s_eq_version;
     __shared__ __attribute__((aligned(16))) unsigned s_eq_blk[(sizeof(RtMailbox) - offsetof(RtMailbox, eq_version) + 3) / 4];
     __shared__ __attribute__((aligned(16))) unsigned s_args[(sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4];
+    // thread 0's bookkeeping lives in LDS, not in registers: the call body below takes every one of the 256 VGPRs two
+    // waves per SIMD leave, and anything alive across it (five 64-bit time stamps, the doorbell value, the host
+    // pointers) was spilled to scratch memory and reloaded on the call's critical path
+    __shared__ unsigned long long s_st[5];      // doorbell seen, inputs visible, body done, stores drained; shader clock
+    __shared__ unsigned s_last;                 // the doorbell value already served
+    __shared__ const float *s_host_src[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     fill_twiddle_tables(tab, tw, threadIdx.x, 512);
     {
@@ -604,12 +624,13 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     for (int p = 0; p < 4; ++p)
         for (int i = threadIdx.x; i < kFft; i += 512) cache[kFft + p * kFft + i] = A.H[p][i];
     __syncthreads();
-    const float *const host_src_l = E.src_l, *const host_src_r = E.src_r;
-    unsigned last = first_seq;              // the doorbell value already served
+    if (threadIdx.x == 0) { s_host_src[0] = E.src_l; s_host_src[1] = E.src_r; s_last = first_seq; }
+    __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) {
             unsigned cmd = 0;
             unsigned long long idle = 0;
+            unsigned last = s_last;
             for (;;) {
                 // {seq, n, gain, stop}: one aligned 16-byte read, so the arguments arrive with their doorbell.
                 // TWO reads are kept in flight (a new one is issued while the older one is awaited), so the word is
@@ -667,7 +688,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
                     : "memory", "scc", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
                 if (w.w) break;                                         // stop
                 if (w.x != last) {
-                    last = w.x; cmd = 1;
+                    last = w.x; s_last = last; cmd = 1;
                     // w.y = n (bits 0..15) | EQ block version, low 15 bits (16..30) | run the EQ (31)
                     s_n = (int)(w.y & 0xffffu); s_eq = (int)(w.y >> 31); s_eq_ver_call = (w.y >> 16) & 0x7fffu;
                     s_gain = __uint_as_float(w.z);
@@ -681,8 +702,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         }
         __syncthreads();
         if (s_cmd == 0) break;              // uniform: s_cmd is read by every thread after the barrier
-        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, ck0 = 0;
-        if (threadIdx.x == 0) { st0 = __builtin_amdgcn_s_memrealtime(); ck0 = __builtin_amdgcn_s_memtime(); }
+        if (threadIdx.x == 0) { s_st[0] = __builtin_amdgcn_s_memrealtime(); s_st[4] = __builtin_amdgcn_s_memtime(); }
         // the host's writes (input frames) precede its doorbell store; make them visible to this CU
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         if (s_eq) {
@@ -695,7 +715,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             if (s_eq_ver_call != (s_eq_version & 0x7fffu) || s_eq_version == 0xffffffffu) {      // uniform
                 __syncthreads();
                 const unsigned *src = reinterpret_cast<const unsigned *>(&mb->eq_version);
-                for (int i = threadIdx.x; i < eq_words; i += 512) s_eq_blk[i] = src[i];
+                for (int i = here((int)threadIdx.x); i < eq_words; i += 512) s_eq_blk[i] = src[i];
                 __syncthreads();
                 if (threadIdx.x == 0) s_eq_version = s_eq_blk[0];
                 __syncthreads();
@@ -705,18 +725,20 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             float *const buf = eqb->eq_buf;
             const long long stride = eqb->eq_buf_stride;
             const int n = s_n;
+            const int tix = here((int)threadIdx.x);
             // eight PCIe reads per thread in flight (clamped index instead of a branch around each load: one round
             // trip for a 1024-frame block, not one per loop iteration)
+            const float *const host_src_l = s_host_src[0], *const host_src_r = s_host_src[1];
             for (int base = 0; base < n; base += 4 * 512) {
                 float l[4], r[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int i = base + k * 512 + (int)threadIdx.x, ic = i < n ? i : n - 1;
+                    const int i = base + k * 512 + tix, ic = i < n ? i : n - 1;
                     l[k] = host_src_l[ic]; r[k] = host_src_r[ic];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int i = base + k * 512 + (int)threadIdx.x;
+                    const int i = base + k * 512 + tix;
                     if (i < n) { buf[i] = l[k]; buf[stride + i] = r[k]; }
                 }
             }
@@ -732,12 +754,12 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         }
         if (threadIdx.x == 0) {             // this call's FIFO arithmetic (convolution.rs:149-163)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            st1 = __builtin_amdgcn_s_memrealtime();
+            s_st[1] = __builtin_amdgcn_s_memrealtime();
             if (s_eq) {
                 const RtMailbox *const eqb2 = reinterpret_cast<const RtMailbox *>(reinterpret_cast<const char *>(s_eq_blk) -
                                                                                    offsetof(RtMailbox, eq_version));
                 E.src_l = eqb2->eq_buf; E.src_r = eqb2->eq_buf + eqb2->eq_buf_stride;
-            } else { E.src_l = host_src_l; E.src_r = host_src_r; }
+            } else { E.src_l = s_host_src[0]; E.src_r = s_host_src[1]; }
             const int n = s_n;
             const int k = (E.in_len + n) / kBlock;  // <= kResidentMaxBlocks: the host routes longer calls elsewhere
             A.n_blocks = k;
@@ -755,7 +777,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             uniform_copy(Er, E);
             engine_call_body<false, true>(Ar, Er, tab, slabs, zx, cache, wave, lane, 8, mb->stamps);
         }
-        if (threadIdx.x == 0) st2 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) s_st[2] = __builtin_amdgcn_s_memrealtime();
         // publish: every wave's stores (outputs to host memory, state to device memory) drained, then one
         // system-scope release in front of the flag.  (Tried: system-scope `sc0 sc1` loads / stores for the
         // host-visible frames in place of both fences -- engine_call_body<true> -- no faster per call, and not
@@ -763,16 +785,16 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            st3 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
             // diagnostics (read by ohs_engine_debug_rt_stamps after the call): doorbell seen, inputs visible,
             // body done, stores drained, released -- written BEFORE the flag, so they are in place when it is seen
-            mb->stamps[0] = st0; mb->stamps[1] = st1; mb->stamps[2] = st2; mb->stamps[3] = st3; mb->stamps[4] = st4;
-            mb->stamps[5] = __builtin_amdgcn_s_memtime() - ck0;         // shader-clock cycles over the same span
+            mb->stamps[0] = s_st[0]; mb->stamps[1] = s_st[1]; mb->stamps[2] = s_st[2]; mb->stamps[3] = st3; mb->stamps[4] = st4;
+            mb->stamps[5] = __builtin_amdgcn_s_memtime() - s_st[4];     // shader-clock cycles over the same span
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            __hip_atomic_store(&mb->done, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->done, s_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             // advance the counters for the next call
             const int k = A.n_blocks;
             A.cnt += (unsigned long long)k;
