@@ -599,10 +599,10 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     __shared__ __attribute__((aligned(16))) unsigned s_eq_blk[(sizeof(RtMailbox) - offsetof(RtMailbox, eq_version) + 3) / 4];
     __shared__ __attribute__((aligned(16))) unsigned s_args[(sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4];
     // thread 0's bookkeeping lives in LDS, not in registers: the call body below takes every one of the 256 VGPRs two
-    // waves per SIMD leave, and anything alive across it (five 64-bit time stamps, the doorbell value, the host
-    // pointers) was spilled to scratch memory and reloaded on the call's critical path
+    // waves per SIMD leave, and what was alive across it (five 64-bit time stamps, the host pointers) was spilled to
+    // scratch memory and reloaded on the call's critical path.  (The doorbell value stays in a register: with it in LDS as
+    // well the kernel never answered its first call on the GPU -- not understood, tools/rt_probe.py reproduces it.)
     __shared__ unsigned long long s_st[5];      // doorbell seen, inputs visible, body done, stores drained; shader clock
-    __shared__ unsigned s_last;                 // the doorbell value already served
     __shared__ const float *s_host_src[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     fill_twiddle_tables(tab, tw, threadIdx.x, 512);
@@ -624,13 +624,13 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     for (int p = 0; p < 4; ++p)
         for (int i = threadIdx.x; i < kFft; i += 512) cache[kFft + p * kFft + i] = A.H[p][i];
     __syncthreads();
-    if (threadIdx.x == 0) { s_host_src[0] = E.src_l; s_host_src[1] = E.src_r; s_last = first_seq; }
+    if (threadIdx.x == 0) { s_host_src[0] = E.src_l; s_host_src[1] = E.src_r; }
     __syncthreads();
+    unsigned last = first_seq;              // the doorbell value already served
     for (;;) {
         if (threadIdx.x == 0) {
             unsigned cmd = 0;
             unsigned long long idle = 0;
-            unsigned last = s_last;
             for (;;) {
                 // {seq, n, gain, stop}: one aligned 16-byte read, so the arguments arrive with their doorbell.
                 // TWO reads are kept in flight (a new one is issued while the older one is awaited), so the word is
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
                     : "memory", "scc", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
                 if (w.w) break;                                         // stop
                 if (w.x != last) {
-                    last = w.x; s_last = last; cmd = 1;
+                    last = w.x; cmd = 1;
                     // w.y = n (bits 0..15) | EQ block version, low 15 bits (16..30) | run the EQ (31)
                     s_n = (int)(w.y & 0xffffu); s_eq = (int)(w.y >> 31); s_eq_ver_call = (w.y >> 16) & 0x7fffu;
                     s_gain = __uint_as_float(w.z);
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             mb->stamps[0] = s_st[0]; mb->stamps[1] = s_st[1]; mb->stamps[2] = s_st[2]; mb->stamps[3] = st3; mb->stamps[4] = st4;
             mb->stamps[5] = __builtin_amdgcn_s_memtime() - s_st[4];     // shader-clock cycles over the same span
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            __hip_atomic_store(&mb->done, s_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->done, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             // advance the counters for the next call
             const int k = A.n_blocks;
             A.cnt += (unsigned long long)k;
