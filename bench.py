@@ -595,14 +595,22 @@ def main() -> int:
     y = torch.empty_like(x)
     torch.cuda.synchronize()
 
+    # The steps are queued on a stream of their own, not on torch's default (NULL) stream: the NULL stream synchronises
+    # implicitly with every blocking stream of the process and its launches cost more (the same job through
+    # ohs_node_batch_*, whose devices have their own streams, ran 1.9 % faster than this loop did on the NULL stream:
+    # profiles/r04_v1_bench.json).  torch.cuda.synchronize() on both sides of the timed region waits for every stream.
+    proc_stream = torch.cuda.Stream(device=device)
+    proc_stream.wait_stream(torch.cuda.current_stream(device))
+    hs = proc_stream.cuda_stream
+
     # --pipelined: consecutive steps through ohs_batch_process_deferred (the next step's EQ starts while this
     # step's last convolution chunk finishes); the default is the strict call.
     def step():
-        bp.process(x, out=y, deferred=args.pipelined)
+        bp.process(x, out=y, hip_stream=hs, deferred=args.pipelined)
 
     for _ in range(args.warmup):
         step()
-    bp.join()
+    bp.join(hs)
     torch.cuda.synchronize()
 
     bp.set_profiling(True)
@@ -611,7 +619,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    bp.join()
+    bp.join(hs)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
