@@ -61,7 +61,7 @@ STREAMS_PER_GPU = 256
 TAPS = 512
 FS = 48000.0
 NOMINAL_CLOCK_GHZ = 2.4        # same guide: max clock; only used to express the EQ's ns per sample in cycles
-EQ_ISSUE_FLOOR_CYCLES = 26.7   # 6.5 VALU per sample x 4.1 cycles per instruction of a lone wave (DESIGN.md 4.4)
+EQ_ISSUE_FLOOR_CYCLES = 26.7   # 6.5 VALU per sample x 4.1 cycles per instruction of a lone wave (DESIGN.md 4.5)
 
 
 def cpu_info():

@@ -1,5 +1,5 @@
 // conv_mac_kernels.hip -- long impulse responses: the spectral multiply-accumulate of the time-parallel
-// path (DESIGN.md 4.3).  Separate translation unit because it wants hipcc's SLP vectoriser (packed f32
+// path (DESIGN.md 4.4).  Separate translation unit because it wants hipcc's SLP vectoriser (packed f32
 // MACs on pairs of accumulators), while the FFT kernels of conv_kernels.hip are built with
 // -fno-slp-vectorize: there the vectoriser pairs the real parts of two different complex values and
 // pays for it with ~30 % register moves (k_conv_p1: 168 -> 124 VGPRs, 0.97 -> 0.87 ms without it).

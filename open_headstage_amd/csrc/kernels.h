@@ -124,7 +124,7 @@ hipError_t launch_engine_resident(RtMailbox *mb_dev, const float2 *tw, unsigned 
 // with its own L2); a kernel confined to the XCDs [lo, lo + n) is launched with xcd_grid(workgroups, n) workgroups, those
 // on other XCDs return at once and the rest renumber themselves ((b >> 3) * n + (b & 7) - lo).  ohs_batch_process gives
 // the EQ and the overlapped convolution disjoint XCD sets: an EQ wave saturates the vector unit of its SIMD, and a
-// convolution workgroup that shares a CU with one waits for its starved waves.
+// convolution workgroup that shares a CU with one waits for its starved waves (LABNOTES.md, "What sharing a CU is worth").
 inline unsigned xcd_grid(unsigned workgroups, int xcd_n)
 {
     return xcd_n == 8 ? workgroups : ((workgroups + (unsigned)xcd_n - 1) / (unsigned)xcd_n) * 8u;

@@ -23,7 +23,7 @@ struct Tuning {
     int p1_weights[4] = {1425, 1128, 825, 622};     // chunk length by the age rank of the wave that runs it
     int p1_lazy_state = 1;                  // batch objects leave the merged overlap + last input block behind
     int p1_xcd_lo = 0, p1_xcd_n = 0;        // n > 0: every P = 1 launch confined to XCDs [lo, lo + n)
-    // EQ launches (DESIGN.md 4.4)
+    // EQ launches (DESIGN.md 4.5)
     int eq_xcd_lo = 0, eq_xcd_n = 0;        // n > 0: every ring launch confined to XCDs [lo, lo + n)
     int eq_conveyor = 0;                    // k_eq_pass also for <= 12 bands
     int eq_ring_v1 = 0;                     // round 2's 114-VGPR ring kernel (experiments build only)

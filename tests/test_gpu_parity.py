@@ -821,7 +821,7 @@ def test_eq_sample_routing_identity_filters_on_a_ramp(ohs, nb):
 
 
 def test_eq_ring_documented_edge_cases_signed_zero_and_non_finite_input(ohs, synth, oracle):
-    """the ring kernel's pass-on lanes run `1*x + 0` in the asm groups.  (a) A -0.0
+    """DESIGN.md 4.5 / LABNOTES.md: the ring kernel's pass-on lanes run `1*x + 0` in the asm groups.  (a) A -0.0
     sample may come out as +0.0: equal as numbers, every other sample bit-exact.  (b) A non-finite
     input sample: the reference (and the oracle) is non-finite from that sample on; this kernel
     may additionally lose up to 16 samples BEFORE it -- everything earlier is bit-exact."""
