@@ -114,7 +114,7 @@ int  ohs_engine_set_realtime(ohs_engine *e, int enable);
  * is served launch per call) and idle_polls, the doorbell polls (~0.6 us each) after which an idle kernel leaves
  * (0: keep the current value; default 3 000 000 ~ 2 s).  The library reads NO environment variable: these are the only
  * run-time settings that are not per handle. */
-int  ohs_rt_configure(int max_resident_per_device, unsigned long long idle_polls);
+int  ohs_rt_configure(int max_resident_per_device, uint64_t idle_polls);
 /* Delay the FIFO adapter of process_block adds for a constant host block size n (convolution.rs:163-181):
  * 0 when n is a multiple of 512; otherwise the frames answered with silence before the output FIFO can
  * serve every call (e.g. 256 for n = 256).  What a plugin host reports as its latency for compensation. */

@@ -52,7 +52,7 @@ PROTOTYPES = {
     "ohs_engine_process_block": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t]),     # audio pointers as plain addresses (hot call)
     "ohs_engine_num_partitions": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
     "ohs_engine_set_realtime": (C.c_int, [vp, C.c_int]),
-    "ohs_rt_configure": (C.c_int, [C.c_int, C.c_ulonglong]),
+    "ohs_rt_configure": (C.c_int, [C.c_int, C.c_uint64]),
     "ohs_engine_latency_samples": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ohs_engine_silent_frames": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "ohs_engine_debug_rt_stamps": (C.c_int, [vp, C.POINTER(C.c_uint64)]),

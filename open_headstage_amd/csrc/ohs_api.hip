@@ -1386,7 +1386,7 @@ int ohs_device_count(int *count)
 }
 
 // the two deployment options of the resident real-time kernels (include/ohs_hip.h)
-int ohs_rt_configure(int max_resident_per_device, unsigned long long idle_polls)
+int ohs_rt_configure(int max_resident_per_device, uint64_t idle_polls)
 {
     Tuning &t = tuning_rt();
     t.rt_max_resident = max_resident_per_device;        // < 0: the default, a quarter of the device's CUs

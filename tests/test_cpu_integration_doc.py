@@ -83,7 +83,7 @@ def test_every_rust_declaration_matches_the_header():
     rust, c = rust_decls(), c_decls()
     assert len(rust) >= 20, sorted(rust)            # the blocks were found and parsed
     opaque = {"OhsEngine": "ohs_engine", "OhsEq": "ohs_eq", "OhsBatch": "ohs_batch", "OhsSofa": "ohs_sofa",
-              "OhsBandSetting": "ohs_band_setting", "OhsNodeBatch": "ohs_node_batch"}
+              "OhsBandSetting": "ohs_band_setting", "OhsNodeBatch": "ohs_node_batch", "OhsBiquad": "ohs_biquad"}
     for name, (rparams, rret) in sorted(rust.items()):
         assert name in c, f"INTEGRATION.md declares {name}, include/ohs_hip.h does not"
         cparams, cret = c[name]

@@ -170,6 +170,9 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
         eq_on = bool(rng.random() < 0.6)
         gain = float(np.float32(rng.uniform(0.3, 1.0)))
         bp.set_eq_enabled(eq_on); bp.set_gain(gain)
+        # the plan of the one-partition path: library's choice, block 512 / FFT 1024, hop 1536 / FFT 2048 -- they hand the
+        # same state over, so any sequence of them must stay on the oracle (no effect while a path has more partitions)
+        bp.set_conv_plan(int(rng.integers(0, 3)))
         nblk = int(rng.choice([1, 2, 3, 5, 9, 17, 40, 64, 70, 130]))
         n = nblk * 512
         xt = torch.from_numpy(np.ascontiguousarray(x[:, :, pos:pos + n])).cuda()
