@@ -184,7 +184,7 @@ class NodeBatchProcessor:
     stream-id shards, one per-device batch each, the shared tables carried from the first device to the others by one
     RCCL broadcast inside the library.  Host mirror of what a Rust host binds."""
 
-    def __init__(self, streams_total: int, num_bands: int = 10, devices=None, n_devices: int | None = None):
+    def __init__(self, streams_total: int, num_bands: int = 10, devices=None, n_devices: int | None = None, library=None):
         if devices is None:
             if n_devices is None:
                 raise ValueError("give devices=[...] or n_devices=N")
@@ -196,14 +196,22 @@ class NodeBatchProcessor:
         self.streams_total = int(streams_total)
         self.num_bands = int(num_bands)
         self.n_devices = n
+        self._L = library
         h = C.c_void_p()
-        check(lib().ohs_node_batch_create(n, arr, self.streams_total, self.num_bands, C.byref(h)))
+        self._check(self._lib.ohs_node_batch_create(n, arr, self.streams_total, self.num_bands, C.byref(h)))
         self._h = h
+
+    @property
+    def _lib(self):
+        return getattr(self, "_L", None) or lib()
+
+    def _check(self, status: int) -> None:
+        check(status, self._lib)
 
     def shard(self, slot: int):
         """(HIP device index, first stream id, number of streams) of device slot `slot`"""
         d, f, c = C.c_int(), C.c_size_t(), C.c_size_t()
-        check(lib().ohs_node_batch_shard(self._h, int(slot), C.byref(d), C.byref(f), C.byref(c)))
+        self._check(self._lib.ohs_node_batch_shard(self._h, int(slot), C.byref(d), C.byref(f), C.byref(c)))
         return int(d.value), int(f.value), int(c.value)
 
     def set_tables(self, irs, eq_coeffs=None, eq_enabled=None) -> None:
@@ -215,47 +223,47 @@ class NodeBatchProcessor:
         ptrs = (fp * 4)(*[a.ctypes.data_as(fp) if a.size else None for a in arrs])
         lens = (C.c_size_t * 4)(*[a.size for a in arrs])
         if eq_coeffs is None:
-            check(lib().ohs_node_batch_set_tables(self._h, ptrs, lens, None, None))
+            self._check(self._lib.ohs_node_batch_set_tables(self._h, ptrs, lens, None, None))
             return
         c = np.ascontiguousarray(eq_coeffs, dtype=np.float32).reshape(self.num_bands, 5)
         en = np.ascontiguousarray(np.asarray(eq_enabled).astype(np.int32)).reshape(self.num_bands)
-        check(lib().ohs_node_batch_set_tables(self._h, ptrs, lens, c.ctypes.data_as(fp),
+        self._check(self._lib.ohs_node_batch_set_tables(self._h, ptrs, lens, c.ctypes.data_as(fp),
                                               en.ctypes.data_as(C.POINTER(C.c_int))))
 
     def set_ir(self, path, ir_data) -> None:
         ir = np.ascontiguousarray(ir_data, dtype=np.float32).ravel()
-        check(lib().ohs_node_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp) if ir.size else None, ir.size))
+        self._check(self._lib.ohs_node_batch_set_ir(self._h, int(path), ir.ctypes.data_as(fp) if ir.size else None, ir.size))
 
     def set_speakers(self, sofa, az_l: float = -30.0, el_l: float = 0.0, az_r: float = 30.0, el_r: float = 0.0,
                      radius_m: float = 1.0, fs: float = 0.0) -> int:
         """speaker angles -> the four shared impulse responses, one broadcast per path that changed
         (ohs_node_batch_set_speakers); -> bit mask of the paths that were re-loaded"""
         m = C.c_uint()
-        check(lib().ohs_node_batch_set_speakers(self._h, sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, C.byref(m)))
+        self._check(self._lib.ohs_node_batch_set_speakers(self._h, sofa._h, az_l, el_l, az_r, el_r, radius_m, fs, C.byref(m)))
         return int(m.value)
 
     def set_band_coeffs(self, band_idx: int, coeffs, enabled: bool) -> None:
         c = np.ascontiguousarray(coeffs, dtype=np.float32).ravel()
         if c.size != 5:
             raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
-        check(lib().ohs_node_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp), int(bool(enabled))))
+        self._check(self._lib.ohs_node_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp), int(bool(enabled))))
 
     def set_eq_enabled(self, eq_enable: bool) -> None:
-        check(lib().ohs_node_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
+        self._check(self._lib.ohs_node_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
 
     def set_gain(self, gain: float) -> None:
-        check(lib().ohs_node_batch_set_gain(self._h, float(gain)))
+        self._check(self._lib.ohs_node_batch_set_gain(self._h, float(gain)))
 
     def set_conv_plan(self, plan: int) -> None:
-        check(lib().ohs_node_batch_set_conv_plan(self._h, int(plan)))
+        self._check(self._lib.ohs_node_batch_set_conv_plan(self._h, int(plan)))
 
     def reset(self) -> None:
-        check(lib().ohs_node_batch_reset(self._h))
+        self._check(self._lib.ohs_node_batch_reset(self._h))
 
     def rccl_info(self):
         """(size of the RCCL communicator, librccl.so loaded)"""
         n, ok = C.c_int(), C.c_int()
-        check(lib().ohs_node_batch_rccl_info(self._h, C.byref(n), C.byref(ok)))
+        self._check(self._lib.ohs_node_batch_rccl_info(self._h, C.byref(n), C.byref(ok)))
         return int(n.value), bool(ok.value)
 
     def device_batch(self, slot: int) -> "BatchProcessor":
@@ -263,9 +271,9 @@ class NodeBatchProcessor:
         models and direct ohs_batch_process calls on that device)"""
         dev, _, cnt = self.shard(slot)
         h = C.c_void_p()
-        check(lib().ohs_node_batch_device_batch(self._h, int(slot), C.byref(h)))
+        self._check(self._lib.ohs_node_batch_device_batch(self._h, int(slot), C.byref(h)))
         v = BatchProcessor.__new__(BatchProcessor)
-        v._L = None
+        v._L = self._L
         v.n_streams, v.num_bands, v.device = cnt, self.num_bands, dev
         v._h = h
         v._borrowed = self         # keeps the owner alive; __del__ must not destroy the handle
@@ -280,7 +288,7 @@ class NodeBatchProcessor:
             raise ValueError("one pointer per device slot")
         ai = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_in])
         ao = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_out])
-        check(lib().ohs_node_batch_process(self._h, ai, ao, int(n_blocks), int(stream_stride), int(channel_stride)))
+        self._check(self._lib.ohs_node_batch_process(self._h, ai, ao, int(n_blocks), int(stream_stride), int(channel_stride)))
 
     def process(self, xs, outs=None):
         """xs: one float32 CUDA tensor [n_streams(slot), 2, frames] per slot, each on its slot's device; outs likewise
@@ -304,21 +312,21 @@ class NodeBatchProcessor:
         return outs
 
     def sync(self) -> None:
-        check(lib().ohs_node_batch_sync(self._h))
+        self._check(self._lib.ohs_node_batch_sync(self._h))
 
     def stream(self, slot: int) -> int:
         """the hipStream_t (as an integer) the slot's work is queued on"""
         p = C.c_void_p()
-        check(lib().ohs_node_batch_stream(self._h, int(slot), C.byref(p)))
+        self._check(self._lib.ohs_node_batch_stream(self._h, int(slot), C.byref(p)))
         return int(p.value or 0)
 
     def timer_begin(self) -> None:
-        check(lib().ohs_node_batch_timer_begin(self._h))
+        self._check(self._lib.ohs_node_batch_timer_begin(self._h))
 
     def timer_end(self):
         """-> device milliseconds per slot of what was queued since timer_begin (waits for it)"""
         ms = (C.c_float * self.n_devices)()
-        check(lib().ohs_node_batch_timer_end(self._h, ms))
+        self._check(self._lib.ohs_node_batch_timer_end(self._h, ms))
         return [float(v) for v in ms]
 
     def process_host(self, x, out=None, chunk_blocks: int = 0):
@@ -341,7 +349,7 @@ class NodeBatchProcessor:
             if x.is_cuda or out.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or not out.is_contiguous():
                 raise TypeError("x / out must be contiguous float32 HOST tensors")
             pi, po = x.data_ptr(), out.data_ptr()
-        check(lib().ohs_node_batch_process_host(self._h, C.c_void_p(pi), C.c_void_p(po), frames // BLOCK_SIZE,
+        self._check(self._lib.ohs_node_batch_process_host(self._h, C.c_void_p(pi), C.c_void_p(po), frames // BLOCK_SIZE,
                                                 2 * frames, frames, int(chunk_blocks)))
         return out
 
@@ -349,6 +357,6 @@ class NodeBatchProcessor:
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
-                lib().ohs_node_batch_destroy(h)
+                self._lib.ohs_node_batch_destroy(h)
             except Exception:
                 pass

@@ -10,6 +10,7 @@
 // library has no RCCL dependency and a single-GPU host never loads it.
 #include "../../include/ohs_hip.h"
 #include "host_internal.h"
+#include "tuning.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types and enums only; the functions are looked up in the loaded library
@@ -150,6 +151,7 @@ struct ohs_node_batch {
     // ohs_node_batch_set_speakers: what it last loaded into each path (any other set_ir / set_tables forgets it)
     std::vector<float> spk_ir[4];
     bool spk_set[4] = {false, false, false, false};
+    bool shared_device = false;         // experiments build: slots share a device, no RCCL (Tuning::node_shared_device_rehearsal)
 };
 
 namespace {
@@ -187,6 +189,15 @@ int broadcast_from_host(ohs_node_batch *nb, const float *host, size_t floats)
     if (rc) return rc;
     NB_HIP(hipSetDevice(nb->dev[0]));
     NB_HIP(hipMemcpyAsync(nb->d_tab[0], host, floats * sizeof(float), hipMemcpyHostToDevice, nb->st[0]));
+    if (nb->shared_device) {        // rehearsal on one GPU: slot 0's buffer to the other slots by device copies
+        NB_HIP(hipStreamSynchronize(nb->st[0]));
+        for (int i = 1; i < nb->n; ++i) {
+            NB_HIP(hipSetDevice(nb->dev[(size_t)i]));
+            NB_HIP(hipMemcpyAsync(nb->d_tab[(size_t)i], nb->d_tab[0], floats * sizeof(float), hipMemcpyDeviceToDevice, nb->st[(size_t)i]));
+            NB_HIP(hipStreamSynchronize(nb->st[(size_t)i]));
+        }
+        return OHS_OK;
+    }
     Rccl &R = rccl();
     NB_NCCL(R.GroupStart());
     for (int i = 0; i < nb->n; ++i) {
@@ -240,17 +251,22 @@ int ohs_node_batch_create(int n_devices, const int *devices, size_t streams_tota
     int rc = ohs_device_count(&have);
     if (rc) return fail(rc, std::string(ohs_last_error()) + " -- the library has no CPU fallback");
     std::vector<int> dev((size_t)n_devices);
+    bool shared = false;
     for (int i = 0; i < n_devices; ++i) {
         dev[(size_t)i] = devices ? devices[i] : i;
         if (dev[(size_t)i] < 0 || dev[(size_t)i] >= have) return fail(OHS_ERR_INVALID_ARG, "device index out of range");
         for (int k = 0; k < i; ++k)
-            if (dev[(size_t)k] == dev[(size_t)i]) return fail(OHS_ERR_INVALID_ARG, "a device is listed twice");
+            if (dev[(size_t)k] == dev[(size_t)i]) {
+                if (!ohs::tuning().node_shared_device_rehearsal) return fail(OHS_ERR_INVALID_ARG, "a device is listed twice");
+                shared = true;
+            }
     }
     Rccl &R = rccl();
-    if (!R.error.empty()) return fail(OHS_ERR_RCCL, R.error);
+    if (!shared && !R.error.empty()) return fail(OHS_ERR_RCCL, R.error);
     ohs_node_batch *nb = new (std::nothrow) ohs_node_batch;
     if (!nb) return fail(OHS_ERR_ALLOC, "out of host memory");
     nb->n = n_devices; nb->streams_total = streams_total; nb->num_bands = num_bands; nb->dev = dev;
+    nb->shared_device = shared;
     nb->first.resize((size_t)n_devices); nb->count.resize((size_t)n_devices);
     nb->b.assign((size_t)n_devices, nullptr); nb->comm.assign((size_t)n_devices, nullptr);
     nb->st.assign((size_t)n_devices, nullptr); nb->d_tab.assign((size_t)n_devices, nullptr);
@@ -268,7 +284,7 @@ int ohs_node_batch_create(int n_devices, const int *devices, size_t streams_tota
             NB_HIP(hipEventCreate(&nb->ev0[(size_t)i]));
             NB_HIP(hipEventCreate(&nb->ev1[(size_t)i]));
         }
-        NB_NCCL(R.CommInitAll(nb->comm.data(), n_devices, dev.data()));
+        if (!shared) NB_NCCL(R.CommInitAll(nb->comm.data(), n_devices, dev.data()));
         for (int i = 0; i < n_devices; ++i) {
             nb->worker.emplace_back(new DeviceWorker);
             DeviceWorker *w = nb->worker.back().get();
@@ -490,7 +506,7 @@ int ohs_node_batch_rccl_info(const ohs_node_batch *nb, int *comm_size, int *rccl
     if (rccl_loaded) *rccl_loaded = R.so != nullptr && R.error.empty();
     if (comm_size) {
         int n = 0;
-        NB_NCCL(R.CommCount(nb->comm[0], &n));
+        if (!nb->shared_device) NB_NCCL(R.CommCount(nb->comm[0], &n));      // (shared-device rehearsal: no communicator, 0)
         *comm_size = n;
     }
     return OHS_OK;

@@ -35,6 +35,7 @@ const struct { const char *env, *key; } kEnvKeys[] = {
     {"OHS_CONV_CU_MASK", "conv_cu_mask"}, {"OHS_MAC_NO_XCD", "mac_no_xcd"}, {"OHS_HOST_PIPE_TRACE", "host_pipe_trace"},
     {"OHS_HOST_PIPE_FLAT_PRIORITIES", "host_pipe_flat_priorities"}, {"OHS_RT_MAX_RESIDENT", "rt_max_resident"},
     {"OHS_RT_IDLE_POLLS", "rt_idle_polls"}, {"OHS_RT_POLL_SLEEP", "rt_poll_sleep"},
+    {"OHS_NODE_SHARED_DEVICE", "node_shared_device_rehearsal"},
 };
 std::once_flag g_env_once;
 void load_env()
@@ -131,6 +132,7 @@ bool tuning_set(const std::string &key, const std::string &value)
     if (key == "mac_no_xcd") return one(&t.mac_no_xcd);
     if (key == "host_pipe_trace") return one(&t.host_pipe_trace);
     if (key == "host_pipe_flat_priorities") return one(&t.host_pipe_flat_priorities);
+    if (key == "node_shared_device_rehearsal") return one(&t.node_shared_device_rehearsal);
     if (key == "rt_max_resident") return one(&t.rt_max_resident);
     if (key == "rt_idle_polls") { t.rt_idle_polls = strtoull(value.c_str(), nullptr, 10); return true; }
     if (key == "rt_poll_sleep") { if (!one(v)) return false; t.rt_poll_sleep = (unsigned)v[0]; return true; }

@@ -38,6 +38,10 @@ struct Tuning {
     int mac_no_xcd = 0;                     // plain stream-major workgroup order in k_conv_tp_mac
     // ohs_batch_process_host
     int host_pipe_trace = 0, host_pipe_flat_priorities = 0;
+    // ohs_node_batch_create (experiments build only): several device slots may name the SAME device -- a rehearsal of the
+    // multi-slot logic (sharding, per-slot unpack, worker threads, per-slot pointers) on a one-GPU box.  RCCL refuses two
+    // ranks on one device, so in this mode the tables travel slot to slot by device copies and no communicator exists.
+    int node_shared_device_rehearsal = 0;
     // resident real-time kernels: set through ohs_rt_configure in either build
     int rt_max_resident = -1;               // per device; < 0: a quarter of the CUs
     unsigned long long rt_idle_polls = 3000000ull;      // polls without a doorbell before the kernel leaves (~2 s)

@@ -116,6 +116,61 @@ def test_node_batch_device_resident_process_is_the_device_batch_bit_for_bit(ohs,
         nb.process_ptrs([0], [0], 4, 4096, 2048)        # NULL device pointers
 
 
+@pytest.mark.parametrize("slots,S", [(2, 9), (3, 10), (4, 4)])
+def test_node_batch_several_slots_rehearsed_on_one_device(ohs, synth, exp_tuning, slots, S):
+    """What a one-GPU box can check of N > 1: the experiments library lets several device slots name the SAME device
+    (Tuning::node_shared_device_rehearsal), so the sharding, the per-slot unpack of the packed tables, the per-slot worker
+    threads, streams and pointers and the shard offsets of process_host all run with N slots -- against one batch of all
+    the streams, bit for bit.  NOT covered: the grouped ncclBroadcast over N communicators (RCCL refuses two ranks on a
+    device; in this mode the tables travel by device copies and rccl_info reports size 0)."""
+    import torch
+    dev = torch.device("cuda:0")
+    L = exp_tuning.lib
+    exp_tuning("node_shared_device_rehearsal", "1")
+    irs, coeffs, enabled = _tables(ohs, synth, 1300)
+    nb = ohs.NodeBatchProcessor(S, num_bands=len(coeffs), devices=[0] * slots, library=L)
+    assert nb.rccl_info()[0] == 0
+    shards = [nb.shard(i) for i in range(slots)]
+    assert [s[0] for s in shards] == [0] * slots
+    assert sum(s[2] for s in shards) == S and [s[1] for s in shards] == list(np.cumsum([0] + [s[2] for s in shards[:-1]]))
+    assert max(s[2] for s in shards) - min(s[2] for s in shards) <= 1
+    nb.set_tables(irs, coeffs, enabled)
+    nb.set_eq_enabled(True)
+    nb.set_gain(0.9)
+    bp = ohs.BatchProcessor(S, num_bands=len(coeffs), library=L)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i in range(len(coeffs)):
+        bp.set_band_coeffs(i, coeffs[i], bool(enabled[i]))
+    bp.set_eq_enabled(True)
+    bp.set_gain(0.9)
+    n = 40 * 512
+    for call in range(3):
+        x = synth.white_noise_torch(9 * call, S, n, dev)
+        xs = [x[f:f + c].contiguous() for _, f, c in shards]
+        ys = [torch.empty_like(a) for a in xs]
+        torch.cuda.synchronize()
+        nb.timer_begin()
+        nb.process(xs, ys)
+        ms = nb.timer_end()
+        assert len(ms) == slots and all(m > 0.0 for m in ms)
+        nb.sync()
+        y_one = bp.process(x)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(ys).view(torch.int32), y_one.view(torch.int32)), call
+        if call == 0:       # one path and one band changed in mid-stream, on every slot
+            nb.set_ir(3, irs[3][:700]); bp.set_ir(3, irs[3][:700])
+        if call == 1:
+            nb.set_conv_plan(2); bp.set_conv_plan(2)
+    # the host-buffer form: every slot takes its own rows of the one host array
+    xh = synth.white_noise(range(300, 300 + S), n)
+    assert np.array_equal(nb.process_host(xh.copy(), chunk_blocks=16).view(np.uint32),
+                          bp.process_host(xh.copy(), chunk_blocks=16).view(np.uint32))
+    nb.reset(); bp.reset()
+    assert np.array_equal(nb.process_host(xh.copy(), chunk_blocks=16).view(np.uint32),
+                          bp.process_host(xh.copy(), chunk_blocks=16).view(np.uint32))
+
+
 def test_node_batch_without_librccl_fails_with_err_rccl(tmp_path):
     """OHS_ERR_RCCL when librccl.so cannot be loaded: a child process whose dynamic loader is made to miss it.  The
     library names it tries are librccl.so.1 / librccl.so by soname and under /opt/rocm/lib; the child pre-loads a
