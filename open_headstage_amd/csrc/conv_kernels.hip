@@ -600,8 +600,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     __shared__ __attribute__((aligned(16))) unsigned s_args[(sizeof(ConvGeneralArgs) + sizeof(EngineCallArgs) + 3) / 4];
     // thread 0's bookkeeping lives in LDS, not in registers: the call body below takes every one of the 256 VGPRs two
     // waves per SIMD leave, and what was alive across it (five 64-bit time stamps, the host pointers) was spilled to
-    // scratch memory and reloaded on the call's critical path.  (The doorbell value stays in a register: with it in LDS as
-    // well the kernel never answered its first call on the GPU -- not understood, tools/rt_probe.py reproduces it.)
+    // scratch memory and reloaded on the call's critical path.
     __shared__ unsigned long long s_st[5];      // doorbell seen, inputs visible, body done, stores drained; shader clock
     __shared__ const float *s_host_src[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -626,9 +625,18 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
     __syncthreads();
     if (threadIdx.x == 0) { s_host_src[0] = E.src_l; s_host_src[1] = E.src_r; }
     __syncthreads();
-    unsigned last = first_seq;              // the doorbell value already served
+    // CONTROL FLOW OF THIS LOOP IS WAVE-UNIFORM ON PURPOSE.  Every branch that decides whether a wave reaches one of the
+    // loop's barriers tests a value the compiler can prove uniform (readfirstlane): hipcc otherwise treats the exit test
+    // and the "thread 0 only" blocks as divergent and is free to thread the block that ends one iteration into the one
+    // that starts the next -- it then builds an inner loop in which lanes 1..63 of wave 0 and all other waves run ahead
+    // through the top barrier while lane 0 is parked, and the call is served again and again without ever being
+    // published (seen with the doorbell value kept in LDS; tools/rt_probe.py).  So: the doorbell loop is run by the whole
+    // of wave 0 (EXEC is narrowed to lane 0 inside the asm statement, where the compiler cannot see it), its results
+    // are broadcast through SGPRs, and lane predication is left to leaf stores.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned last = first_seq;              // the doorbell value already served (meaningful in wave 0)
     for (;;) {
-        if (threadIdx.x == 0) {
+        if (wave_u == 0) {
             unsigned cmd = 0;
             unsigned long long idle = 0;
             for (;;) {
@@ -637,14 +645,14 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
                 // sampled every half PCIe round trip instead of once per round trip: ~0.3 us less from the host's
                 // store to the kernel's start.  One asm statement, because a register that is the destination of a
                 // load in flight must not be touched by compiler-generated moves; it leaves after kRtPollBurst
-                // polls at the latest (idle accounting and the sleep are done outside).
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 w;
+                // polls at the latest (idle accounting and the sleep are done outside).  Lane 0 alone issues the reads.
+                unsigned w0, w1, w2, w3;
                 unsigned sx, sw, budget = kRtPollBurst;
                 const unsigned last_s = (unsigned)__builtin_amdgcn_readfirstlane((int)last);
                 // (the two destinations are fixed registers, v[8:11] and v[12:15]: inline asm cannot name the
                 // components of a 128-bit operand)
                 asm volatile(
+                    "s_mov_b64 exec, 1\n\t"
                     "global_load_dwordx4 v[8:11], %[p], off sc0 sc1\n"
                     "1:\n\t"
                     "global_load_dwordx4 v[12:15], %[p], off sc0 sc1\n\t"
@@ -676,43 +684,49 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
                     "v_mov_b32 v9, v13\n\t"
                     "v_mov_b32 v10, v14\n\t"
                     "v_mov_b32 v11, v15\n"
-                    "2:\n\t"                          // result in v[8:11]; nothing may stay in flight
+                    "2:\n\t"                          // result in v[8:11] (lane 0); nothing may stay in flight
                     "s_waitcnt vmcnt(0)\n\t"
-                    "v_mov_b32 %[w0], v8\n\t"
-                    "v_mov_b32 %[w1], v9\n\t"
-                    "v_mov_b32 %[w2], v10\n\t"
-                    "v_mov_b32 %[w3], v11\n"
-                    : [w0] "=&v"(w.x), [w1] "=&v"(w.y), [w2] "=&v"(w.z), [w3] "=&v"(w.w), [sx] "=&s"(sx), [sw] "=&s"(sw),
+                    "v_readfirstlane_b32 %[w0], v8\n\t"
+                    "v_readfirstlane_b32 %[w1], v9\n\t"
+                    "v_readfirstlane_b32 %[w2], v10\n\t"
+                    "v_readfirstlane_b32 %[w3], v11\n\t"
+                    "s_mov_b64 exec, -1\n"
+                    : [w0] "=&s"(w0), [w1] "=&s"(w1), [w2] "=&s"(w2), [w3] "=&s"(w3), [sx] "=&s"(sx), [sw] "=&s"(sw),
                       [n] "+s"(budget)
                     : [p] "v"(&mb->call_word[0]), [last] "s"(last_s)
                     : "memory", "scc", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15");
-                if (w.w) break;                                         // stop
-                if (w.x != last) {
-                    last = w.x; cmd = 1;
-                    // w.y = n (bits 0..15) | EQ block version, low 15 bits (16..30) | run the EQ (31)
-                    s_n = (int)(w.y & 0xffffu); s_eq = (int)(w.y >> 31); s_eq_ver_call = (w.y >> 16) & 0x7fffu;
-                    s_gain = __uint_as_float(w.z);
+                if (w3) break;                                          // stop
+                if (w0 != last) {
+                    last = w0; cmd = 1;
+                    // w1 = n (bits 0..15) | EQ block version, low 15 bits (16..30) | run the EQ (31)
+                    if (lane == 0) {
+                        s_n = (int)(w1 & 0xffffu); s_eq = (int)(w1 >> 31); s_eq_ver_call = (w1 >> 16) & 0x7fffu;
+                        s_gain = __uint_as_float(w2);
+                    }
                     break;
                 }
                 idle += 2 * kRtPollBurst;
                 if (idle >= idle_limit) break;
                 for (unsigned k = 0; k < sleep_arg; ++k) __builtin_amdgcn_s_sleep(16);     // ~0.4 us each
             }
-            s_cmd = cmd;
+            if (lane == 0) s_cmd = cmd;
         }
         __syncthreads();
-        if (s_cmd == 0) break;              // uniform: s_cmd is read by every thread after the barrier
+        if (__builtin_amdgcn_readfirstlane((int)s_cmd) == 0) break;     // (every thread reads s_cmd after the barrier)
         if (threadIdx.x == 0) { s_st[0] = __builtin_amdgcn_s_memrealtime(); s_st[4] = __builtin_amdgcn_s_memtime(); }
         // the host's writes (input frames) precede its doorbell store; make them visible to this CU
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        if (s_eq) {
+        const int eq_u = __builtin_amdgcn_readfirstlane(s_eq);
+        if (eq_u) {
             // lib.rs:1194: the EQ runs on this host block before the engine sees it.  (1) the EQ block (table,
             // state pointer, staging buffer) if the host has changed it, (2) the block's frames from pinned
             // host memory to the device staging buffer, all waves -- the EQ kernel's one-group prefetch cannot
             // cover a PCIe read --, (3) wave 0 = the two chains L, R in place, (4) the convolution reads from there.
             constexpr int eq_words = (int)((sizeof(RtMailbox) - offsetof(RtMailbox, eq_version) + 3) / 4);
             // the version the call wants travels in the call word, so an unchanged block costs no PCIe read
-            if (s_eq_ver_call != (s_eq_version & 0x7fffu) || s_eq_version == 0xffffffffu) {      // uniform
+            const unsigned ver_call = (unsigned)__builtin_amdgcn_readfirstlane((int)s_eq_ver_call);
+            const unsigned ver_held = (unsigned)__builtin_amdgcn_readfirstlane((int)s_eq_version);
+            if (ver_call != (ver_held & 0x7fffu) || ver_held == 0xffffffffu) {
                 __syncthreads();
                 const unsigned *src = reinterpret_cast<const unsigned *>(&mb->eq_version);
                 for (int i = here((int)threadIdx.x); i < eq_words; i += 512) s_eq_blk[i] = src[i];
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (wave == 0) {
+            if (wave_u == 0) {
                 if (threadIdx.x == 0) mb->stamps[6] = __builtin_amdgcn_s_memrealtime();
                 rt_eq_call(buf, stride, (long long)n, eqb->eq_nb, &eqb->eq_tab, eqb->eq_state);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -755,7 +769,7 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
         if (threadIdx.x == 0) {             // this call's FIFO arithmetic (convolution.rs:149-163)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_st[1] = __builtin_amdgcn_s_memrealtime();
-            if (s_eq) {
+            if (eq_u) {
                 const RtMailbox *const eqb2 = reinterpret_cast<const RtMailbox *>(reinterpret_cast<const char *>(s_eq_blk) -
                                                                                    offsetof(RtMailbox, eq_version));
                 E.src_l = eqb2->eq_buf; E.src_r = eqb2->eq_buf + eqb2->eq_buf_stride;
