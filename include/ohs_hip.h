@@ -417,7 +417,11 @@ int  ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h
  * the devices' queues fill side by side; nothing crosses PCIe or xGMI -- all mutable state is per stream
  * (convolution.rs:36-42,76-79; parametric_eq.rs:125-129).  Returns when every device has QUEUED its work: the outputs
  * are complete after ohs_node_batch_sync.  Calls queue up in order; the set_* / reset calls of the node batch wait for
- * what is queued.  Results are bit-identical to ohs_batch_process on one device holding the same streams. */
+ * what is queued.  Results are bit-identical to ohs_batch_process on one device holding the same streams.
+ * Failure: if ANY slot fails the call returns that slot's status ("device slot k: ...") and the node batch refuses
+ * every later ohs_node_batch_process / _process_host with OHS_ERR_HIP until ohs_node_batch_reset (the other shards have
+ * advanced: the node's streams are out of step).  Likewise after a table call that failed half-way (devices hold
+ * different tables) until a complete ohs_node_batch_set_tables -- four paths and the EQ -- has succeeded. */
 int  ohs_node_batch_process(ohs_node_batch *nb, const float *const d_in[], float *const d_out[], size_t n_blocks,
                             size_t stream_stride, size_t channel_stride);
 /* waits (host side) for everything ohs_node_batch_process has queued, on every device */

@@ -152,6 +152,11 @@ struct ohs_node_batch {
     std::vector<float> spk_ir[4];
     bool spk_set[4] = {false, false, false, false};
     bool shared_device = false;         // experiments build: slots share a device, no RCCL (Tuning::node_shared_device_rehearsal)
+    // fail-closed at node level: a processing call that failed on ANY slot leaves the shards out of step (the others
+    // have advanced); a table call that failed half-way leaves the devices with different tables.  Both are refused
+    // until the call that repairs them (ohs_node_batch_reset / a complete ohs_node_batch_set_tables) has succeeded.
+    bool failed = false, tables_torn = false;
+    std::string fail_msg, torn_msg;
 };
 
 namespace {
@@ -235,6 +240,29 @@ int run_on_all(ohs_node_batch *nb, const std::function<int(int)> &fn)
     }
     if (first_rc) return fail(first_rc, "device slot " + std::to_string(first_slot) + ": " + first_err);
     return OHS_OK;
+}
+
+int refuse_if_unusable(const ohs_node_batch *nb)
+{
+    if (nb->failed)
+        return fail(OHS_ERR_HIP, "an earlier processing call failed on one device (" + nb->fail_msg + "): the shards' per-stream "
+                    "state is half-advanced and out of step; ohs_node_batch_reset first");
+    if (nb->tables_torn)
+        return fail(OHS_ERR_HIP, "an earlier table call failed half-way (" + nb->torn_msg + "): the devices hold different "
+                    "tables; repeat ohs_node_batch_set_tables first");
+    return OHS_OK;
+}
+
+int processing_result(ohs_node_batch *nb, int rc)
+{
+    if (rc) { nb->failed = true; nb->fail_msg = ohs_last_error(); }
+    return rc;
+}
+
+int table_result(ohs_node_batch *nb, int rc)
+{
+    if (rc) { nb->tables_torn = true; nb->torn_msg = ohs_last_error(); }
+    return rc;
 }
 
 }  // namespace
@@ -359,26 +387,35 @@ int ohs_node_batch_set_tables(ohs_node_batch *nb, const float *const irs[4], con
         pack[off[4] + 6 * i + 5] = eq_enabled[i] ? 1.0f : 0.0f;
     }
     for (int p = 0; p < 4; ++p) nb->spk_set[p] = false;
-    int rc = broadcast_from_host(nb, pack.data(), pack.size());
-    if (rc) return rc;
-    std::vector<float> eq_back(eq_floats);
-    for (int i = 0; i < nb->n; ++i) {
-        for (int p = 0; p < 4; ++p) {
-            rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], p, nb->d_tab[(size_t)i] + off[p], lens[p]);
-            if (rc) return rc;
-        }
-        if (eq_floats) {
-            // the EQ table is host-side state of a handle (kernel arguments): every device's handle gets the bits its
-            // OWN device received
-            NB_HIP(hipSetDevice(nb->dev[(size_t)i]));
-            NB_HIP(hipMemcpy(eq_back.data(), nb->d_tab[(size_t)i] + off[4], eq_floats * sizeof(float), hipMemcpyDeviceToHost));
-            for (size_t k = 0; k < nb->num_bands; ++k) {
-                rc = ohs_batch_set_eq_band_coeffs(nb->b[(size_t)i], k, eq_back.data() + 6 * k, eq_back[6 * k + 5] != 0.0f);
+    auto unpack = [&]() -> int {
+        int rc = broadcast_from_host(nb, pack.data(), pack.size());
+        if (rc) return rc;
+        std::vector<float> eq_back(eq_floats);
+        for (int i = 0; i < nb->n; ++i) {
+            if (ohs::tuning().node_inject_table_failure_slot == i + 1)     // (experiments build only; 0 in the product)
+                return fail(OHS_ERR_HIP, "injected table failure (node_inject_table_failure_slot)");
+            for (int p = 0; p < 4; ++p) {
+                rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], p, nb->d_tab[(size_t)i] + off[p], lens[p]);
                 if (rc) return rc;
             }
+            if (eq_floats) {
+                // the EQ table is host-side state of a handle (kernel arguments): every device's handle gets the bits
+                // its OWN device received
+                NB_HIP(hipSetDevice(nb->dev[(size_t)i]));
+                NB_HIP(hipMemcpy(eq_back.data(), nb->d_tab[(size_t)i] + off[4], eq_floats * sizeof(float), hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < nb->num_bands; ++k) {
+                    rc = ohs_batch_set_eq_band_coeffs(nb->b[(size_t)i], k, eq_back.data() + 6 * k, eq_back[6 * k + 5] != 0.0f);
+                    if (rc) return rc;
+                }
+            }
         }
-    }
-    return OHS_OK;
+        return OHS_OK;
+    };
+    const int rc = table_result(nb, unpack());
+    // a COMPLETE table set (four paths and the EQ) repairs whatever an earlier table call tore; without the EQ part only
+    // if it was not an EQ call that tore it -- kept simple: the four paths and the EQ together
+    if (rc == OHS_OK && eq_coeffs) nb->tables_torn = false;
+    return rc;
 }
 
 int ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t len)
@@ -389,13 +426,16 @@ int ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t 
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     DeviceRestore restore;
     nb->spk_set[path] = false;
-    int rc = broadcast_from_host(nb, ir, len);
-    if (rc) return rc;
-    for (int i = 0; i < nb->n; ++i) {
-        rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], path, nb->d_tab[(size_t)i], len);
+    auto unpack = [&]() -> int {
+        int rc = broadcast_from_host(nb, ir, len);
         if (rc) return rc;
-    }
-    return OHS_OK;
+        for (int i = 0; i < nb->n; ++i) {
+            rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], path, nb->d_tab[(size_t)i], len);
+            if (rc) return rc;
+        }
+        return OHS_OK;
+    };
+    return table_result(nb, unpack());
 }
 
 // speaker angles -> four impulse responses (speakers.cpp), one broadcast per path whose response changed
@@ -429,7 +469,10 @@ int ohs_node_batch_set_speakers(ohs_node_batch *nb, const ohs_sofa *sofa, float 
 
 int ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const float coeffs[5], int enabled)
 {
-    NB_FOR_EACH(ohs_batch_set_eq_band_coeffs(h, band, coeffs, enabled))
+    if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");
+    if (band >= nb->num_bands) return OHS_OK;       // parametric_eq.rs:144-164 ignores a band index past the last one
+    auto each = [&]() -> int { NB_FOR_EACH(ohs_batch_set_eq_band_coeffs(h, band, coeffs, enabled)) };
+    return table_result(nb, each());
 }
 int ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable) { NB_FOR_EACH(ohs_batch_set_eq_enabled(h, eq_enable)) }
 int ohs_node_batch_set_gain(ohs_node_batch *nb, float gain) { NB_FOR_EACH(ohs_batch_set_gain(h, gain)) }
@@ -437,18 +480,22 @@ int ohs_node_batch_set_conv_plan(ohs_node_batch *nb, int plan) { NB_FOR_EACH(ohs
 int ohs_node_batch_reset(ohs_node_batch *nb)
 {
     DeviceRestore restore;
-    NB_FOR_EACH(ohs_batch_reset(h))
+    auto each = [&]() -> int { NB_FOR_EACH(ohs_batch_reset(h)) };
+    const int rc = each();
+    if (rc == OHS_OK) { nb->failed = false; nb->fail_msg.clear(); }     // every shard is back at zeroed state, tables kept
+    return rc;
 }
 
 int ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h_out, size_t n_blocks,
                                 size_t stream_stride, size_t channel_stride, size_t chunk_blocks)
 {
     if (!nb || !h_in || !h_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
-    return run_on_all(nb, [&](int i) {
+    if (const int r = refuse_if_unusable(nb)) return r;
+    return processing_result(nb, run_on_all(nb, [&](int i) {
         const size_t o = nb->first[(size_t)i] * stream_stride;
         return ohs_batch_process_host(nb->b[(size_t)i], h_in + o, h_out + o, n_blocks, stream_stride, channel_stride,
                                       chunk_blocks);
-    });
+    }));
 }
 
 // Device-resident data path: every device's ohs_batch_process is issued by that device's own host thread on that
@@ -459,10 +506,11 @@ int ohs_node_batch_process(ohs_node_batch *nb, const float *const d_in[], float 
     if (!nb || !d_in || !d_out) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
     for (int i = 0; i < nb->n; ++i)
         if (!d_in[i] || !d_out[i]) return fail(OHS_ERR_INVALID_ARG, "NULL device pointer for slot " + std::to_string(i));
-    return run_on_all(nb, [&](int i) {
+    if (const int r = refuse_if_unusable(nb)) return r;
+    return processing_result(nb, run_on_all(nb, [&](int i) {
         return ohs_batch_process(nb->b[(size_t)i], d_in[i], d_out[i], n_blocks, stream_stride, channel_stride,
                                  nb->pst[(size_t)i]);
-    });
+    }));
 }
 
 int ohs_node_batch_sync(ohs_node_batch *nb)

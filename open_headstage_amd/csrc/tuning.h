@@ -42,6 +42,7 @@ struct Tuning {
     // multi-slot logic (sharding, per-slot unpack, worker threads, per-slot pointers) on a one-GPU box.  RCCL refuses two
     // ranks on one device, so in this mode the tables travel slot to slot by device copies and no communicator exists.
     int node_shared_device_rehearsal = 0;
+    int node_inject_table_failure_slot = 0;     // ohs_node_batch_set_tables fails in front of device slot (this - 1): the tear test
     // resident real-time kernels: set through ohs_rt_configure in either build
     int rt_max_resident = -1;               // per device; < 0: a quarter of the CUs
     unsigned long long rt_idle_polls = 3000000ull;      // polls without a doorbell before the kernel leaves (~2 s)

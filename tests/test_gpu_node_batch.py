@@ -171,6 +171,92 @@ def test_node_batch_several_slots_rehearsed_on_one_device(ohs, synth, exp_tuning
                           bp.process_host(xh.copy(), chunk_blocks=16).view(np.uint32))
 
 
+def _rehearsal_pair(ohs, synth, exp_tuning, slots, S, taps=512):
+    L = exp_tuning.lib
+    exp_tuning("node_shared_device_rehearsal", "1")
+    irs, coeffs, enabled = _tables(ohs, synth, taps)
+    nb = ohs.NodeBatchProcessor(S, num_bands=len(coeffs), devices=[0] * slots, library=L)
+    nb.set_tables(irs, coeffs, enabled)
+    nb.set_eq_enabled(True)
+    bp = ohs.BatchProcessor(S, num_bands=len(coeffs), library=L)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i in range(len(coeffs)):
+        bp.set_band_coeffs(i, coeffs[i], bool(enabled[i]))
+    bp.set_eq_enabled(True)
+    return nb, bp, (irs, coeffs, enabled)
+
+
+def test_node_batch_fails_closed_when_one_slot_fails(ohs, synth, exp_tuning):
+    """A processing call that fails on ONE device slot leaves the other shards advanced: the node handle refuses every
+    later processing call (device-resident and host-buffer form) until ohs_node_batch_reset, then answers with the bits
+    of a fresh object.  The failure is injected in the experiments build (the k-th chunk launch of any batch fails)."""
+    import torch
+    from open_headstage_amd import _ffi
+    dev = torch.device("cuda:0")
+    slots, S, n = 3, 9, 128 * 512
+    nb, bp, _ = _rehearsal_pair(ohs, synth, exp_tuning, slots, S)
+    shards = [nb.shard(i) for i in range(slots)]
+    x = synth.white_noise_torch(4, S, n, dev)
+    xs = [x[f:f + c].contiguous() for _, f, c in shards]
+    ys = [torch.empty_like(a) for a in xs]
+    y_fresh = bp.process(x).clone()
+    torch.cuda.synchronize()
+    exp_tuning.lib.ohs_debug_inject_batch_failure(8)       # 6 time chunks per slot and call: some slot's second chunk or later
+    with pytest.raises(ohs.OhsError) as ei:
+        nb.process(xs, ys)
+        nb.sync()
+    assert ei.value.status == _ffi.OHS_ERR_HIP and "device slot" in str(ei.value) and "injected failure" in str(ei.value)
+    exp_tuning.lib.ohs_debug_inject_batch_failure(0)
+    torch.cuda.synchronize()
+    for call in (lambda: nb.process(xs, ys), lambda: nb.process_host(x.cpu().numpy())):
+        with pytest.raises(ohs.OhsError) as ei:
+            call()
+        assert ei.value.status == _ffi.OHS_ERR_HIP and "out of step" in str(ei.value) and "ohs_node_batch_reset" in str(ei.value)
+    nb.reset()
+    nb.process(xs, ys)
+    nb.sync()
+    assert torch.equal(torch.cat(ys).view(torch.int32), y_fresh.view(torch.int32))
+
+
+def test_node_batch_refuses_to_process_on_torn_tables(ohs, synth, exp_tuning):
+    """A table call that fails after some devices have taken the new tables leaves the node with different tables per
+    device: processing is refused until a complete ohs_node_batch_set_tables has succeeded."""
+    import torch
+    from open_headstage_amd import _ffi
+    dev = torch.device("cuda:0")
+    slots, S, n = 3, 7, 24 * 512
+    nb, bp, (irs, coeffs, enabled) = _rehearsal_pair(ohs, synth, exp_tuning, slots, S)
+    shards = [nb.shard(i) for i in range(slots)]
+    x = synth.white_noise_torch(11, S, n, dev)
+    xs = [x[f:f + c].contiguous() for _, f, c in shards]
+    ys = [torch.empty_like(a) for a in xs]
+    torch.cuda.synchronize()
+    nb.process(xs, ys); nb.sync()
+    y1 = bp.process(x)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(ys).view(torch.int32), y1.view(torch.int32))
+    irs2 = [h[::-1].copy() * 0.5 for h in irs]
+    exp_tuning("node_inject_table_failure_slot", "2")       # slot 0 takes the new tables, slot 1 fails, slot 2 keeps the old
+    with pytest.raises(ohs.OhsError) as ei:
+        nb.set_tables(irs2, coeffs, enabled)
+    assert "injected table failure" in str(ei.value)
+    exp_tuning("node_inject_table_failure_slot", "0")
+    with pytest.raises(ohs.OhsError) as ei:
+        nb.process(xs, ys)
+    assert ei.value.status == _ffi.OHS_ERR_HIP and "different" in str(ei.value) and "ohs_node_batch_set_tables" in str(ei.value)
+    nb.set_ir(0, irs2[0])                                   # one path alone does not repair it
+    with pytest.raises(ohs.OhsError):
+        nb.process(xs, ys)
+    nb.set_tables(irs2, coeffs, enabled)                    # the complete set does; every path restarts (convolution.rs:135-138)
+    for p in range(4):
+        bp.set_ir(p, irs2[p])
+    nb.process(xs, ys); nb.sync()
+    y2 = bp.process(x)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(ys).view(torch.int32), y2.view(torch.int32))
+
+
 def test_node_batch_without_librccl_fails_with_err_rccl(tmp_path):
     """OHS_ERR_RCCL when librccl.so cannot be loaded: a child process whose dynamic loader is made to miss it.  The
     library names it tries are librccl.so.1 / librccl.so by soname and under /opt/rocm/lib; the child pre-loads a
