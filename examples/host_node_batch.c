@@ -7,8 +7,21 @@
  *   gcc -O2 -Iinclude -o host_node_batch examples/host_node_batch.c -Lopen_headstage_amd -lohs_hip -lm
  *   ./host_node_batch n_devices streams irs.f32 taps in.f32 out.f32 frames
  *     irs.f32 : 4 x taps f32 (Lsl, Lsr, Rsl, Rsr);  in/out.f32 : planar [streams][2][frames], frames % 512 == 0
+ *
+ * Built with -DDEVICE_RESIDENT (plus -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include ... -L/opt/rocm/lib -lamdhip64) the
+ * host owns the device memory itself -- one buffer per device slot holding that slot's shard -- and drives the node's
+ * data path, ohs_node_batch_process / _sync with the per-slot device timer, instead of the PCIe-fed _process_host: what
+ * a production host with audio already resident in HBM calls.
  */
 #include "ohs_hip.h"
+#ifdef DEVICE_RESIDENT
+#include <hip/hip_runtime_api.h>
+#define HIPCHECK(call)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } \
+    } while (0)
+#endif
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,7 +84,36 @@ int main(int argc, char **argv)
     CHECK(ohs_node_batch_set_tables(nb, ir_ptrs, lens, coeffs, enabled));     /* ONE broadcast */
     CHECK(ohs_node_batch_set_eq_enabled(nb, 1));
     CHECK(ohs_node_batch_set_gain(nb, 0.8912509f));
+#ifdef DEVICE_RESIDENT
+    {
+        enum { MAX_SLOTS = 64 };
+        float *d_buf[MAX_SLOTS];
+        const float *d_in[MAX_SLOTS];
+        float ms[MAX_SLOTS];
+        if (n_devices > MAX_SLOTS) return 2;
+        for (int s = 0; s < n_devices; ++s) {           /* each slot's shard onto its own device, in place */
+            int dev; size_t first, n;
+            CHECK(ohs_node_batch_shard(nb, s, &dev, &first, &n));
+            HIPCHECK(hipSetDevice(dev));
+            HIPCHECK(hipMalloc((void **)&d_buf[s], n * 2 * frames * sizeof(float)));
+            HIPCHECK(hipMemcpy(d_buf[s], x + first * 2 * frames, n * 2 * frames * sizeof(float), hipMemcpyHostToDevice));
+            d_in[s] = d_buf[s];
+        }
+        CHECK(ohs_node_batch_timer_begin(nb));
+        CHECK(ohs_node_batch_process(nb, d_in, d_buf, frames / OHS_BLOCK_SIZE, 2 * frames, frames));   /* queued on every device */
+        CHECK(ohs_node_batch_timer_end(nb, ms));        /* waits for every device */
+        for (int s = 0; s < n_devices; ++s) {
+            int dev; size_t first, n;
+            CHECK(ohs_node_batch_shard(nb, s, &dev, &first, &n));
+            HIPCHECK(hipSetDevice(dev));
+            HIPCHECK(hipMemcpy(y + first * 2 * frames, d_buf[s], n * 2 * frames * sizeof(float), hipMemcpyDeviceToHost));
+            HIPCHECK(hipFree(d_buf[s]));
+            fprintf(stderr, "slot %d: %.3f ms on the device\n", s, ms[s]);
+        }
+    }
+#else
     CHECK(ohs_node_batch_process_host(nb, x, y, frames / OHS_BLOCK_SIZE, 2 * frames, frames, 0));
+#endif
     ohs_node_batch_destroy(nb);
 
     FILE *f = fopen(argv[6], "wb");

@@ -87,3 +87,21 @@ def test_c_host_node_batch_matches_oracle(tmp_path, oracle):
         l, rr = x[s, 0].copy(), x[s, 1].copy()
         oracle.chain_process(eng, eq, l, rr, eq_enable=True, gain=0.8912509)
         assert_parity(y[s], np.stack([l, rr]), f"C node-batch host, stream {s}")
+    # the same host built -DDEVICE_RESIDENT: it owns the device buffers (hipMalloc from C) and drives the node's data
+    # path, ohs_node_batch_process / _timer_end -- the bits of the PCIe-fed form (streams do not interact, the time
+    # chunking of the host pipeline changes nothing)
+    rocm = "/opt/rocm"
+    if not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("no HIP headers for the device-resident C host")
+    exe2 = str(tmp_path / "host_node_batch_dev")
+    subprocess.run([gcc, "-O2", "-std=c99", "-Wall", "-DDEVICE_RESIDENT", "-D__HIP_PLATFORM_AMD__",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(rocm, "include"), "-o", exe2,
+                    os.path.join(ROOT, "examples", "host_node_batch.c"), "-L" + libdir, "-lohs_hip",
+                    "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lm",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(rocm, "lib")], check=True)
+    r = subprocess.run([exe2, "1", str(S), str(tmp_path / "irs.f32"), str(taps), str(tmp_path / "in.f32"),
+                        str(tmp_path / "out_dev.f32"), str(frames)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ms on the device" in r.stderr
+    y_dev = np.fromfile(tmp_path / "out_dev.f32", np.float32).reshape(S, 2, frames)
+    assert np.array_equal(y_dev.view(np.uint32), y.view(np.uint32))
