@@ -205,3 +205,73 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
         assert np.abs(y - o).max() < 2e-5, (seed, call, nblk, mode, eq_on, S, [int(v) for v in np.argwhere(np.abs(y - o) > 2e-5)[:6].ravel()])
         got.append(y); ref.append(o)
     assert_parity(np.concatenate(got, 2), np.concatenate(ref, 2), f"fuzz batch seed {seed}")
+
+
+@pytest.mark.parametrize("seed", range(_FIRST if _EXTRA else 0, max(4, _EXTRA // 4)))
+def test_fuzz_node_batch_slots_against_one_batch(ohs, synth, exp_tuning, seed):
+    """Random operation sequences through ohs_node_batch_* with 2 ... 4 device slots (all of them device 0: the
+    experiments build's rehearsal mode) against ONE batch holding all the streams, bit for bit: sharding, per-slot
+    tables, per-slot worker threads and pointers, the host-buffer form's row offsets, table changes and resets in
+    mid-stream.  (The single batch is itself pinned to the oracle by test_fuzz_batch.)"""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7000 + seed)
+    L = exp_tuning.lib
+    exp_tuning("node_shared_device_rehearsal", "1")
+    slots = int(rng.integers(2, 5))
+    S = int(rng.integers(slots, 14))
+    bands = synth.eq_table()
+    coeffs = np.stack([ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db) for b in bands])
+    enabled = np.array([b.enabled for b in bands])
+    long_ir = bool(seed % 2)
+    lengths = [300, 512, 2000, 5000] if long_ir else [64, 300, 512]
+    irs = [_random_ir(rng, int(rng.choice(lengths))) for _ in range(4)]
+    nb = ohs.NodeBatchProcessor(S, num_bands=len(bands), devices=[0] * slots, library=L)
+    bp = ohs.BatchProcessor(S, num_bands=len(bands), library=L)
+    nb.set_tables(irs, coeffs, enabled)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i in range(len(bands)):
+        bp.set_band_coeffs(i, coeffs[i], bool(enabled[i]))
+    shards = [nb.shard(i) for i in range(slots)]
+    assert sum(c for _, _, c in shards) == S
+    for step in range(14):
+        op = rng.random()
+        if op < 0.55:
+            n = 512 * int(rng.choice([1, 2, 7, 16, 40, 70]))
+            x = synth.white_noise_torch(int(rng.integers(0, 1 << 20)), S, n, dev)
+            if rng.random() < 0.7:          # device-resident form
+                xs = [x[f:f + c].contiguous() for _, f, c in shards]
+                ys = [torch.empty_like(a) for a in xs]
+                torch.cuda.synchronize()
+                nb.process(xs, ys); nb.sync()
+                y = torch.cat(ys)
+            else:                           # host-buffer form
+                y = torch.from_numpy(nb.process_host(x.cpu().numpy(), chunk_blocks=int(rng.choice([0, 4, 16])))).to(dev)
+            y_one = bp.process(x)
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.int32), y_one.view(torch.int32)), (seed, step, slots, S, n)
+        elif op < 0.70:
+            p = int(rng.integers(0, 4))
+            h = _random_ir(rng, int(rng.choice([0, 1, 100, 512, 513] + ([1500, 4000] if long_ir else []))))
+            nb.set_ir(p, h); bp.set_ir(p, h)
+        elif op < 0.78:
+            i = int(rng.integers(0, len(bands)))
+            c = ohs.biquad_coefficients(*_band_args(_random_band(ohs, rng), synth.FS))
+            en = bool(rng.random() < 0.8)
+            nb.set_band_coeffs(i, c, en); bp.set_band_coeffs(i, c, en)
+        elif op < 0.86:
+            on = bool(rng.random() < 0.7)
+            nb.set_eq_enabled(on); bp.set_eq_enabled(on)
+        elif op < 0.92:
+            g = float(np.float32(rng.uniform(0.2, 1.0)))
+            nb.set_gain(g); bp.set_gain(g)
+        elif op < 0.96:
+            plan = int(rng.integers(0, 3))
+            nb.set_conv_plan(plan); bp.set_conv_plan(plan)
+        else:
+            nb.reset(); bp.reset()
+
+
+def _band_args(b, fs):
+    return b.filter_type, fs, b.center_freq, b.q, b.gain_db
