@@ -417,7 +417,12 @@ int  ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h
  * the devices' queues fill side by side; nothing crosses PCIe or xGMI -- all mutable state is per stream
  * (convolution.rs:36-42,76-79; parametric_eq.rs:125-129).  Returns when every device has QUEUED its work: the outputs
  * are complete after ohs_node_batch_sync.  Calls queue up in order; the set_* / reset calls of the node batch wait for
- * what is queued.  Results are bit-identical to ohs_batch_process on one device holding the same streams.
+ * what is queued.  Results are bit-identical to ohs_batch_process on one device holding the same streams when every
+ * path has one partition (taps <= 512, plan 1: every block is computed on its own).  With longer impulse responses the
+ * time-parallel kernels cut a call into segments of max(8, min(16384 / streams on the device, 1024)) blocks and round
+ * differently across a segment or call boundary (stored overlap, added in time) than inside one (overlap folded into
+ * the spectrum): a shard and the unsharded batch agree bit for bit only while they cut alike, otherwise within the
+ * parity bar (<= 1e-6 relative RMS against the reference either way).
  * Failure: if ANY slot fails the call returns that slot's status ("device slot k: ...") and the node batch refuses
  * every later ohs_node_batch_process / _process_host with OHS_ERR_HIP until ohs_node_batch_reset (the other shards have
  * advanced: the node's streams are out of step).  Likewise after a table call that failed half-way (devices hold

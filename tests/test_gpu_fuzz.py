@@ -246,9 +246,11 @@ def test_fuzz_node_batch_slots_against_one_batch(ohs, synth, exp_tuning, seed):
                 torch.cuda.synchronize()
                 nb.process(xs, ys); nb.sync()
                 y = torch.cat(ys)
-            else:                           # host-buffer form
-                y = torch.from_numpy(nb.process_host(x.cpu().numpy(), chunk_blocks=int(rng.choice([0, 4, 16])))).to(dev)
-            y_one = bp.process(x)
+                y_one = bp.process(x)
+            else:                           # host-buffer form: the same time chunks on both sides (with partitions > 1 the
+                cb = int(rng.choice([0, 4, 16]))    # long-IR kernels round differently across a call boundary than inside)
+                y = torch.from_numpy(nb.process_host(x.cpu().numpy(), chunk_blocks=cb)).to(dev)
+                y_one = torch.from_numpy(bp.process_host(x.cpu().numpy(), chunk_blocks=cb)).to(dev)
             torch.cuda.synchronize()
             assert torch.equal(y.view(torch.int32), y_one.view(torch.int32)), (seed, step, slots, S, n)
         elif op < 0.70:
