@@ -58,7 +58,7 @@ def _units():
         ("conv_mac_kernels.hip", [f"-D{k}={os.environ[k]}" for k in ("OHS_MAC_TB", "OHS_MAC_PI")
                                   if EXPERIMENTS and k in os.environ]),
         ("eq_kernels.hip", ["-ffp-contract=off"]),
-        ("ohs_api.hip", []),
+        ("api_core.hip", []), ("api_conv.hip", []), ("api_eq.hip", []), ("api_engine.hip", []), ("api_batch.hip", []),   # the C ABI (api_internal.h)
         ("sofa_reader.cpp", ["-x", "hip"]),     # host-only C++ (HDF5 subset reader), built by the same driver
         ("sofa_conditioning.cpp", ["-x", "hip"]),   # host-only C++ (libmysofa-style loudness / interpolation)
         ("autoeq_parser.cpp", ["-x", "hip"]),   # host-only C++ (AutoEQ CSV)
@@ -86,6 +86,7 @@ def _deps(src: str) -> list[str]:
     deps = [os.path.join(CSRC, src)]
     deps += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc")))
     deps.append(os.path.join(os.path.dirname(HERE), "include", "ohs_hip.h"))
+    deps.append(os.path.join(CSRC, "exports.map"))
     deps.append(os.path.abspath(__file__))
     return deps
 
@@ -148,7 +149,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 json.dump(_parse_resource_remarks(remarks), f, indent=1, sort_keys=True)
             with open(obj + ".hash", "w") as f:
                 f.write(want[src])
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz", "-ldl", "-lpthread"]
+    # exported surface = the C ABI (csrc/exports.map); the C++ internals stay local
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-lz", "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

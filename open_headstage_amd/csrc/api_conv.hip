@@ -1,0 +1,478 @@
+// api_conv.hip -- the convolution state of a handle (ConvState: one stream for ohs_engine, S streams for ohs_batch):
+// set_ir (convolution.rs:111-139), the ring of input spectra, and conv_launch, which picks the kernels that serve a call
+// (one partition: k_conv_p1 / k_conv_p1_os; several: the time-parallel kernels, k_conv_tp_old after a per-path set_ir,
+// k_conv_general as the fallback).
+#include "api_internal.h"
+
+using namespace ohs;
+using namespace ohs_api;
+
+namespace ohs_api {
+
+void conv_free(ConvState &c)
+{
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    for (int p = 0; p < 4; ++p) { if (c.d_H[p]) hipFree(c.d_H[p]); c.d_H[p] = nullptr; }
+    if (c.d_hist) hipFree(c.d_hist);
+    if (c.d_tails) hipFree(c.d_tails);
+    if (c.d_tails_alt) hipFree(c.d_tails_alt);
+    if (c.d_cd) hipFree(c.d_cd);
+    if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
+    if (c.d_cdm) hipFree(c.d_cdm);
+    if (c.d_W) hipFree(c.d_W);
+    if (c.d_W1) hipFree(c.d_W1);
+    if (c.d_merged) hipFree(c.d_merged);
+    if (c.d_merged_alt) hipFree(c.d_merged_alt);
+    if (c.d_last_in) hipFree(c.d_last_in);
+    if (c.d_irt) hipFree(c.d_irt);
+    if (c.d_cd_os) hipFree(c.d_cd_os);
+    c.d_irt = nullptr; c.d_cd_os = nullptr; c.cd_os_valid = false;
+    c.d_merged = nullptr; c.d_merged_alt = nullptr; c.d_last_in = nullptr; c.tails_lazy = false; c.lazy_ok = false;
+    c.d_cdm = nullptr; c.d_W = nullptr; c.d_W1 = nullptr;
+    c.d_hist = nullptr; c.d_tails = nullptr; c.d_tails_alt = nullptr; c.d_cd = nullptr; c.d_chunk_tails = nullptr;
+}
+
+int conv_init(ConvState &c, size_t S, hipStream_t st)
+{
+    c.S = S;
+    for (int p = 0; p < 4; ++p) {
+        // default path: one all-zero partition (convolution.rs:46-63); FFT(0) == 0
+        HIP_TRY(hipMalloc(&c.d_H[p], NF * sizeof(float2)));
+        HIP_TRY(hipMemsetAsync(c.d_H[p], 0, NF * sizeof(float2), st));
+        c.P[p] = 1;
+        c.since[p] = 0;
+    }
+    c.cap = 1;
+    c.cnt = 0;
+    HIP_TRY(hipMalloc(&c.d_hist, S * (size_t)c.cap * NF * sizeof(float2)));
+    HIP_TRY(hipMemsetAsync(c.d_hist, 0, S * (size_t)c.cap * NF * sizeof(float2), st));
+    HIP_TRY(hipMalloc(&c.d_tails, S * 2 * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMemsetAsync(c.d_tails, 0, S * 2 * 8 * 64 * sizeof(float2), st));
+    HIP_TRY(hipMalloc(&c.d_tails_alt, S * 2 * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c.d_cd, 2 * NF * sizeof(float2)));
+    c.cd_valid = false;
+    return OHS_OK;
+}
+
+// Batch objects let the P = 1 fast path leave its state behind lazily: a k_conv_p1 launch then ends with the merged
+// overlap of its last block and a copy of that block's input instead of a k_conv_p1_state launch (9 us + a launch gap
+// per call, hidden nowhere when the convolution runs alone); the next fast launch starts from the merged overlap -- which
+// also makes a call boundary invisible in the output bits.  (Tuning::p1_lazy_state = 0: the per-path state after every launch.)
+int conv_enable_lazy_state(ConvState &c)
+{
+    if (!tuning().p1_lazy_state) return OHS_OK;
+    HIP_TRY(hipMalloc(&c.d_merged, c.S * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c.d_merged_alt, c.S * 8 * 64 * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c.d_last_in, c.S * 2 * BS * sizeof(float)));
+    HIP_TRY(hipMalloc(&c.d_irt, 4 * BS * sizeof(float)));
+    HIP_TRY(hipMemset(c.d_irt, 0, 4 * BS * sizeof(float)));        // (default paths: one all-zero partition)
+    HIP_TRY(hipMalloc(&c.d_cd_os, 2 * NF * sizeof(float4)));
+    c.cd_os_valid = false;
+    c.lazy_ok = true;
+    c.tails_lazy = false;
+    return OHS_OK;
+}
+
+// the per-path overlaps (d_tails) from the lazy state: whoever reads or edits d_tails calls this first -- a per-path
+// set_ir (with the OLD spectra still in place: the overlaps belong to them), the general and the long-IR kernels
+int conv_materialise_state(ConvState &c, DeviceCtx *ctx, hipStream_t st)
+{
+    if (!c.tails_lazy) return OHS_OK;
+    ConvP1Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = c.d_last_in; a.in_stream_stride = 2 * (long long)BS; a.in_ch_stride = (long long)BS;
+    a.n_blocks = 1; a.n_streams = (int)c.S;
+    for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
+    a.tails_out = c.d_tails;
+    a.tw = ctx->d_tw; a.fp_mode = c.fp_mode;
+    a.xcd_lo = 0; a.xcd_n = 8;
+    hipError_t e = launch_conv_p1_state(a, st);
+    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1_state launch: ") + hipGetErrorString(e));
+    c.tails_lazy = false;
+    return OHS_OK;
+}
+
+// grow the spectrum ring so that cap >= need, keeping the most recent old_cap blocks
+int conv_grow_ring(ConvState &c, int need, hipStream_t st)
+{
+    if (need <= c.cap) return OHS_OK;
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    const int ncap = next_pow2(need);
+    float2 *nh = nullptr;
+    HIP_TRY(hipMalloc(&nh, c.S * (size_t)ncap * NF * sizeof(float2)));
+    HIP_TRY(hipMemsetAsync(nh, 0, c.S * (size_t)ncap * NF * sizeof(float2), st));
+    for (int i = 0; i < c.cap; ++i) {
+        if (c.cnt < (unsigned long long)(i + 1)) break;
+        const unsigned long long u = c.cnt - 1 - (unsigned long long)i;
+        const size_t so = (size_t)(u & (unsigned long long)(c.cap - 1));
+        const size_t sn = (size_t)(u & (unsigned long long)(ncap - 1));
+        // one strided copy over all streams
+        HIP_TRY(hipMemcpy2DAsync(nh + sn * NF, (size_t)ncap * NF * sizeof(float2),
+                                 c.d_hist + so * NF, (size_t)c.cap * NF * sizeof(float2),
+                                 NF * sizeof(float2), c.S, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(c.d_hist);
+    c.d_hist = nh;
+    c.cap = ncap;
+    return OHS_OK;
+}
+
+// set_ir (convolution.rs:111-139) for one path; `ir` is a host pointer, or a device pointer on the state's
+// device when ir_on_device (the node-level batch hands over what RCCL has just broadcast)
+int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st,
+                bool ir_on_device)
+{
+    if (path < 0 || path > 3) return fail(OHS_ERR_INVALID_ARG, "path must be 0..3");
+    if (len && !ir) return fail(OHS_ERR_INVALID_ARG, "ir is NULL");
+    if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
+    const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
+    DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    {   // the overlaps at rest belong to the spectra that are about to be replaced
+        const int rcm = conv_materialise_state(c, ctx, st);
+        if (rcm) return rcm;
+    }
+    // every failure path below frees what it allocated: a HIP_TRY inside the lambda returns from the
+    // lambda only, the buffers are released after it
+    float2 *nH = nullptr;
+    float *d_ir = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&nH, (size_t)P * NF * sizeof(float2)));
+        if (len == 0) {
+            HIP_TRY(hipMemsetAsync(nH, 0, NF * sizeof(float2), st));   // :114-118 mute
+        } else {
+            const float *src = ir;
+            if (!ir_on_device) {
+                HIP_TRY(hipMalloc(&d_ir, len * sizeof(float)));
+                HIP_TRY(hipMemcpyAsync(d_ir, ir, len * sizeof(float), hipMemcpyHostToDevice, st));
+                src = d_ir;
+            }
+            HIP_TRY(launch_ir_spectrum(src, (int)len, P, nH, ctx->d_tw, st));
+            if (c.d_irt && P == 1) {        // the overlap-save plan builds its 2048-point tables from the taps themselves
+                HIP_TRY(hipMemsetAsync(c.d_irt + path * BS, 0, BS * sizeof(float), st));
+                HIP_TRY(hipMemcpyAsync(c.d_irt + path * BS, src, len * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+        }
+        if (c.d_irt && len == 0) HIP_TRY(hipMemsetAsync(c.d_irt + path * BS, 0, BS * sizeof(float), st));
+        int rc = conv_grow_ring(c, P, st);
+        if (rc) return rc;
+        // one wait: the spectrum kernel has read d_ir, and nothing queued earlier on `st` still reads the
+        // old d_H[path]
+        HIP_TRY(hipStreamSynchronize(st));
+        return OHS_OK;
+    };
+    const int rc0 = body();
+    if (d_ir) hipFree(d_ir);
+    if (rc0) { if (nH) hipFree(nH); return rc0; }
+    hipFree(c.d_H[path]);
+    c.d_H[path] = nH;
+    c.P[path] = P;
+    c.spk_set[path] = false;
+    c.cd_os_valid = false;
+    c.cd_valid = false;
+    c.cdm_valid = false;
+    c.since[path] = 0;      // :135-137 that path's history is "all zero" again
+    if (c.since[0] == 0 && c.since[1] == 0 && c.since[2] == 0 && c.since[3] == 0) {
+        // every path has forgotten its past: the ring holds nothing any path may still see.  Zeroing
+        // it lets the gate-free time-parallel kernels run right away (all `since` equal).
+        HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), st));
+    }
+    // :138 that path's overlap := 0.  Tails are (lsl + j lsr) and (rsl + j rsr).
+    const int which = path >> 1, comp = path & 1;
+    HIP_TRY(launch_zero_tail_component(c.d_tails, (long long)c.S, which, comp, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return OHS_OK;
+}
+
+// Chunks per stream of the P = 1 kernel: at least ONE round of resident waves (CUs x 16), and a wave count S * K that
+// FILLS its last round -- all waves of a launch take the same time, so 2.13 rounds cost 3 (1024 and 2048 streams with
+// K = ceil(2 R / S) ran at 71 % for that reason).  K is the smallest value from ceil(R / S) upwards whose last round is
+// >= 97 % full.  (Rounds 1 and 2 asked for two rounds; since the chunk lengths follow the waves' age ranks one exact
+// round is the faster plan -- config 3 without EQ: 4096 waves 0.537-0.541 ms, 8192 waves 0.549-0.555, 3840 0.563,
+// 4352 0.81 -- and the pre-pass has half the boundary tails to compute.  Tuning::p1_rounds = 2 restores the old rule.)
+long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override, int xcd_n)
+{
+    const long long R = (long long)ctx->num_cus * xcd_n / 8 * conv_p1_waves_per_cu();
+    long long K;
+    if (target_override > 0) {
+        K = (target_override + (long long)S - 1) / (long long)S;
+    } else {
+        const long long rounds = tuning().p1_rounds;
+        const long long k0 = std::max<long long>(1, (rounds * R + (long long)S - 1) / (long long)S);
+        K = k0;
+        double best = 0.0;
+        for (long long k = k0; k < k0 + 32; ++k) {
+            const double rd = (double)((long long)S * k) / (double)R;
+            const double eff = rd / std::ceil(rd - 1e-9);
+            if (eff > best + 1e-9) { best = eff; K = k; }
+            if (eff >= 0.97) break;
+        }
+    }
+    // One chunk per stream (4096 streams and more) leaves the age ranks nothing to balance: two chunks, dealt out over
+    // ranks {0, 3} / {1, 2} (conv_kernels.hip: p1_wave_job), cost a second round but end together -- 4096 streams: 8.9 ->
+    // 8.0 ms of convolution per step.
+    if (K == 1 && n_blocks >= 16 && target_override <= 0 && conv_p1_waves_per_cu() == 16) K = 2;
+    if (n_blocks < 4 * K && target_override <= 0) {
+        // A short launch (the last, 2 % time chunk of an overlapped batch step: 19 blocks), a few blocks per wave at
+        // best: every chunk boundary costs the pre-pass a block's work, and a wave count just above a round starts a second,
+        // almost empty one.  Cost in block times: rounds x blocks per wave for the main kernel + rounds for the boundary
+        // tails (one more block per wave where the chunks' own waves compute them -- K = 2, 4, 8, 16 --, else a pre-pass
+        // launch: its rounds + about a block time of launch); the smallest K of minimal cost (19 blocks x 256 streams:
+        // K = 16, one round of at most 2 + 1 blocks, no pre-pass).
+        const bool own_ok = conv_p1_waves_per_cu() == 16;
+        long long best_k = std::min(K, n_blocks), best_cost = -1;
+        for (long long k = 1; k <= std::min(K, n_blocks); ++k) {
+            const long long rounds_main = ((long long)S * k + R - 1) / R, per_wave = (n_blocks + k - 1) / k;
+            long long cost;
+            if (k == 1) cost = rounds_main * per_wave;
+            else if (own_ok && (k == 2 || k == 4 || k == 8 || k == 16)) cost = rounds_main * (per_wave + 1);
+            else cost = rounds_main * per_wave + ((long long)S * (k - 1) + R - 1) / R + 1;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_k = k; }
+        }
+        K = best_k;
+    }
+    if (K > n_blocks) K = n_blocks;
+    if (K < 1) K = 1;
+    return K;
+}
+
+// ohs_batch_set_conv_plan(0): which P = 1 plan the library picks by itself
+bool conv_plan_auto_is_os(size_t S, long long n_blocks)
+{
+    (void)S; (void)n_blocks;
+    return false;
+}
+
+int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
+                float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
+                bool allow_fast, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    // (ev_start / ev_stop: recorded at the start / completion of the call's launches)
+    struct EvScope {        // the paths that do not carry the events in a dispatch: recorded around their launches
+        hipStream_t st; hipEvent_t stop; bool armed;
+        ~EvScope() { if (armed && stop) hipEventRecord(stop, st); }
+    } ev_scope{st, ev_stop, false};
+    if (n_blocks <= 0) {                    // nothing to do (the pre-pass would index block -1)
+        if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
+        if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, st));
+        return OHS_OK;
+    }
+    const bool p1 = c.P[0] == 1 && c.P[1] == 1 && c.P[2] == 1 && c.P[3] == 1;
+    if (p1 && allow_fast) {
+        // every path has one partition: time-parallel single-FFT-pair kernel
+        if (!c.cd_valid) {
+            hipError_t e = launch_build_cd(c.d_H[0], c.d_H[1], c.d_H[2], c.d_H[3], c.d_cd, st);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("build_cd: ") + hipGetErrorString(e));
+            c.cd_valid = true;
+        }
+        const Tuning &tn = tuning();
+        // Two plans for this case (ohs_batch_set_conv_plan): block 512 / FFT 1024 overlap-add (k_conv_p1: the plan whose
+        // output bits tests/golden/p1_output_sha256.txt holds) and hop 1536 / FFT 2048 overlap-save (k_conv_p1_os: a third
+        // less transform and product work per frame; batch objects only -- it hands the lazy state over).
+        const bool os_ok = c.lazy_ok && c.d_irt && n_blocks >= 3 && c.xcd_n == 8 && tn.p1_xcd_n == 0 &&
+                           ((in_ss | in_cs | out_ss | out_cs) & 1) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7) == 0 &&
+                           (unsigned long long)n_blocks * BS + 1536ull < (1ull << 31);
+        const bool use_os = os_ok && (c.conv_plan == 2 || (c.conv_plan == 0 && conv_plan_auto_is_os(c.S, n_blocks)));
+        if (use_os) {
+            if (!c.cd_os_valid) {
+                hipError_t e = launch_os_tables(c.d_irt, ctx->d_tw, ctx->d_tw2048, c.d_cd_os, st);
+                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("os tables: ") + hipGetErrorString(e));
+                c.cd_os_valid = true;
+            }
+            // hop ranges per stream: a divisor of the workgroup's wave count (all of a stream's in one workgroup); rounds of resident waves
+            // x hops per wave (+ 1: the tables and the first window), the smallest count of minimal cost
+            const long long R = (long long)ctx->num_cus * conv_os_waves_per_cu();
+            const long long H = ((long long)n_blocks * BS + 1535) / 1536;
+            int K = 1;
+            long long best = -1;
+            for (int k = 1; k <= conv_os_waves_per_cu() && k <= H; ++k) {
+                if (conv_os_waves_per_cu() % k) continue;       // (all of a stream's chunks in one workgroup)
+                const long long cost = (((long long)c.S * k + R - 1) / R) * ((H + k - 1) / k + 1);
+                if (best < 0 || cost < best) { best = cost; K = k; }
+            }
+            ConvOsArgs o;
+            o.in = in; o.out = out;
+            o.in_stream_stride = in_ss; o.in_ch_stride = in_cs; o.out_stream_stride = out_ss; o.out_ch_stride = out_cs;
+            o.n_blocks = n_blocks; o.n_streams = (int)c.S; o.chunks = K;
+            o.CD = c.d_cd_os; o.tw2048 = ctx->d_tw2048;
+            o.tails = c.d_tails; o.merged_in = c.tails_lazy ? c.d_merged : nullptr;
+            o.merged_out = c.d_merged_alt; o.last_in = c.d_last_in;
+            o.tw = ctx->d_tw; o.gain = gain; o.fp_mode = c.fp_mode;
+            hipError_t e = launch_conv_p1_os(o, st, ev_start, ev_stop);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1_os launch: ") + hipGetErrorString(e));
+            std::swap(c.d_merged, c.d_merged_alt);
+            c.tails_lazy = true;
+            c.cnt += (unsigned long long)n_blocks;
+            for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;
+            return OHS_OK;
+        }
+        const long long target_override = tn.p1_target_waves;
+        int xcd_lo = c.xcd_lo, xcd_n = c.xcd_n;
+        if (tn.p1_xcd_n > 0) { xcd_lo = tn.p1_xcd_lo; xcd_n = tn.p1_xcd_n; }
+        const long long K = conv_p1_chunks(ctx, c.S, n_blocks, target_override, xcd_n);
+        if ((size_t)K > c.chunk_tails_cap) {
+            DeviceWideSection dws;
+            HIP_TRY(hipStreamSynchronize(st));
+            if (c.d_chunk_tails) hipFree(c.d_chunk_tails);
+            c.d_chunk_tails = nullptr; c.chunk_tails_cap = 0;
+            HIP_TRY(hipMalloc(&c.d_chunk_tails, c.S * (size_t)K * 512 * sizeof(float2)));
+            c.chunk_tails_cap = (size_t)K;
+        }
+        ConvP1Args a;
+        a.in = in; a.out = out;
+        a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+        a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+        a.n_blocks = n_blocks; a.n_streams = (int)c.S; a.chunks = (int)K;
+        a.CD = c.d_cd;
+        for (int p = 0; p < 4; ++p) a.H[p] = c.d_H[p];
+        a.tails = c.d_tails; a.tails_out = c.d_tails_alt; a.chunk_tails = c.d_chunk_tails;
+        a.merged_in = c.tails_lazy ? c.d_merged : nullptr;
+        a.merged_out = c.lazy_ok ? c.d_merged_alt : nullptr;
+        a.last_in = c.lazy_ok ? c.d_last_in : nullptr;
+        a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
+        a.xcd_lo = xcd_lo; a.xcd_n = xcd_n;
+        {   // boundary tails by the chunks' own waves where a stream's chunks share a workgroup (else: the pre-pass)
+            const bool allowed = conv_p1_waves_per_cu() == 16 && (K == 2 || K == 4 || K == 8 || K == 16);
+            a.own_tails = (allowed && tn.p1_own_tails) ? 1 : 0;
+        }
+        a.stagger = tn.p1_stagger;
+        a.prio_mode = tn.p1_prio;
+        // Chunk lengths by the age rank of the wave that runs a chunk (p1_chunk_begin), equal lengths when chunks are
+        // short.  In the plans that do not spread a stream's chunks over the ranks, ALL of a stream's chunks can sit on
+        // heavy ranks: its shortest chunk is then n * wmin / (K * wmax) blocks, and that one must keep >= 2 blocks (a
+        // chunk of zero blocks would make the boundary-tail code index block b0 - 1 = -1).
+        const int *kw = tn.p1_weights;
+        const int wmin = std::min(std::min(kw[0], kw[1]), std::min(kw[2], kw[3]));
+        const int wmax = std::max(std::max(kw[0], kw[1]), std::max(kw[2], kw[3]));
+        const bool weighted = (long long)n_blocks * wmin >= 2ll * K * wmax;
+        for (int g = 0; g < 4; ++g) a.weights[g] = weighted ? kw[g] : 1;
+        hipError_t e = launch_conv_p1(a, st, ev_start, ev_stop);
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_p1 launch: ") + hipGetErrorString(e));
+        if (c.lazy_ok) {
+            std::swap(c.d_merged, c.d_merged_alt);
+            c.tails_lazy = true;
+        } else {
+            std::swap(c.d_tails, c.d_tails_alt);
+        }
+    } else {
+        if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
+        ev_scope.armed = true;
+        {   // these kernels read and write the per-path overlaps
+            const int rcm = conv_materialise_state(c, ctx, st);
+            if (rcm) return rcm;
+        }
+        int Pmax = 1;
+        for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
+        const bool since_equal = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3];
+        bool since_old = true;
+        for (int p = 0; p < 4; ++p) since_old = since_old && c.since[p] >= c.P[p] - 1;
+        // gate-free condition of the time-parallel kernels: no path may have blocks in the ring that
+        // it must not see (either every path is older than its own IR -- path p reads P[p] - 1 blocks back --, or all
+        // were reset together: conv_set_ir zeroed the ring then)
+        const bool gate_free = since_old || since_equal;
+        // Otherwise -- a per-path set_ir in mid-stream -- the same three kernels run on a ring whose old blocks they
+        // cannot reach (the call starts Ppad - 1 zeroed slots further on) and k_conv_tp_old adds what each path may
+        // still see of them to the first Pmax - 1 blocks.  The first segment must reach beyond every old block
+        // (n_blocks >= Pmax): the state it leaves behind is computed gate-free.  Shorter calls take the general kernel
+        // (one wave per stream, blocks in sequence: 290 x slower on BASELINE config 4, which is why long calls do not).
+        const bool tp_gated = allow_fast && !gate_free && n_blocks >= 4 && n_blocks >= Pmax;
+        const bool tp = allow_fast && n_blocks >= 4 && (gate_free || tp_gated);
+        auto general = [&](const float *gin, float *gout, int nb, unsigned long long cnt, int since_add,
+                           int skip_store, int zero_in, float2 *tails_out) -> int {
+            ConvGeneralArgs a;
+            a.in = gin; a.out = gout;
+            a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+            a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+            a.n_blocks = nb;
+            for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p] + since_add; }
+            a.hist = c.d_hist; a.cap = c.cap; a.cnt = cnt;
+            a.tails = c.d_tails; a.tails_out = tails_out;
+            a.skip_store = skip_store; a.zero_tails_in = zero_in;
+            a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
+            hipError_t e = launch_conv_general(a, (int)c.S, st);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+            return OHS_OK;
+        };
+        if (!tp) {
+            int rc = general(in, out, n_blocks, c.cnt, 0, 0, 0, c.d_tails);
+            if (rc) return rc;
+        } else {
+            // segment size: keep the MAC scratch around 128 MiB
+            long long SEG = 16384 / (long long)c.S;
+            SEG = std::max<long long>(8, std::min<long long>(SEG, 1024));
+            if (tp_gated) SEG = std::max<long long>(SEG, Pmax);
+            const long long seg_max = std::min<long long>(SEG, n_blocks);
+            const int Ppad = Ppad_for_ring(Pmax);
+            // (gated: old blocks + the zeroed gap + the segment live in the ring together)
+            int rc = conv_grow_ring(c, (int)(seg_max + (tp_gated ? 2 : 1) * (Ppad - 1) + (tp_gated ? Pmax : 0)), st);
+            if (rc) return rc;
+            const unsigned long long cnt_old = c.cnt;
+            if (tp_gated) {
+                // the zeroed gap: ring slots cnt .. cnt + Ppad - 2 of every stream (two strided memsets when it wraps)
+                const unsigned long long gap = (unsigned long long)(Ppad - 1), cap = (unsigned long long)c.cap;
+                const unsigned long long s0 = c.cnt & (cap - 1), n0 = std::min(gap, cap - s0);
+                const size_t pitch = (size_t)c.cap * NF * sizeof(float2);
+                HIP_TRY(hipMemset2DAsync(c.d_hist + s0 * NF, pitch, 0, (size_t)n0 * NF * sizeof(float2), c.S, st));
+                if (n0 < gap)
+                    HIP_TRY(hipMemset2DAsync(c.d_hist, pitch, 0, (size_t)(gap - n0) * NF * sizeof(float2), c.S, st));
+                c.cnt += gap;
+            }
+            if (!c.d_cdm || c.cdm_ppad != Ppad) {       // (a set_ir that keeps Ppad re-uses the buffer: no wait, no malloc)
+                DeviceWideSection dws;
+                HIP_TRY(hipStreamSynchronize(st));
+                if (c.d_cdm) hipFree(c.d_cdm);
+                c.d_cdm = nullptr; c.cdm_valid = false;
+                HIP_TRY(hipMalloc(&c.d_cdm, (size_t)Ppad * 2 * NF * sizeof(float2)));
+                c.cdm_ppad = Ppad;
+            }
+            if (!c.cdm_valid) {
+                hipError_t e = launch_build_cd_multi(c.d_H[0], c.d_H[1], c.d_H[2], c.d_H[3], c.P[0], c.P[1],
+                                                     c.P[2], c.P[3], Ppad, c.d_cdm, st);
+                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("build_cd_multi: ") + hipGetErrorString(e));
+                c.cdm_ppad = Ppad; c.cdm_valid = true;
+            }
+            if ((size_t)seg_max > c.w_blocks) {
+                DeviceWideSection dws;
+                HIP_TRY(hipStreamSynchronize(st));
+                if (c.d_W) hipFree(c.d_W);
+                c.d_W = nullptr; c.w_blocks = 0;
+                HIP_TRY(hipMalloc(&c.d_W, c.S * (size_t)seg_max * NF * sizeof(float2)));
+                c.w_blocks = (size_t)seg_max;
+            }
+            if (!c.d_W1) HIP_TRY(hipMalloc(&c.d_W1, c.S * (size_t)NF * sizeof(float2)));
+            long long done = 0;
+            while (done < n_blocks) {
+                const int seg = (int)std::min<long long>(SEG, n_blocks - done);
+                ConvTpArgs a;
+                a.in = in + done * BS; a.out = out + done * BS;
+                a.in_stream_stride = in_ss; a.in_ch_stride = in_cs;
+                a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+                a.n_streams = (int)c.S; a.seg_blocks = seg; a.n_mac = seg; a.Ppad = Ppad;
+                a.CD = c.d_cdm; a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt + (unsigned long long)done;
+                a.W = c.d_W; a.W1 = c.d_W1; a.tails = c.d_tails; a.tails_out = c.d_tails_alt;
+                a.pairs = ctx->d_pairs; a.n_pairs = ctx->n_pairs;
+                a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
+                hipError_t e = launch_conv_tp_forward(a, st);
+                if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
+                if (e == hipSuccess && tp_gated && done == 0 && Pmax > 1) {
+                    ConvTpOldArgs o;
+                    o.n_streams = (int)c.S; o.n_old = Pmax - 1; o.Pmax = Pmax;
+                    for (int p = 0; p < 4; ++p) { o.H[p] = c.d_H[p]; o.P[p] = c.P[p]; o.since[p] = c.since[p]; }
+                    o.hist = c.d_hist; o.cap = c.cap; o.cnt_old = cnt_old;
+                    o.W = c.d_W; o.n_mac = seg; o.fp_mode = c.fp_mode;
+                    e = launch_conv_tp_old(o, st);
+                }
+                if (e == hipSuccess) e = launch_conv_tp_inverse(a, st);   // block 0 reads the OLD state; new state -> the other slab
+                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp: ") + hipGetErrorString(e));
+                std::swap(c.d_tails, c.d_tails_alt);
+                done += seg;
+            }
+        }
+    }
+    c.cnt += (unsigned long long)n_blocks;
+    for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;
+    return OHS_OK;
+}
+
+}  // namespace ohs_api

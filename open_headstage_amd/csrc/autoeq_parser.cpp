@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-extern "C" void ohs_internal_set_error(const char *msg);     // ohs_api.hip: feeds ohs_last_error()
+extern "C" void ohs_internal_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
 
 namespace {
 

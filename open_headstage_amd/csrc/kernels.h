@@ -153,7 +153,7 @@ struct ConvP1Args {
     // Lazy state (batch objects): merged_out != nullptr -- the launch leaves its state as the MERGED overlap of its last
     // block ([stream][8][64], what its own chunks hand each other) plus a copy of that block's input frames
     // (last_in: [stream][2][512]), and k_conv_p1_state is not launched; the per-path overlaps the state at rest
-    // consists of are computed from last_in when somebody needs them (ohs_api.hip: conv_materialise_state).
+    // consists of are computed from last_in when somebody needs them (api_conv.hip: conv_materialise_state).
     // merged_in != nullptr: the state the launch starts from is such a merged overlap (else tails: the per-path form).
     const float2 *merged_in;
     float2 *merged_out;

@@ -439,7 +439,7 @@ struct Reader {
 
 #include "sofa_internal.h"
 
-extern "C" void ohs_internal_set_error(const char *msg);     // ohs_api.hip: feeds ohs_last_error()
+extern "C" void ohs_internal_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
 namespace {
 int sfail(int code, const std::string &m) { ohs_internal_set_error(m.c_str()); return code; }
 const double kPi = 3.14159265358979323846264338327950288;
