@@ -71,7 +71,6 @@ inline int next_pow2(int v)
     return p;
 }
 
-// ---- convolution state shared by the engine (1 stream) and batch (S streams) ----
 // ---- resident real-time kernels vs. device-wide waits ------------------------------------------------------
 // hipFree, hipDeviceSynchronize and hipHostFree wait for EVERY kernel on the device -- a resident real-time kernel
 // (k_engine_resident) of some other engine included, which only leaves when its owner stops it or after ~2 s without
@@ -88,7 +87,7 @@ struct RtRegistry {
     int hold = 0;                           // open DeviceWideSections
 };
 extern RtRegistry g_rt_reg[kMaxDevices];
-void rt_request_stop_locked(ohs_engine *e);      // (defined with the mailbox protocol below)
+void rt_request_stop_locked(ohs_engine *e);      // (api_engine.hip, with the mailbox protocol)
 struct DeviceWideSection {
     int dev = 0;
     DeviceWideSection()
@@ -109,6 +108,7 @@ struct DeviceWideSection {
     DeviceWideSection &operator=(const DeviceWideSection &) = delete;
 };
 
+// ---- convolution state shared by the engine (1 stream) and batch (S streams); api_conv.hip ----
 struct ConvState {
     size_t S = 1;
     float2 *d_H[4] = {nullptr, nullptr, nullptr, nullptr};
