@@ -809,11 +809,33 @@ def main() -> int:
             dt = e0.elapsed_time(e1) * 1e-3 / 16
             _, cb_alone = bp.kernel_bytes(n_blocks)
             out["roofline"]["conv_alone"] = {
-                "what": "the same batch with the EQ off, 16 steps back to back after 40 warm-up steps (ONE kernel per step: k_conv_p1; HIP events)",
+                "what": "the same batch with the EQ off, 16 steps back to back after 40 warm-up steps (ONE kernel per step: k_conv_p1, "
+                        "the plan the library picks at this stream count; HIP events)",
                 "ms_per_step": round(dt * 1e3, 4), "Msamples_s": round(args.streams * frames / dt / 1e6, 1),
                 "design_bytes_per_step": int(cb_alone),
                 "achieved": round(cb_alone / dt / 1e9, 1), "unit": "GB/s",
                 "frac": round(cb_alone / dt / 1e9 / HBM_PEAK_GBS, 5)}
+            # the hop-1536 plan (k_conv_p1_os; what the library picks by itself from 512 streams on) on the same batch:
+            # the same 16 B per frame of audio traffic
+            try:
+                bp.set_conv_plan(2)
+                for _ in range(10):
+                    bp.process(x, out=y)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(16):
+                    bp.process(x, out=y)
+                e1.record()
+                torch.cuda.synchronize()
+                dt2 = e0.elapsed_time(e1) * 1e-3 / 16
+                io_bytes = 16.0 * args.streams * frames
+                out["roofline"]["conv_alone"]["hop_1536_plan"] = {
+                    "kernel": "k_conv_p1_os", "ms_per_step": round(dt2 * 1e3, 4),
+                    "achieved": round(io_bytes / dt2 / 1e9, 1), "unit": "GB/s", "frac": round(io_bytes / dt2 / 1e9 / HBM_PEAK_GBS, 5),
+                    "bytes": "16 B per frame (audio in + out)"}
+            except Exception as e:      # noqa: BLE001
+                out["roofline"]["conv_alone"]["hop_1536_plan"] = {"error": str(e)[:200]}
+            bp.set_conv_plan(0)
             bp.set_eq_enabled(True)
             bp.reset()
         except Exception as e:      # noqa: BLE001
@@ -857,11 +879,11 @@ def main() -> int:
             torch.cuda.synchronize()
             dt = sa.elapsed_time(sb) * 1e-3 / 6
             eb2, cb2 = bp2.kernel_bytes(n_blocks)
-            # the same with the overlap-save plan of the one-partition convolution (ohs_batch_set_conv_plan(2); not bit-stable
-            # across call boundaries, hence opt-in): profiles/r04_conv_plan_ab_*.txt
-            dt_os = None
+            # the same with the block-512 plan of the one-partition convolution forced (ohs_batch_set_conv_plan(1)); from 512
+            # streams on the library picks the hop-1536 plan by itself: profiles/r04_conv_plan_ab_run3.txt
+            dt_p1 = None
             try:
-                bp2.set_conv_plan(2)
+                bp2.set_conv_plan(1)
                 for _ in range(2):
                     bp2.process(x2, out=y2)
                 torch.cuda.synchronize()
@@ -870,11 +892,12 @@ def main() -> int:
                     bp2.process(x2, out=y2)
                 sb.record()
                 torch.cuda.synchronize()
-                dt_os = sa.elapsed_time(sb) * 1e-3 / 6
+                dt_p1 = sa.elapsed_time(sb) * 1e-3 / 6
             except Exception:       # noqa: BLE001
                 pass
             sat.append({"streams": S2, "ms_per_step": round(dt * 1e3, 4), "how": "6 steps after 3, HIP events",
-                        "ms_per_step_conv_plan_2": None if dt_os is None else round(dt_os * 1e3, 4),
+                        "conv_plan": "library's choice (hop 1536 / FFT 2048 at this stream count)",
+                        "ms_per_step_conv_plan_1": None if dt_p1 is None else round(dt_p1 * 1e3, 4),
                         "Msamples_s": round(S2 * frames / dt / 1e6, 1),
                         "hbm_frac_8d_model": round(bp2.algorithmic_bytes(n_blocks) / dt / 1e9 / HBM_PEAK_GBS, 5),
                         "hbm_frac_design_bytes": round((eb2 + cb2) / dt / 1e9 / HBM_PEAK_GBS, 5)})

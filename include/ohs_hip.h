@@ -318,11 +318,13 @@ int  ohs_batch_set_gain(ohs_batch *b, float gain);
 /* Which kernel plan serves calls in which every path has ONE partition (taps <= 512, BASELINE configs[2] / [4]):
  *   1  block 512 / FFT 1024, overlap-add -- the reference's own blocking (convolution.rs:22-23); output bits do not depend
  *      on where a signal is cut into calls, and are the ones tests/golden/p1_output_sha256.txt records
- *   2  hop 1536 / FFT 2048, overlap-save -- a third less transform and product work per frame; equal to plan 1 up to f32
- *      rounding (2-3e-7 relative RMS against the oracle, like every FFT path), not bit for bit, and the rounding depends
- *      on where the calls cut the signal
- *   0  the library's choice (default).
- * Longer impulse responses, odd strides and the single-stream engine are not affected. */
+ *   2  hop 1536 / FFT 2048, overlap-save -- a quarter less transform and product work per frame, 11-12 % less time where
+ *      the convolution is what the step waits for; equal to plan 1 up to f32 rounding (2-3e-7 relative RMS against the
+ *      oracle, like every FFT path), not bit for bit, and the rounding depends on where the calls cut the signal
+ *   0  the library's choice (default): plan 2 from 512 streams and 48 blocks per call on, plan 1 below (at BASELINE
+ *      configs[2] the convolution hides under the EQ either way, and the block-512 bits stay as recorded).
+ * Plan 2 needs even strides and 8-byte aligned buffers; calls that do not meet that, longer impulse responses and the
+ * single-stream engine are served as before. */
 int  ohs_batch_set_conv_plan(ohs_batch *b, int plan);
 /* zero every stream's EQ state, history and overlap (IRs and EQ table kept).  Also the way back from a failed handle:
  * a HIP failure in the middle of a processing call leaves the per-stream state advanced for some time chunks only, so

@@ -648,13 +648,19 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
     // re-reads that are served by L2 are not counted).  This is NOT the SURVEY 8d per-block model
     // (ohs_batch_algorithmic_bytes): the P = 1 kernel keeps overlaps in registers and writes no history.
     //   EQ:             audio in + out, state + coefficients
-    //   P = 1:          audio in + out; per stream and chunk boundary the input block in front of it once more (4 KiB;
+    //   P = 1, block 512: audio in + out; per stream and chunk boundary the input block in front of it once more (4 KiB;
     //                   where the pre-pass computes the boundary tails, K not in {2, 4, 8, 16}: the tail written and read
     //                   as well) and the four-overlap state (8 KiB in + 8 KiB out)
     //   P > 1 (time-parallel): audio in, ring write, ring read once, W write, W read, audio out
     const uint64_t eq_sb = 4096u + 4096u + 520u;
     *eq_bytes = b->eq_enable ? nbk * S * eq_sb : 0;
-    if (P == 1) {
+    const bool os_plan = P == 1 && b->conv.lazy_ok &&
+                         (b->conv.conv_plan == 2 || (b->conv.conv_plan == 0 && conv_plan_auto_is_os((size_t)S, (long long)nbk)));
+    if (os_plan) {
+        // hop-1536 plan: audio in + out; per stream the 512 frames in front of every hop range but the first once more
+        // (<= 11 x 4 KiB), the merged overlap in + out and the last input block (3 x 4 KiB)
+        *conv_bytes = nbk * S * 8192u + S * (uint64_t)((conv_os_waves_per_cu() - 1) * 4096 + 3 * 4096);
+    } else if (P == 1) {
         const uint64_t K = (uint64_t)conv_p1_chunks(b->ctx, (size_t)S, (long long)nbk, 0);
         const bool own_tails = conv_p1_waves_per_cu() == 16 && (K == 2 || K == 4 || K == 8 || K == 16);
         // state: per-path overlaps 8 KiB in + 8 KiB out, or (lazy, kernels.h) merged overlap 4 KiB in + 4 KiB out + the

@@ -237,10 +237,15 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
 }
 
 // ohs_batch_set_conv_plan(0): which P = 1 plan the library picks by itself
+// The hop-1536 plan does a quarter less work per frame at three waves per SIMD and wins wherever the convolution's time
+// is exposed: 0.884-0.888 x the block-512 plan's time at 1 024 and 2 048 streams without EQ, 0.976 x with it
+// (profiles/r04_conv_plan_ab_run3.txt).  At 256 streams with the EQ on -- BASELINE configs[2] -- the convolution hides
+// under the EQ's serial chain either way (1.000-1.004 x), and the block-512 plan keeps its two properties there: output
+// bits that do not depend on where the calls cut the signal, and the recorded golden hash.  Short calls stay with it as
+// well (a wave's first and last hops run the guarded form of the hop).
 bool conv_plan_auto_is_os(size_t S, long long n_blocks)
 {
-    (void)S; (void)n_blocks;
-    return false;
+    return S >= 512 && n_blocks >= 48;
 }
 
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,

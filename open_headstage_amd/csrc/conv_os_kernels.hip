@@ -32,18 +32,31 @@
 
 namespace ohs {
 
-// where the next hop's 24 loads are issued: 0 = behind the spectral product, 1 = between the two inverse transforms,
-// 2 = behind both (in front of the stores).  0 keeps 48 more registers alive through both inverse transforms and spills
-// 330 B per lane; 1 and 2 fit (a few per-lane constants aside).  Experiments builds may override.
+// Launch shape and register plan (constants of the product; experiments builds may override them):
+//   OHS_OS_WAVES     waves per workgroup = per CU.  12 = three per SIMD: 168 registers per lane, and the LDS plan below still
+//                    fits (48.5 KiB of tables + 12 slabs = 152.5 KiB).  With 8 (two per SIMD, 256 registers) the kernel is
+//                    issue-latency-bound: at the board's power cap it clocks 2.07 GHz against the block-512 kernel's 1.82
+//                    and needs 11 % more cycles for a quarter less work -- a tie (profiles/r04_power_conv_plans.txt).
+//   OHS_OS_PARK      1: the spectral product's results for slots {0, 1} (16 complex values per lane) wait in the wave's
+//                    exchange slab -- idle between the transforms -- while slots {2, 3} go through.  Without it hipcc
+//                    needs ~290 registers for the product phase and the 12-wave kernel spills 130 scratch instructions
+//                    per hop (0.92 ms per headline-sized step); with it the steady hop has no spill (0.486 ms).
+//   OHS_OS_PREFETCH  where the next hop's 24 loads are issued: 0 = behind the spectral product, 1 = between the two inverse
+//                    transforms, 2 = behind both (in front of the stores).  0 keeps 48 more registers alive through both
+//                    inverse transforms; 2 is the one that fits 168 registers without a spill in the steady hop.
 #if !defined(OHS_OS_PREFETCH) || !defined(OHS_EXPERIMENTS)
 #undef OHS_OS_PREFETCH
-#define OHS_OS_PREFETCH 1
+#define OHS_OS_PREFETCH 2
+#endif
+#if !defined(OHS_OS_PARK) || !defined(OHS_EXPERIMENTS)
+#undef OHS_OS_PARK
+#define OHS_OS_PARK 1
 #endif
 #if !defined(OHS_OS_WAVES) || !defined(OHS_EXPERIMENTS)
 #undef OHS_OS_WAVES
-#define OHS_OS_WAVES 8
+#define OHS_OS_WAVES 12
 #endif
-constexpr int kOsWaves = OHS_OS_WAVES;  // waves per workgroup = per CU (8: two per SIMD, 12: three)
+constexpr int kOsWaves = OHS_OS_WAVES;
 constexpr int kOsHop = 1536;
 // LDS: twiddle tables + (C, D) lo / hi [2][16][64] float4 + w2048 [16][64] float2 + one FFT slab per wave
 constexpr size_t kOsCdComplex = 2 * 2 * kFft;      // float4 = 2 float2
@@ -259,6 +272,15 @@ __device__ __forceinline__ void os_hop(const ConvOsArgs &A, const OsWave &w, int
         product(i, xli, xhi, xhm, xlm, twi);
         product(m, xlm, xhm, xhi, xli, twm);
     }
+    // the results of slots {0, 1} wait in the wave's exchange slab (idle between the transforms) while slots {2, 3} go
+    // through: 32 registers less alive there -- what three waves per SIMD (168 registers) need
+#if OHS_OS_PARK
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lds_st(&w.lds[j * 64 + lane], E[j]); lds_st(&w.lds[(8 + j) * 64 + lane], O[j]); }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     {
         float2 Xl[8], Xh[8];
 #pragma unroll
@@ -281,6 +303,13 @@ __device__ __forceinline__ void os_hop(const ConvOsArgs &A, const OsWave &w, int
             product(i, Xl[j], Xh[j], ml, mh, lds_ld(&w.tw2[i * 64 + lane]));
         }
     }
+#if OHS_OS_PARK
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { E[j] = lds_ld(&w.lds[j * 64 + lane]); O[j] = lds_ld(&w.lds[(8 + j) * 64 + lane]); }
+    wave_lds_sync();
+#endif
 #if OHS_OS_PREFETCH == 0
     if (!GENERIC) os_load_new<false>(w, h + 1, lane, nl, nr);
     else if (h + 1 < w.h1) os_load_new<true>(w, h + 1, lane, nl, nr);
@@ -401,9 +430,10 @@ __global__ __launch_bounds__(64 * kOsWaves) void k_conv_p1_os(const ConvOsArgs A
     __syncthreads();
     if (!active) return;
 
-    // steady hops: whole, not the call's first, and followed by a whole hop of this wave's range
+    // steady hops: whole, not the call's first, and followed by a whole hop OF THE CALL (the steady hop requests the next
+    // hop's frames unguarded; at the end of a chunk these belong to the next chunk's wave and are read for nothing)
     const int F = (int)(w.n_frames / kOsHop);                   // whole hops of the call
-    const int hs = (h1 < F ? h1 : F) - 1;                       // hops [.., hs) are steady
+    const int hs = h1 < F - 1 ? h1 : F - 1;                     // hops [.., hs) are steady
     int h = h0;
     if (h == 0 || h >= hs) { os_hop<true>(A, w, h, lane, plan, pl, pr, nl, nr); ++h; }
     for (; h < hs; ++h) os_hop<false>(A, w, h, lane, plan, pl, pr, nl, nr);

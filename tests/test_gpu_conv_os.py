@@ -1,6 +1,6 @@
 """The overlap-save plan of the one-partition batch path (ohs_batch_set_conv_plan(2): hop 1536 / FFT 2048,
 csrc/conv_os_kernels.hip) against the oracle, the f64 ground truth and the block-512 plan: every hop-count remainder (the
-last window holds 512, 1024 or 1536 new frames), every chunk count the launcher picks (1, 2, 4, 8 hop ranges per stream),
+last window holds 512, 1024 or 1536 new frames), every chunk count the launcher picks (1, 2, 3, 4, 6, 12 hop ranges per stream),
 in place, with the EQ in front, across calls that alternate between the two plans (they hand the same state over: the
 merged overlap and the last input block), and across a per-path set_ir in mid-stream."""
 import numpy as np
@@ -51,7 +51,9 @@ def test_overlap_save_plan_matches_the_oracle_and_f64(oracle, n_blocks):
     assert r <= 1e-6
 
 
-@pytest.mark.parametrize("S,n_blocks,want_chunks", [(2048, 12, 1), (600, 40, 2), (300, 60, 4), (37, 100, 8)])
+# (hop ranges per stream the launcher picks with twelve waves per CU on 256 CUs: api_conv.hip)
+@pytest.mark.parametrize("S,n_blocks,want_chunks", [(2048, 12, 1), (1536, 40, 2), (1000, 24, 3), (600, 60, 4), (300, 100, 6),
+                                                  (37, 100, 12)])
 def test_every_chunk_count_of_the_launcher(S, n_blocks, want_chunks):
     """against the block-512 plan on all streams (both are 2-3e-7 from the truth), in place and out of place"""
     import torch
@@ -120,3 +122,37 @@ def test_plan_argument_and_fallbacks():
     bp.set_ir(0, synth.hrir_set(1300)[0]); ref.set_ir(0, synth.hrir_set(1300)[0])
     x = torch.from_numpy(synth.white_noise(range(5, 7), 12 * 512)).cuda()
     assert torch.equal(bp.process(x).view(torch.int32), ref.process(x).view(torch.int32))
+
+
+def test_the_library_picks_the_hop_plan_from_512_streams_on(oracle):
+    """ohs_batch_set_conv_plan(0), the default: the hop-1536 plan from 512 streams and 48 blocks per call on (where the
+    convolution's time is exposed: profiles/r04_conv_plan_ab_run3.txt), the block-512 plan below -- BASELINE configs[2]
+    keeps the bits the golden hash records.  Told by the bits: each choice must equal the explicit plan it stands for."""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    dev = torch.device("cuda:0")
+    for S, n_blocks, want in ((512, 60, 2), (512, 40, 1), (256, 60, 1), (700, 48, 2)):
+        base = synth.white_noise_torch(90 + S, 3, 2 * n_blocks * 512, dev)
+        x = base[torch.arange(S, device=dev) % 3].contiguous()
+        out = {}
+        for plan in (0, 1, 2):
+            bp, irs = _make(ohs, synth, S, plan, eq=True, gain=0.7)
+            out[plan] = torch.cat([bp.process(x[:, :, c * n_blocks * 512:(c + 1) * n_blocks * 512].contiguous())
+                                   for c in range(2)], dim=2)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0].view(torch.int32), out[want].view(torch.int32)), (S, n_blocks, want)
+        assert not torch.equal(out[1].view(torch.int32), out[2].view(torch.int32))
+        if want == 2:           # ... and what it picked is within the parity bar of the oracle
+            for s in (0, 1, 2):
+                eng = oracle.ConvolutionEngine()
+                for p in range(4):
+                    eng.set_ir(p, irs[p])
+                bands = synth.eq_table()
+                eq = oracle.StereoParametricEQ(len(bands), synth.FS)
+                for i, b in enumerate(bands):
+                    eq.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+                xs = base[s].cpu().numpy()
+                l, r = xs[0].copy(), xs[1].copy()
+                oracle.chain_process(eng, eq, l, r, eq_enable=True, gain=0.7)
+                assert_parity(out[0][s].cpu().numpy(), np.stack([l, r]), f"auto plan, {S} streams, stream {s}")

@@ -22,6 +22,7 @@ for S, blocks, calls in ((1, 1, 3), (3, 37, 2), (5, 300, 2), (64, 938, 1), (256,
         bp.set_ir(p, irs[p])
     bp.set_eq_enabled(False)
     bp.set_gain(0.7)
+    bp.set_conv_plan(1)     # the block-512 plan: the bits this file records
     h = hashlib.sha256()
     for c in range(calls):
         x = synth.white_noise_torch(10 * S + c, S, blocks * 512, dev)
