@@ -130,3 +130,61 @@ def test_config5_per_node_stream_count_on_one_gpu():
         l, r = xs[0].copy(), xs[1].copy()
         orc.chain_process(eng, eq, l, r, eq_enable=True, gain=0.7)
         assert_parity(y[s].cpu().numpy(), np.stack([l, r]), f"config 5 stream {s}")
+
+
+def test_config5_stream_count_with_calls_long_enough_for_the_hop_plan():
+    """2048 streams, 96 blocks per call: the library serves the convolution with its hop-1536 plan here (from 512
+    streams and 48 blocks on) -- three hop ranges per stream, two rounds of waves.  Streams 0, 1023, 2047 against the
+    oracle across two calls, every other stream against the stream it repeats."""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    from oracle import ohs_oracle as orc
+
+    S, n_blocks, taps = 2048, 96, 512
+    frames = n_blocks * 512
+    irs = synth.hrir_set(taps)
+    bands = synth.eq_table()
+    bp = ohs.BatchProcessor(S, num_bands=len(bands))
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i, b in enumerate(bands):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(True)
+    bp.set_gain(0.7)
+    dev = torch.device("cuda:0")
+    base = synth.white_noise_torch(77, 3, 2 * frames, dev)
+    x = base[torch.arange(S, device=dev) % 3].contiguous()
+    ys = [bp.process(x[:, :, c * frames:(c + 1) * frames].contiguous()) for c in range(2)]
+    y = torch.cat(ys, dim=2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    for s in range(3, S):
+        assert torch.equal(y[s], y[s % 3]), f"stream {s} differs from stream {s % 3}"
+    for s in (0, 1023, 2047):
+        eng = orc.ConvolutionEngine()
+        for p in range(4):
+            eng.set_ir(p, irs[p])
+        eq = orc.StereoParametricEQ(len(bands), synth.FS)
+        for i, b in enumerate(bands):
+            eq.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+        xs = base[s % 3].cpu().numpy()
+        l, r = xs[0].copy(), xs[1].copy()
+        orc.chain_process(eng, eq, l, r, eq_enable=True, gain=0.7)
+        assert_parity(y[s].cpu().numpy(), np.stack([l, r]), f"config 5, hop plan, stream {s}")
+    # ... and it is the hop plan that ran: the bits of plan 2, not of plan 1
+    outs = {}
+    for plan in (1, 2):
+        b2 = ohs.BatchProcessor(S, num_bands=len(bands))
+        for p in range(4):
+            b2.set_ir(p, irs[p])
+        for i, b in enumerate(bands):
+            b2.update_band_coeffs(i, synth.FS, b)
+        b2.set_eq_enabled(True)
+        b2.set_gain(0.7)
+        b2.set_conv_plan(plan)
+        outs[plan] = b2.process(x[:, :, :frames].contiguous())[:3].clone()
+        del b2
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0][:3].view(torch.int32), outs[2].view(torch.int32))
+    assert not torch.equal(outs[1].view(torch.int32), outs[2].view(torch.int32))
