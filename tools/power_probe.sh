@@ -1,6 +1,7 @@
 #!/bin/bash
 # Board power and clocks while the P = 1 convolution runs back to back (rocm-smi sampled in the background):
 #   gpurun -- 'bash tools/power_probe.sh [plan] > gpurun_out/power_probe.txt 2>&1'     plan: 1 (default) or 2 (hop 1536)
+#   OHS_PROBE_STREAMS / _FRAMES / _TAPS: another workload (config 4: 64 / 131072 / 16384)
 export OHS_PROBE_PLAN=${1:-1}
 echo "conv plan $OHS_PROBE_PLAN"
 python3 - <<'PY' &
@@ -9,9 +10,9 @@ sys.path.insert(0, os.getcwd())
 import torch
 import open_headstage_amd as ohs
 from open_headstage_amd import synth
-S, frames = 256, 480256
+S, frames = int(os.environ.get('OHS_PROBE_STREAMS', '256')), int(os.environ.get('OHS_PROBE_FRAMES', '480256'))
 bp = ohs.BatchProcessor(S, num_bands=10)
-for p, h in enumerate(synth.hrir_set(512)):
+for p, h in enumerate(synth.hrir_set(int(os.environ.get('OHS_PROBE_TAPS', '512')))):
     bp.set_ir(p, h)
 bp.set_eq_enabled(False)
 bp.set_conv_plan(int(os.environ.get("OHS_PROBE_PLAN", "1")))
