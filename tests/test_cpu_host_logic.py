@@ -261,3 +261,41 @@ def test_the_product_library_has_no_debug_entry_points_and_reads_no_environment(
     assert names and all(n == "OHS_OK" or n.startswith("OHS_ERR_") for n in names), names
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(_ffi.HERE, "libohs_hip.so")],
                                           capture_output=True, text=True).stdout
+
+
+def test_the_hop_kernels_steady_loop_does_not_spill(tmp_path):
+    """k_conv_p1_os runs three waves per SIMD (168 registers per lane).  Left alone hipcc over-commits its product phase
+    (130 scratch instructions per hop: 0.92 instead of 0.49 ms per headline-sized step); the kernel parks the results of
+    slots {0, 1} in the wave's idle exchange slab to cut those live ranges.  Held here on the ISA of the steady hop --
+    the kernel-wide scratch figure also covers the guarded first / last hops, which may spill."""
+    import re
+    import shutil
+    from open_headstage_amd import build
+    res = build.resources()
+    if res:
+        assert res["k_conv_p1_os"]["occupancy_waves_per_simd"] == 3 and res["k_conv_p1_os"]["vgprs"] <= 168, res["k_conv_p1_os"]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    csrc = os.path.join(ROOT, "open_headstage_amd", "csrc")
+    out = tmp_path / "os.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-ffp-contract=off", "-S",
+                    "--cuda-device-only", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-o", str(out),
+                    os.path.join(csrc, "conv_os_kernels.hip")], check=True, timeout=600)
+    lines = out.read_text().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*k_conv_p1_os\w*:", l))
+    end = next(i for i, l in enumerate(lines) if i > start and ".Lfunc_end" in l)
+    lines = lines[start:end]
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and 2000 < i - labels[m.group(1)]:
+            loops.append((i - labels[m.group(1)], labels[m.group(1)], i))
+    assert loops, "no hop loop found in k_conv_p1_os"
+    _, a, b = min(loops)                        # the innermost big loop: the steady hops
+    body = [x.strip().split()[0] for x in lines[a:b] if x.startswith("\t") and not x.strip().startswith((".", ";"))]
+    stores = sum(1 for op in body if op.startswith("scratch_store"))
+    loads = sum(1 for op in body if op.startswith("scratch_load"))
+    assert stores == 0 and loads <= 8, f"steady hop: {stores} scratch stores, {loads} scratch loads in {len(body)} instructions"
+    assert 2800 < len(body) < 3700, len(body)
