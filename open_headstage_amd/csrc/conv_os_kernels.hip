@@ -44,9 +44,16 @@ namespace ohs {
 //   OHS_OS_PREFETCH  where the next hop's 24 loads are issued: 0 = behind the spectral product, 1 = between the two inverse
 //                    transforms, 2 = behind both (in front of the stores).  0 keeps 48 more registers alive through both
 //                    inverse transforms; 2 is the one that fits 168 registers without a spill in the steady hop.
+//                    3 = the first OHS_OS_SPLIT register pairs between the inverse transforms, the rest behind both
+//                    (4 scratch instructions per hop): 3 % faster than 2 at 256 streams (one round of waves, the
+//                    loads' latency shows), equal or 1 % slower at 2 048 -- where the library picks this plan; 1 alike.
 #if !defined(OHS_OS_PREFETCH) || !defined(OHS_EXPERIMENTS)
 #undef OHS_OS_PREFETCH
 #define OHS_OS_PREFETCH 2
+#endif
+#if !defined(OHS_OS_SPLIT) || !defined(OHS_EXPERIMENTS)
+#undef OHS_OS_SPLIT
+#define OHS_OS_SPLIT 6
 #endif
 #if !defined(OHS_OS_PARK) || !defined(OHS_EXPERIMENTS)
 #undef OHS_OS_PARK
@@ -193,12 +200,12 @@ struct OsWave {             // wave-uniform context of the hop loop
 };
 
 // new frames of hop h -> nl / nr; GUARD: frames beyond the call are zeros and are not read
-template <bool GUARD>
+template <bool GUARD, int A0 = 0, int A1 = 12>
 __device__ __forceinline__ void os_load_new(const OsWave &w, int h, int lane, float2 (&nl)[12], float2 (&nr)[12])
 {
     const unsigned base = (unsigned)h * kOsHop + 2u * (unsigned)lane;
 #pragma unroll
-    for (int a = 0; a < 12; ++a) {
+    for (int a = A0; a < A1; ++a) {
         const bool ok = !GUARD || (unsigned long long)h * kOsHop + 128ull * a < w.n_frames;       // wave-uniform
         nl[a] = ok ? os_ld_nt(w.in_l + base + 128 * a) : make_float2(0.f, 0.f);
         nr[a] = ok ? os_ld_nt(w.in_r + base + 128 * a) : make_float2(0.f, 0.f);
@@ -321,6 +328,10 @@ __device__ __forceinline__ void os_hop(const ConvOsArgs &A, const OsWave &w, int
     if (!GENERIC) os_load_new<false>(w, h + 1, lane, nl, nr);
     else if (h + 1 < w.h1) os_load_new<true>(w, h + 1, lane, nl, nr);
     __builtin_amdgcn_sched_barrier(0);
+#elif OHS_OS_PREFETCH == 3      // the first OHS_OS_SPLIT register pairs here, the rest behind the second inverse transform
+    if (!GENERIC) os_load_new<false, 0, OHS_OS_SPLIT>(w, h + 1, lane, nl, nr);
+    else if (h + 1 < w.h1) os_load_new<true, 0, OHS_OS_SPLIT>(w, h + 1, lane, nl, nr);
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     wave_fft_inv_paired(O, w.lds, w.tab, lane, plan);       // y[2m + 1]
     __builtin_amdgcn_sched_barrier(0);
@@ -329,6 +340,10 @@ __device__ __forceinline__ void os_hop(const ConvOsArgs &A, const OsWave &w, int
 #if OHS_OS_PREFETCH == 2
     if (!GENERIC) os_load_new<false>(w, h + 1, lane, nl, nr);
     else if (h + 1 < w.h1) os_load_new<true>(w, h + 1, lane, nl, nr);
+    __builtin_amdgcn_sched_barrier(0);
+#elif OHS_OS_PREFETCH == 3
+    if (!GENERIC) os_load_new<false, OHS_OS_SPLIT, 12>(w, h + 1, lane, nl, nr);
+    else if (h + 1 < w.h1) os_load_new<true, OHS_OS_SPLIT, 12>(w, h + 1, lane, nl, nr);
     __builtin_amdgcn_sched_barrier(0);
 #endif
 
