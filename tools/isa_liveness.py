@@ -38,7 +38,9 @@ def main():
             loops.append((i - labels[m.group(1)], labels[m.group(1)], i))
     if not loops:
         sys.exit(f"no loop of more than {min_len} lines in {kname}")
-    _, a, b = min(loops)
+    # (prefer loops that do vector work: a kernel's launch-plan arithmetic can be a long scalar loop of its own)
+    busy = [t for t in loops if sum(1 for x in lines[t[1]:t[2]] if x.strip().startswith(("ds_", "v_pk_", "v_fma", "v_add_f32"))) > 200]
+    _, a, b = min(busy or loops)
     body = [x.strip().split(";")[0].strip() for x in lines[a:b + 1] if x.startswith("\t") and not x.strip().startswith((".", ";"))]
     mix = collections.Counter()
     for t in body:
