@@ -809,16 +809,16 @@ def main() -> int:
             dt = e0.elapsed_time(e1) * 1e-3 / 16
             _, cb_alone = bp.kernel_bytes(n_blocks)
             out["roofline"]["conv_alone"] = {
-                "what": "the same batch with the EQ off, 16 steps back to back after 40 warm-up steps (ONE kernel per step: k_conv_p1, "
-                        "the plan the library picks at this stream count; HIP events)",
+                "what": "the same batch with the EQ off, out of place, 16 steps back to back after 40 warm-up steps (ONE kernel per "
+                        "step, the plan the library picks for such a call: hop 1536 / FFT 2048, k_conv_p1_os; HIP events)",
+                "kernel": "k_conv_p1_os" if args.streams >= 256 and n_blocks >= 48 else "k_conv_p1",
                 "ms_per_step": round(dt * 1e3, 4), "Msamples_s": round(args.streams * frames / dt / 1e6, 1),
                 "design_bytes_per_step": int(cb_alone),
                 "achieved": round(cb_alone / dt / 1e9, 1), "unit": "GB/s",
                 "frac": round(cb_alone / dt / 1e9 / HBM_PEAK_GBS, 5)}
-            # the hop-1536 plan (k_conv_p1_os; what the library picks by itself from 512 streams on) on the same batch:
-            # the same 16 B per frame of audio traffic
+            # the block-512 plan forced (k_conv_p1: what serves BASELINE configs[2] underneath the EQ) on the same batch
             try:
-                bp.set_conv_plan(2)
+                bp.set_conv_plan(1)
                 for _ in range(10):
                     bp.process(x, out=y)
                 torch.cuda.synchronize()
@@ -827,14 +827,13 @@ def main() -> int:
                     bp.process(x, out=y)
                 e1.record()
                 torch.cuda.synchronize()
-                dt2 = e0.elapsed_time(e1) * 1e-3 / 16
-                io_bytes = 16.0 * args.streams * frames
-                out["roofline"]["conv_alone"]["hop_1536_plan"] = {
-                    "kernel": "k_conv_p1_os", "ms_per_step": round(dt2 * 1e3, 4),
-                    "achieved": round(io_bytes / dt2 / 1e9, 1), "unit": "GB/s", "frac": round(io_bytes / dt2 / 1e9 / HBM_PEAK_GBS, 5),
-                    "bytes": "16 B per frame (audio in + out)"}
+                dt1 = e0.elapsed_time(e1) * 1e-3 / 16
+                _, cb1 = bp.kernel_bytes(n_blocks)
+                out["roofline"]["conv_alone"]["block_512_plan"] = {
+                    "kernel": "k_conv_p1", "ms_per_step": round(dt1 * 1e3, 4), "design_bytes_per_step": int(cb1),
+                    "achieved": round(cb1 / dt1 / 1e9, 1), "unit": "GB/s", "frac": round(cb1 / dt1 / 1e9 / HBM_PEAK_GBS, 5)}
             except Exception as e:      # noqa: BLE001
-                out["roofline"]["conv_alone"]["hop_1536_plan"] = {"error": str(e)[:200]}
+                out["roofline"]["conv_alone"]["block_512_plan"] = {"error": str(e)[:200]}
             bp.set_conv_plan(0)
             bp.set_eq_enabled(True)
             bp.reset()

@@ -321,8 +321,9 @@ int  ohs_batch_set_gain(ohs_batch *b, float gain);
  *   2  hop 1536 / FFT 2048, overlap-save -- a quarter less transform and product work per frame, 11-12 % less time where
  *      the convolution is what the step waits for; equal to plan 1 up to f32 rounding (2-3e-7 relative RMS against the
  *      oracle, like every FFT path), not bit for bit, and the rounding depends on where the calls cut the signal
- *   0  the library's choice (default): plan 2 from 512 streams and 48 blocks per call on, plan 1 below (at BASELINE
- *      configs[2] the convolution hides under the EQ either way, and the block-512 bits stay as recorded).
+ *   0  the library's choice (default): plan 2 for calls of 48 blocks or more on 512 streams or more -- on 256 or more
+ *      when the call is out of place and the EQ is off --, plan 1 otherwise (at BASELINE configs[2] the convolution hides
+ *      under the EQ either way, and the block-512 bits stay as recorded).
  * Plan 2 needs even strides and 8-byte aligned buffers; calls that do not meet that, longer impulse responses and the
  * single-stream engine are served as before. */
 int  ohs_batch_set_conv_plan(ohs_batch *b, int plan);

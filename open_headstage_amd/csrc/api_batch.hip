@@ -655,11 +655,13 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
     const uint64_t eq_sb = 4096u + 4096u + 520u;
     *eq_bytes = b->eq_enable ? nbk * S * eq_sb : 0;
     const bool os_plan = P == 1 && b->conv.lazy_ok &&
-                         (b->conv.conv_plan == 2 || (b->conv.conv_plan == 0 && conv_plan_auto_is_os((size_t)S, (long long)nbk)));
+                         (b->conv.conv_plan == 2 ||
+                          (b->conv.conv_plan == 0 && conv_plan_auto_is_os((size_t)S, (long long)nbk, b->eq_enable != 0)));   // (EQ on: in place)
     if (os_plan) {
         // hop-1536 plan: audio in + out; per stream the 512 frames in front of every hop range but the first once more
-        // (<= 11 x 4 KiB), the merged overlap in + out and the last input block (3 x 4 KiB)
-        *conv_bytes = nbk * S * 8192u + S * (uint64_t)((conv_os_waves_per_cu() - 1) * 4096 + 3 * 4096);
+        // (4 KiB each), the merged overlap in + out and the last input block (3 x 4 KiB)
+        const uint64_t K = (uint64_t)conv_os_chunks(b->ctx, (size_t)S, (long long)nbk, b->eq_enable != 0);
+        *conv_bytes = nbk * S * 8192u + S * ((K - 1) * 4096u + 3u * 4096u);
     } else if (P == 1) {
         const uint64_t K = (uint64_t)conv_p1_chunks(b->ctx, (size_t)S, (long long)nbk, 0);
         const bool own_tails = conv_p1_waves_per_cu() == 16 && (K == 2 || K == 4 || K == 8 || K == 16);

@@ -238,14 +238,35 @@ long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, lon
 
 // ohs_batch_set_conv_plan(0): which P = 1 plan the library picks by itself
 // The hop-1536 plan does a quarter less work per frame at three waves per SIMD and wins wherever the convolution's time
-// is exposed: 0.884-0.888 x the block-512 plan's time at 1 024 and 2 048 streams without EQ, 0.976 x with it
-// (profiles/r04_conv_plan_ab_run3.txt).  At 256 streams with the EQ on -- BASELINE configs[2] -- the convolution hides
-// under the EQ's serial chain either way (1.000-1.004 x), and the block-512 plan keeps its two properties there: output
-// bits that do not depend on where the calls cut the signal, and the recorded golden hash.  Short calls stay with it as
-// well (a wave's first and last hops run the guarded form of the hop).
-bool conv_plan_auto_is_os(size_t S, long long n_blocks)
+// is exposed and the launch can fill the chip (profiles/r04_conv_plan_ab_run3.txt, _run4.txt):
+//   out of place (the call's hop ranges are independent: any count per stream): 0.944 x the block-512 plan's time at 256
+//     streams, 0.87-0.89 x from 384 on; a tie at 128 and below
+//   in place (a stream's ranges share a workgroup: 1, 2, 3, 4, 6 or 12 of them): 0.93 x at 512 streams, 0.87-0.92 x beyond;
+//     a tie at 384.  The batch's EQ || convolution path is in place: at 256 streams with the EQ on -- BASELINE configs[2] --
+//     the convolution hides under the EQ's serial chain either way (1.000-1.004 x), and the block-512 plan keeps its two
+//     properties there: output bits that do not depend on where the calls cut the signal, and the recorded golden hash.
+// Short calls stay with the block-512 plan as well (a wave's first and last hops run the guarded form of the hop).
+bool conv_plan_auto_is_os(size_t S, long long n_blocks, bool in_place)
 {
-    return S >= 512 && n_blocks >= 48;
+    return n_blocks >= 48 && S >= (in_place ? 512u : 256u);
+}
+
+// hop ranges per stream of the hop-1536 plan: rounds of resident waves x hops per wave (+ 1: the tables and the first
+// window), the smallest count of minimal cost.  In place all of a stream's ranges must share a workgroup
+// (launch_conv_p1_os): a divisor of its wave count; out of place any count goes, and few streams still fill the chip
+// (64 streams x 48 ranges).
+int conv_os_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, bool in_place)
+{
+    const long long R = (long long)ctx->num_cus * conv_os_waves_per_cu();
+    const long long H = (n_blocks * BS + 1535) / 1536;
+    int K = 1;
+    long long best = -1;
+    for (int k = 1; k <= (in_place ? conv_os_waves_per_cu() : 96) && k <= H; ++k) {
+        if (in_place && conv_os_waves_per_cu() % k) continue;
+        const long long cost = (((long long)S * k + R - 1) / R) * ((H + k - 1) / k + 1);
+        if (best < 0 || cost < best) { best = cost; K = k; }
+    }
+    return K;
 }
 
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
@@ -278,24 +299,14 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                            ((in_ss | in_cs | out_ss | out_cs) & 1) == 0 &&
                            ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7) == 0 &&
                            (unsigned long long)n_blocks * BS + 1536ull < (1ull << 31);
-        const bool use_os = os_ok && (c.conv_plan == 2 || (c.conv_plan == 0 && conv_plan_auto_is_os(c.S, n_blocks)));
+        const bool use_os = os_ok && (c.conv_plan == 2 || (c.conv_plan == 0 && conv_plan_auto_is_os(c.S, n_blocks, in == out)));
         if (use_os) {
             if (!c.cd_os_valid) {
                 hipError_t e = launch_os_tables(c.d_irt, ctx->d_tw, ctx->d_tw2048, c.d_cd_os, st);
                 if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("os tables: ") + hipGetErrorString(e));
                 c.cd_os_valid = true;
             }
-            // hop ranges per stream: a divisor of the workgroup's wave count (all of a stream's in one workgroup); rounds of resident waves
-            // x hops per wave (+ 1: the tables and the first window), the smallest count of minimal cost
-            const long long R = (long long)ctx->num_cus * conv_os_waves_per_cu();
-            const long long H = ((long long)n_blocks * BS + 1535) / 1536;
-            int K = 1;
-            long long best = -1;
-            for (int k = 1; k <= conv_os_waves_per_cu() && k <= H; ++k) {
-                if (conv_os_waves_per_cu() % k) continue;       // (all of a stream's chunks in one workgroup)
-                const long long cost = (((long long)c.S * k + R - 1) / R) * ((H + k - 1) / k + 1);
-                if (best < 0 || cost < best) { best = cost; K = k; }
-            }
+            const int K = conv_os_chunks(ctx, c.S, n_blocks, in == out);
             ConvOsArgs o;
             o.in = in; o.out = out;
             o.in_stream_stride = in_ss; o.in_ch_stride = in_cs; o.out_stream_stride = out_ss; o.out_ch_stride = out_cs;

@@ -157,7 +157,8 @@ int conv_materialise_state(ConvState &c, DeviceCtx *ctx, hipStream_t st);
 int conv_grow_ring(ConvState &c, int need, hipStream_t st);
 int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st,
                 bool ir_on_device = false);
-bool conv_plan_auto_is_os(size_t S, long long n_blocks);
+bool conv_plan_auto_is_os(size_t S, long long n_blocks, bool in_place);
+int conv_os_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, bool in_place);
 // time chunks per stream of the one-partition kernel's launch plan (also what ohs_batch_kernel_bytes prices)
 long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override, int xcd_n = 8);
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,

@@ -426,7 +426,8 @@ __global__ __launch_bounds__(64 * kOsWaves) void k_conv_p1_os(const ConvOsArgs A
     const PairedPlan plan = paired_plan(lane);
 
     // frames [1536 h0 - 512, 1536 h0) and the new frames of hop h0: read in front of the barrier -- in place the wave of
-    // chunk ck - 1 overwrites the former with its last outputs (all chunks of a stream live in this workgroup)
+    // chunk ck - 1 overwrites the former with its last outputs (in place all chunks of a stream live in this workgroup:
+    // launch_conv_p1_os)
     float2 pl[4], pr[4], nl[12], nr[12];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { pl[a] = make_float2(0.f, 0.f); pr[a] = make_float2(0.f, 0.f); }
@@ -460,7 +461,11 @@ int conv_os_waves_per_cu() { return kOsWaves; }
 hipError_t launch_conv_p1_os(const ConvOsArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (a.n_blocks <= 0 || a.n_streams <= 0) return hipErrorInvalidValue;
-    if (a.chunks < 1 || kOsWaves % a.chunks != 0) return hipErrorInvalidValue;      // all of a stream's chunks in one workgroup
+    // In place the wave of hop range ck - 1 overwrites the 512 frames in front of range ck with its last outputs: the
+    // ranges of a stream must then share a workgroup (its barrier orders those reads first), so their count must divide the
+    // workgroup's waves.  Out of place the ranges are independent and any count goes.
+    if (a.chunks < 1) return hipErrorInvalidValue;
+    if (a.in == a.out && kOsWaves % a.chunks != 0) return hipErrorInvalidValue;
     if ((unsigned long long)a.n_blocks * kBlock + kOsHop >= (1ull << 31)) return hipErrorInvalidValue;     // 32-bit frame offsets
     if (!a.merged_out || !a.last_in) return hipErrorInvalidValue;       // batch objects only: the lazy state
     // 8-byte accesses: even strides, 8-byte aligned bases

@@ -181,7 +181,7 @@ struct ConvOsArgs {
     long long out_stream_stride, out_ch_stride;
     int n_blocks;               // 512-frame blocks of the call
     int n_streams;
-    int chunks;                 // contiguous hop ranges per stream: 1, 2, 4 or 8 (all of a stream's in one workgroup)
+    int chunks;                 // contiguous hop ranges per stream; in place (in == out) a divisor of the workgroup's waves
     const float4 *CD;           // [2 lo/hi][16][64] (C, D), paired layout, 1/2048 folded in (launch_os_tables)
     const float2 *tw2048;       // [16][64] w2048^bin, paired layout
     const float2 *tails;        // state in, per-path form (used when merged_in == nullptr)

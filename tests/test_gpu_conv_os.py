@@ -51,7 +51,8 @@ def test_overlap_save_plan_matches_the_oracle_and_f64(oracle, n_blocks):
     assert r <= 1e-6
 
 
-# (hop ranges per stream the launcher picks with twelve waves per CU on 256 CUs: api_conv.hip)
+# (hop ranges per stream the launcher picks IN PLACE with twelve waves per CU on 256 CUs -- divisors of 12: api_conv.hip;
+# OUT OF PLACE any count goes: 5 for 600 x 60, 10 for 300 x 100, 34 -- one hop each -- for 37 x 100)
 @pytest.mark.parametrize("S,n_blocks,want_chunks", [(2048, 12, 1), (1536, 40, 2), (1000, 24, 3), (600, 60, 4), (300, 100, 6),
                                                   (37, 100, 12)])
 def test_every_chunk_count_of_the_launcher(S, n_blocks, want_chunks):
@@ -62,17 +63,21 @@ def test_every_chunk_count_of_the_launcher(S, n_blocks, want_chunks):
     dev = torch.device("cuda:0")
     a, _ = _make(ohs, synth, S, 1)
     b, _ = _make(ohs, synth, S, 2)
+    c, _ = _make(ohs, synth, S, 2)
     for call in range(2):
         x = synth.white_noise_torch(9 * call, S, n_blocks * 512, dev)
         ya = torch.empty_like(x)
         a.process(x, out=ya)
         yb = x.clone()
-        b.process(yb, out=yb)
+        b.process(yb, out=yb)               # in place: a divisor of twelve hop ranges per stream
+        yc = torch.empty_like(x)
+        c.process(x, out=yc)                # out of place: the count that fills the chip
         torch.cuda.synchronize()
-        d = (ya - yb).double()
-        rel = float(torch.sqrt((d * d).mean()) / torch.sqrt((ya.double() ** 2).mean()))
-        per_stream = torch.sqrt((d * d).mean(dim=(1, 2))) / torch.sqrt((ya.double() ** 2).mean(dim=(1, 2)))
-        assert rel <= 6e-7 and float(per_stream.max()) <= 1e-6, (call, rel, float(per_stream.max()))
+        for y2, what in ((yb, "in place"), (yc, "out of place")):
+            d = (ya - y2).double()
+            rel = float(torch.sqrt((d * d).mean()) / torch.sqrt((ya.double() ** 2).mean()))
+            per_stream = torch.sqrt((d * d).mean(dim=(1, 2))) / torch.sqrt((ya.double() ** 2).mean(dim=(1, 2)))
+            assert rel <= 6e-7 and float(per_stream.max()) <= 1e-6, (what, call, rel, float(per_stream.max()))
 
 
 def test_the_two_plans_hand_the_same_state_over_and_a_midstream_set_ir(oracle):
@@ -124,24 +129,35 @@ def test_plan_argument_and_fallbacks():
     assert torch.equal(bp.process(x).view(torch.int32), ref.process(x).view(torch.int32))
 
 
-def test_the_library_picks_the_hop_plan_from_512_streams_on(oracle):
-    """ohs_batch_set_conv_plan(0), the default: the hop-1536 plan from 512 streams and 48 blocks per call on (where the
-    convolution's time is exposed: profiles/r04_conv_plan_ab_run3.txt), the block-512 plan below -- BASELINE configs[2]
-    keeps the bits the golden hash records.  Told by the bits: each choice must equal the explicit plan it stands for."""
+def test_the_library_picks_the_hop_plan_where_it_pays(oracle):
+    """ohs_batch_set_conv_plan(0), the default: the hop-1536 plan for calls of 48 blocks or more on 512 streams or more --
+    256 or more when the convolution runs out of place, i.e. with the EQ off and distinct buffers -- and the block-512
+    plan otherwise (profiles/r04_conv_plan_ab_run3.txt, _run4.txt); BASELINE configs[2] (256 streams, EQ on) keeps the
+    bits the golden hash records.  Told by the bits: each choice must equal the explicit plan it stands for."""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
     dev = torch.device("cuda:0")
-    for S, n_blocks, want in ((512, 60, 2), (512, 40, 1), (256, 60, 1), (700, 48, 2)):
+    #     streams, blocks per call, EQ, in place, the plan the library must pick
+    for S, n_blocks, eq, in_place, want in ((512, 60, True, False, 2), (512, 40, True, False, 1), (256, 60, True, False, 1),
+                                            (700, 48, True, False, 2), (256, 60, False, False, 2), (256, 60, False, True, 1),
+                                            (200, 60, False, False, 1), (256, 40, False, False, 1), (512, 60, False, True, 2)):
         base = synth.white_noise_torch(90 + S, 3, 2 * n_blocks * 512, dev)
         x = base[torch.arange(S, device=dev) % 3].contiguous()
         out = {}
         for plan in (0, 1, 2):
-            bp, irs = _make(ohs, synth, S, plan, eq=True, gain=0.7)
-            out[plan] = torch.cat([bp.process(x[:, :, c * n_blocks * 512:(c + 1) * n_blocks * 512].contiguous())
-                                   for c in range(2)], dim=2)
+            bp, irs = _make(ohs, synth, S, plan, eq=eq, gain=0.7)
+            ys = []
+            for c in range(2):
+                xc = x[:, :, c * n_blocks * 512:(c + 1) * n_blocks * 512].contiguous()
+                if in_place:
+                    bp.process(xc, out=xc)
+                    ys.append(xc)
+                else:
+                    ys.append(bp.process(xc))
+            out[plan] = torch.cat(ys, dim=2)
         torch.cuda.synchronize()
-        assert torch.equal(out[0].view(torch.int32), out[want].view(torch.int32)), (S, n_blocks, want)
+        assert torch.equal(out[0].view(torch.int32), out[want].view(torch.int32)), (S, n_blocks, eq, in_place, want)
         assert not torch.equal(out[1].view(torch.int32), out[2].view(torch.int32))
         if want == 2:           # ... and what it picked is within the parity bar of the oracle
             for s in (0, 1, 2):
@@ -149,10 +165,10 @@ def test_the_library_picks_the_hop_plan_from_512_streams_on(oracle):
                 for p in range(4):
                     eng.set_ir(p, irs[p])
                 bands = synth.eq_table()
-                eq = oracle.StereoParametricEQ(len(bands), synth.FS)
+                eqo = oracle.StereoParametricEQ(len(bands), synth.FS)
                 for i, b in enumerate(bands):
-                    eq.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
+                    eqo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), True)
                 xs = base[s].cpu().numpy()
                 l, r = xs[0].copy(), xs[1].copy()
-                oracle.chain_process(eng, eq, l, r, eq_enable=True, gain=0.7)
+                oracle.chain_process(eng, eqo, l, r, eq_enable=eq, gain=0.7)
                 assert_parity(out[0][s].cpu().numpy(), np.stack([l, r]), f"auto plan, {S} streams, stream {s}")
