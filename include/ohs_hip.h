@@ -421,7 +421,9 @@ int  ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h
  * (convolution.rs:36-42,76-79; parametric_eq.rs:125-129).  Returns when every device has QUEUED its work: the outputs
  * are complete after ohs_node_batch_sync.  Calls queue up in order; the set_* / reset calls of the node batch wait for
  * what is queued.  Results are bit-identical to ohs_batch_process on one device holding the same streams when every
- * path has one partition (taps <= 512, plan 1: every block is computed on its own).  With longer impulse responses the
+ * path has one partition (taps <= 512) and both sides run the same plan of ohs_batch_set_conv_plan -- the library's own
+ * choice depends on the number of streams per device, so pin the plan (ohs_node_batch_set_conv_plan) where bits must
+ * match across different shardings; either plan computes a block / a hop on its own.  With longer impulse responses the
  * time-parallel kernels cut a call into segments of max(8, min(16384 / streams on the device, 1024)) blocks and round
  * differently across a segment or call boundary (stored overlap, added in time) than inside one (overlap folded into
  * the spectrum): a shard and the unsharded batch agree bit for bit only while they cut alike, otherwise within the
