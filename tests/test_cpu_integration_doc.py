@@ -111,3 +111,20 @@ def test_the_eq_shim_takes_its_coefficients_from_the_biquad_crate():
     code = re.sub(r"//[^\n]*", "", m.group(0))
     assert "ohs_eq_set_band_coeffs" in code and "from_params" in code
     assert "ohs_eq_update_band" not in code
+
+
+def test_the_document_agrees_with_itself_about_the_biquad_crate():
+    """section 1 once said `Cargo.toml`: drop `rustfft`, `biquad` while section 4's shim calls the
+    crate.  Every sentence of the document that speaks of dropping / removing a dependency must not name `biquad`, the
+    Cargo.toml row of section 1 must say that it stays, and section 4 must still say so too."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    row = [l for l in doc.splitlines() if l.startswith("| `Cargo.toml`")]
+    assert len(row) == 1, row
+    row = row[0]
+    assert "rustfft" in row and re.search(r"`biquad[^`]*`\s+stays", row), row
+    for sentence in re.split(r"(?<=[.;:|])\s", doc):
+        if re.search(r"\b(drop|drops|dropped|remove|removes|removed|delete)\b", sentence, flags=re.I) and "biquad" in sentence:
+            m = re.search(r"\b(drop|drops|dropped|remove|removes|removed|delete)\b[^.;:|]*", sentence, flags=re.I)
+            assert "biquad" not in m.group(0), f"INTEGRATION.md tells the maintainer to drop the biquad crate: {sentence!r}"
+    assert re.search(r"`Cargo.toml`\s+keeps `biquad", doc), "section 4 no longer says that Cargo.toml keeps the crate"
+    assert "biquad::Coefficients" in doc and "from_params" in doc
