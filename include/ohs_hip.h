@@ -409,8 +409,13 @@ int  ohs_node_batch_set_conv_plan(ohs_node_batch *nb, int plan);       /* see oh
 int  ohs_node_batch_reset(ohs_node_batch *nb);
 /* ohs_batch_process_host for the whole job: h_in / h_out hold ALL streams_total streams (same planar layout and
  * strides); every device runs the three-stage host pipeline on its shard from a thread of its own.  Blocking.
- * Pinned host memory must be visible to every device (hipHostMallocPortable).  Results are bit-identical to
- * ohs_batch_process_host on one device with the same chunk_blocks: streams do not interact. */
+ * Pinned host memory must be visible to every device (hipHostMallocPortable).  Streams do not interact; the results are
+ * bit-identical to ohs_batch_process_host on one device with the same chunk_blocks WHEN BOTH SIDES RUN THE SAME PLAN
+ * (ohs_batch_set_conv_plan / ohs_node_batch_set_conv_plan): the library's own choice (plan 0) follows the number of
+ * streams PER DEVICE and the chunk length -- an unsharded batch of 512 streams or more with chunks of 48 blocks or more
+ * takes the hop-1536 plan where its 8-way shards of 256 streams or fewer keep the block-512 plan -- and the two plans
+ * agree to f32 rounding (<= 1e-6 relative RMS against the reference either way), not bit for bit.  Pin the plan where bits
+ * must match across shardings (see ohs_node_batch_process for impulse responses longer than one partition). */
 int  ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h_out, size_t n_blocks,
                                  size_t stream_stride, size_t channel_stride, size_t chunk_blocks);
 /* THE DATA PATH OF THE NODE: ohs_batch_process on every device at once, audio resident in device memory.
@@ -434,13 +439,15 @@ int  ohs_node_batch_process_host(ohs_node_batch *nb, const float *h_in, float *h
  * different tables) until a complete ohs_node_batch_set_tables -- four paths and the EQ -- has succeeded. */
 int  ohs_node_batch_process(ohs_node_batch *nb, const float *const d_in[], float *const d_out[], size_t n_blocks,
                             size_t stream_stride, size_t channel_stride);
-/* waits (host side) for everything ohs_node_batch_process has queued, on every device */
+/* waits (host side) for everything ohs_node_batch_process has queued, on every device.  On a node batch that has failed
+ * (above) it still waits for every device, then returns OHS_ERR_HIP: what the buffers hold is not a result. */
 int  ohs_node_batch_sync(ohs_node_batch *nb);
 /* the stream (hipStream_t) ohs_node_batch_process queues slot's work on: a caller that produces its audio on the device
  * orders its own kernels against it with events */
 int  ohs_node_batch_stream(ohs_node_batch *nb, int slot, void **hip_stream);
 /* device time of what is queued between the two calls, per device slot (HIP events on the slots' streams; _end waits):
- * ms_per_slot has n_devices entries.  The node's rate is the job's frames / the largest entry. */
+ * ms_per_slot has n_devices entries.  The node's rate is the job's frames / the largest entry.  Both refuse a failed node
+ * batch (OHS_ERR_HIP): a time over a half-advanced step is not a step time. */
 int  ohs_node_batch_timer_begin(ohs_node_batch *nb);
 int  ohs_node_batch_timer_end(ohs_node_batch *nb, float *ms_per_slot);
 /* what RCCL reports for the communicators in use: ncclCommCount of slot 0's, and 1 if librccl.so is loaded */

@@ -206,7 +206,8 @@ static int batch_process_impl(ohs_batch *b, const float *d_in, float *d_out, siz
     //  * the caller's stream must not run ahead of what this call put on the second stream
     hipStream_t st = (hipStream_t)hip_stream;
     hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+    // (a timing-enabled event: ev_inflight feeds ev_pool, whose events the profiling spans time with)
+    if (hipEventCreate(&ev) == hipSuccess) {
         if (hipEventRecord(ev, b->st2) != hipSuccess || hipStreamWaitEvent(st, ev, 0) != hipSuccess)
             hipStreamSynchronize(b->st2);
         b->ev_inflight.push_back(ev);
@@ -564,8 +565,21 @@ int ohs_batch_process_host(ohs_batch *b, const float *h_in, float *h_out, size_t
         }
         for (hipEvent_t e : tev) hipEventDestroy(e);
     }
+    // Fail closed (ohs_batch_reset's contract): a copy, an event or a wait that failed with chunks already processed leaves
+    // the per-stream state advanced for some chunks only -- exactly like a failure inside ohs_batch_process, which has
+    // marked the handle itself.  (Argument errors were found before the loop: nothing was queued.)
+    if (rc && rc != OHS_ERR_INVALID_ARG && !b->failed) {
+        const std::string why = g_err;
+        b->failed = true;
+        b->fail_msg = why;
+        return fail(rc, why);
+    }
     if (rc) return rc;
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(OHS_ERR_HIP, "host pipeline: stream sync failed");
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        b->failed = true;
+        b->fail_msg = "host pipeline: stream sync failed";
+        return fail(OHS_ERR_HIP, b->fail_msg);
+    }
     return OHS_OK;
 }
 
@@ -594,16 +608,30 @@ int ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_
     HIP_TRY(hipSetDevice(b->device));
     double t[2] = {0.0, 0.0};
     uint64_t cntk[2] = {0, 0};
+    hipError_t bad = hipSuccess;
     for (auto &sp : b->spans) {
         cntk[sp.kind]++;
         float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(sp.b));
-        HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+        hipError_t e = hipEventSynchronize(sp.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, sp.a, sp.b);
+        if (e != hipSuccess) {
+            // an event that cannot be timed: it does not go back to the pool, and the spans are dropped all the same --
+            // one bad span must not make every later read fail
+            if (bad == hipSuccess) bad = e;
+            hipEventDestroy(sp.a);
+            hipEventDestroy(sp.b);
+            continue;
+        }
         t[sp.kind] += ms;
         b->ev_pool.push_back(sp.a);
         b->ev_pool.push_back(sp.b);
     }
     b->spans.clear();
+    if (bad != hipSuccess) {
+        b->prof_calls = 0;
+        return fail(OHS_ERR_HIP, std::string("profile_read: a span's events could not be timed (") + hipGetErrorString(bad) +
+                                     "); the spans recorded so far were dropped");
+    }
     *eq_ms = t[0]; *conv_ms = t[1]; *n_calls = b->prof_calls;
     *eq_launches = cntk[0]; *conv_launches = cntk[1];
     b->prof_calls = 0;

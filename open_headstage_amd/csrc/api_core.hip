@@ -142,9 +142,8 @@ int ohs_device_count(int *count)
 // the two deployment options of the resident real-time kernels (include/ohs_hip.h)
 int ohs_rt_configure(int max_resident_per_device, uint64_t idle_polls)
 {
-    Tuning &t = tuning_rt();
-    t.rt_max_resident = max_resident_per_device;        // < 0: the default, a quarter of the device's CUs
-    if (idle_polls) t.rt_idle_polls = idle_polls;
+    rt_max_resident_store(max_resident_per_device);     // < 0: the default, a quarter of the device's CUs
+    if (idle_polls) rt_idle_polls_store(idle_polls);
     return OHS_OK;
 }
 

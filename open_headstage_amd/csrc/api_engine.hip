@@ -188,7 +188,7 @@ static std::atomic<int> g_rt_resident[kMaxDevices];
 static bool rt_slot_acquire(ohs_engine *e)
 {
     if (e->rt_slot) return true;
-    const int conf = tuning().rt_max_resident;
+    const int conf = rt_max_resident_load();
     const int cap = conf >= 0 ? conf : std::max(1, e->ctx->num_cus / 4);
     std::atomic<int> &c = g_rt_resident[e->device % kMaxDevices];
     if (c.fetch_add(1, std::memory_order_acq_rel) >= cap) { c.fetch_sub(1, std::memory_order_acq_rel); return false; }
@@ -291,7 +291,7 @@ int rt_start(ohs_engine *e)
     mb->call_word[0] = e->rt_seq; mb->call_word[1] = 0; mb->call_word[2] = 0; mb->call_word[3] = 0;
     mb->done = e->rt_seq; mb->alive = 1;
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    const unsigned long long idle_limit = tuning().rt_idle_polls;   // two reads in flight: one poll per ~0.6 us
+    const unsigned long long idle_limit = rt_idle_polls_load();   // two reads in flight: one poll per ~0.6 us
     const unsigned sleep_arg = tuning().rt_poll_sleep;              // no pause between poll bursts: 0.3 us less per call
     {
         // launch and registration are one step under the registry's mutex: a DeviceWideSection either finds this

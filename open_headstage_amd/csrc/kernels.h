@@ -256,6 +256,50 @@ int conv_tp_build_pairs(int *out);   // host: fills <= 514 leaders, returns the 
 hipError_t launch_build_cd_multi(const float2 *h0, const float2 *h1, const float2 *h2, const float2 *h3,
                                  int p0, int p1, int p2, int p3, int Ppad, float2 *cd, hipStream_t st);
 
+// ---- long impulse responses, batch objects: block 2048 / FFT 4096, overlap-save (conv_lb_kernels.hip) ------------
+// The reference cuts every impulse response into 512-tap partitions (convolution.rs:120-132) and pays P x 1024 complex
+// products per 512 frames (:261-273).  An offline call can afford a longer block: with 2048-tap partitions the product
+// work and the history reads per frame drop to a quarter (16 384 taps: 8 partitions instead of 32) for 1.2 x the
+// transform work.  The 4096-point transform is four of the wave's 1024-point transforms (one per wave of a workgroup)
+// and a lane-local radix-4 step; spectra are stored as PAIRS (Z[q], Z[4096 - q]) so that the packed two-channel product
+// needs no mirror fetch; the product and the inverse transform are ONE kernel (a workgroup owns four consecutive
+// output blocks of a stream: the product's results never travel through HBM).
+//   F  k_conv_lb_forward      : window u = frames [(u - 1) 2048, (u + 1) 2048) -> ring slot (ring_base + u) % ring_cap
+//   MI k_conv_lb_mac_inverse  : W_t = sum_i Z_{t-i} C_i + conj(Z_{t-i}[N - k]) D_i ; out block t = IFFT(W_t)[2048, 4096)
+// Results equal the block-512 kernels' up to f32 rounding, not bit for bit.
+struct ConvLbArgs {
+    const float *in;            // the segment's audio (planar device buffers); tables mode: the impulse responses
+    float *out;
+    long long in_stream_stride, in_ch_stride;       // floats; multiples of 4 (16-byte accesses)
+    long long out_stream_stride, out_ch_stride;
+    const float *xhist;         // [stream][2][xh_len]: the frames in front of the segment (frame -1 at xh_len - 1); may be NULL
+    long long xh_len;
+    int n_streams;
+    long long n_frames;         // valid frames of `in` from the segment's start; beyond: zeros (in) / not stored (out)
+    int u0, n_fwd;              // F: windows u0 .. u0 + n_fwd - 1 (u < 1 reaches into xhist)
+    int n_big;                  // MI: output blocks 0 .. n_big - 1
+    int P2pad;                  // 2048-tap partitions, padded to a multiple of 4 (zero tables beyond the real count)
+    float4 *ring;               // [stream][ring_cap][2048]: slot q = (Z[q], Z[4096 - q]), slot 0 = (Z[0], Z[2048])
+    int ring_cap;
+    long long ring_base;        // window u lives in ring slot (ring_base + u) % ring_cap; ring_base + u >= 0 for every u touched
+    const float4 *cd;           // [P2pad][2 planes][2048]: plane 0 = (C[k], D[k]), plane 1 = (C[N - k], D[N - k]), 1/4096 folded in
+    const float2 *tw;           // master twiddle table of the 1024-point transform
+    const float2 *tw4096;       // [3][1024]: w4096^(n1 c), c = 1 .. 3
+    float gain;
+    int fp_mode;
+    int tables_mode;            // F: 1 = window i is [block i of `in`, 2048 zeros] (impulse-response partitions)
+};
+hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st);
+hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st);
+// (C, D) tables from the spectra of A = h_lsl + j h_lsr (ab[0][i]) and B = h_rsl + j h_rsr (ab[1][i]), i < P2pad
+hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st);
+// dst[s][ch][j] = frame (n_frames - len + j) of the stream: from `in` when >= 0, else from old[s][ch][len + that]
+hipError_t launch_conv_lb_xhist_update(const float *old, const float *in, long long in_ss, long long in_cs, float *dst,
+                                       long long len, long long n_frames, int n_streams, hipStream_t st);
+void conv_lb_build_twiddles(float2 *out);       // host: [3][1024]
+constexpr int kLbBlock = 2048;                  // frames per block of this plan
+constexpr int kLbTile = 4;                      // output blocks per MI workgroup
+
 // IR chunk -> spectrum: dst[part][16][64], one wave per partition.
 hipError_t launch_ir_spectrum(const float *d_ir, int len, int n_parts, float2 *dst,
                               const float2 *tw, hipStream_t st);

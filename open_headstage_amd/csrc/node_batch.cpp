@@ -36,6 +36,8 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -62,6 +64,8 @@ Rccl &rccl()
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(sym("ncclCommCuDevice"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
@@ -97,14 +101,21 @@ struct DeviceWorker {
 
     void loop(int device)
     {
-        hipSetDevice(device);
+        // The thread's current device is what every launch of this slot goes to.  If it cannot be set the slot is dead:
+        // its jobs are refused (never run on whatever device the thread happens to have), and the node batch fails closed.
+        const hipError_t set = hipSetDevice(device);
+        int cur = -1;
+        const bool dev_ok = set == hipSuccess && hipGetDevice(&cur) == hipSuccess && cur == device;
+        const std::string dev_err = dev_ok ? std::string()
+                                           : "worker thread could not make device " + std::to_string(device) + " current (" +
+                                                 (set != hipSuccess ? hipGetErrorString(set) : "hipGetDevice disagrees") + ")";
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             cv.wait(lk, [&] { return has_job || quit; });
             if (quit) return;
             lk.unlock();
-            const int r = job();
-            std::string e = r ? ohs_last_error() : "";      // (thread-local in the core library: carried to the caller)
+            const int r = dev_ok ? job() : (int)OHS_ERR_HIP;
+            std::string e = !dev_ok ? dev_err : (r ? ohs_last_error() : "");      // (thread-local in the core library: carried to the caller)
             lk.lock();
             rc = r; err.swap(e);
             has_job = false;
@@ -253,16 +264,37 @@ int refuse_if_unusable(const ohs_node_batch *nb)
     return OHS_OK;
 }
 
+// (OHS_ERR_INVALID_ARG: every slot's ohs_batch_* call checks its arguments before it queues or stores anything -- the
+// same arguments on every slot, so all of them refused and nothing is out of step or torn)
 int processing_result(ohs_node_batch *nb, int rc)
 {
-    if (rc) { nb->failed = true; nb->fail_msg = ohs_last_error(); }
+    if (rc && rc != OHS_ERR_INVALID_ARG) { nb->failed = true; nb->fail_msg = ohs_last_error(); }
     return rc;
 }
 
 int table_result(ohs_node_batch *nb, int rc)
 {
-    if (rc) { nb->tables_torn = true; nb->torn_msg = ohs_last_error(); }
+    if (rc && rc != OHS_ERR_INVALID_ARG) { nb->tables_torn = true; nb->torn_msg = ohs_last_error(); }
     return rc;
+}
+
+// what ncclCommInitAll returned is what was asked for: one communicator per device slot, rank i on device dev[i], all
+// of size n (a mismatch would make the grouped broadcast write a device other than the one its ohs_batch lives on)
+int check_communicators(ohs_node_batch *nb)
+{
+    Rccl &R = rccl();
+    for (int i = 0; i < nb->n; ++i) {
+        if (!nb->comm[(size_t)i]) return fail(OHS_ERR_RCCL, "ncclCommInitAll returned no communicator for slot " + std::to_string(i));
+        int cnt = -1, cu = -1, rank = -1;
+        NB_NCCL(R.CommCount(nb->comm[(size_t)i], &cnt));
+        NB_NCCL(R.CommCuDevice(nb->comm[(size_t)i], &cu));
+        NB_NCCL(R.CommUserRank(nb->comm[(size_t)i], &rank));
+        if (cnt != nb->n || cu != nb->dev[(size_t)i] || rank != i)
+            return fail(OHS_ERR_RCCL, "ncclCommInitAll: slot " + std::to_string(i) + " got a communicator of size " + std::to_string(cnt) +
+                        " (wanted " + std::to_string(nb->n) + "), rank " + std::to_string(rank) + " (wanted " + std::to_string(i) +
+                        ") on device " + std::to_string(cu) + " (wanted " + std::to_string(nb->dev[(size_t)i]) + ")");
+    }
+    return OHS_OK;
 }
 
 }  // namespace
@@ -312,7 +344,10 @@ int ohs_node_batch_create(int n_devices, const int *devices, size_t streams_tota
             NB_HIP(hipEventCreate(&nb->ev0[(size_t)i]));
             NB_HIP(hipEventCreate(&nb->ev1[(size_t)i]));
         }
-        if (!shared) NB_NCCL(R.CommInitAll(nb->comm.data(), n_devices, dev.data()));
+        if (!shared) {
+            NB_NCCL(R.CommInitAll(nb->comm.data(), n_devices, dev.data()));
+            if (const int r = check_communicators(nb)) return r;
+        }
         for (int i = 0; i < n_devices; ++i) {
             nb->worker.emplace_back(new DeviceWorker);
             DeviceWorker *w = nb->worker.back().get();
@@ -516,7 +551,11 @@ int ohs_node_batch_process(ohs_node_batch *nb, const float *const d_in[], float 
 int ohs_node_batch_sync(ohs_node_batch *nb)
 {
     if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");
-    return run_on_all(nb, [&](int i) { return ohs_batch_sync(nb->b[(size_t)i], nb->pst[(size_t)i]); });
+    // every device is waited for in any case (nothing may still be running when the caller looks at its buffers); a
+    // failed / torn node batch then says so instead of "OK": what the buffers hold is not a result
+    const int rc = run_on_all(nb, [&](int i) { return ohs_batch_sync(nb->b[(size_t)i], nb->pst[(size_t)i]); });
+    if (const int r = refuse_if_unusable(nb)) return r;
+    return rc;
 }
 
 int ohs_node_batch_stream(ohs_node_batch *nb, int slot, void **hip_stream)
@@ -529,6 +568,7 @@ int ohs_node_batch_stream(ohs_node_batch *nb, int slot, void **hip_stream)
 int ohs_node_batch_timer_begin(ohs_node_batch *nb)
 {
     if (!nb) return fail(OHS_ERR_INVALID_ARG, "node batch is NULL");
+    if (const int r = refuse_if_unusable(nb)) return r;
     return run_on_all(nb, [&](int i) {
         NB_HIP(hipEventRecord(nb->ev0[(size_t)i], nb->pst[(size_t)i]));
         return (int)OHS_OK;
@@ -538,6 +578,7 @@ int ohs_node_batch_timer_begin(ohs_node_batch *nb)
 int ohs_node_batch_timer_end(ohs_node_batch *nb, float *ms_per_slot)
 {
     if (!nb || !ms_per_slot) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (const int r = refuse_if_unusable(nb)) return r;     // (a time measured over a half-advanced step is not a step time)
     return run_on_all(nb, [&](int i) {
         NB_HIP(hipEventRecord(nb->ev1[(size_t)i], nb->pst[(size_t)i]));
         const int r = ohs_batch_sync(nb->b[(size_t)i], nb->pst[(size_t)i]);

@@ -134,8 +134,8 @@ bool tuning_set(const std::string &key, const std::string &value)
     if (key == "host_pipe_flat_priorities") return one(&t.host_pipe_flat_priorities);
     if (key == "node_shared_device_rehearsal") return one(&t.node_shared_device_rehearsal);
     if (key == "node_inject_table_failure_slot") return one(&t.node_inject_table_failure_slot);
-    if (key == "rt_max_resident") return one(&t.rt_max_resident);
-    if (key == "rt_idle_polls") { t.rt_idle_polls = strtoull(value.c_str(), nullptr, 10); return true; }
+    if (key == "rt_max_resident") { int v = 0; if (!one(&v)) return false; rt_max_resident_store(v); return true; }
+    if (key == "rt_idle_polls") { rt_idle_polls_store(strtoull(value.c_str(), nullptr, 10)); return true; }
     if (key == "rt_poll_sleep") { if (!one(v)) return false; t.rt_poll_sleep = (unsigned)v[0]; return true; }
     return false;
 }

@@ -51,6 +51,12 @@ struct Tuning {
 
 const Tuning &tuning();
 Tuning &tuning_rt();        // the three rt_* fields only (ohs_rt_configure); everything else stays constant in the product
+// ohs_rt_configure may be called while other threads' engines start resident kernels: the two fields it writes are
+// read and written through these (relaxed atomics on the plain fields -- Tuning stays copyable)
+inline int rt_max_resident_load() { return __atomic_load_n(&tuning().rt_max_resident, __ATOMIC_RELAXED); }
+inline unsigned long long rt_idle_polls_load() { return __atomic_load_n(&tuning().rt_idle_polls, __ATOMIC_RELAXED); }
+inline void rt_max_resident_store(int v) { __atomic_store_n(&tuning_rt().rt_max_resident, v, __ATOMIC_RELAXED); }
+inline void rt_idle_polls_store(unsigned long long v) { __atomic_store_n(&tuning_rt().rt_idle_polls, v, __ATOMIC_RELAXED); }
 #ifdef OHS_EXPERIMENTS
 // "key=value" edits; returns false for an unknown key or an unparsable value
 bool tuning_set(const std::string &key, const std::string &value);

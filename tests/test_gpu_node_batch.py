@@ -213,10 +213,48 @@ def test_node_batch_fails_closed_when_one_slot_fails(ohs, synth, exp_tuning):
         with pytest.raises(ohs.OhsError) as ei:
             call()
         assert ei.value.status == _ffi.OHS_ERR_HIP and "out of step" in str(ei.value) and "ohs_node_batch_reset" in str(ei.value)
+    # sync / the timer do not answer "OK" over half-advanced state either (they still wait for every device)
+    for call in (nb.sync, nb.timer_begin, nb.timer_end):
+        with pytest.raises(ohs.OhsError) as ei:
+            call()
+        assert ei.value.status == _ffi.OHS_ERR_HIP and "out of step" in str(ei.value)
     nb.reset()
     nb.process(xs, ys)
     nb.sync()
     assert torch.equal(torch.cat(ys).view(torch.int32), y_fresh.view(torch.int32))
+
+
+def test_node_batch_argument_errors_do_not_poison_the_handle(ohs, synth, exp_tuning):
+    """an OHS_ERR_INVALID_ARG is found by every slot before anything is queued or stored -- the node batch
+    must stay usable (no reset, which would zero every stream's state; no repeated table call) and answer the next
+    valid call with the bits of the unsharded batch."""
+    import ctypes as C
+    import torch
+    from open_headstage_amd import _ffi
+    dev = torch.device("cuda:0")
+    slots, S, n = 3, 7, 16 * 512
+    nb, bp, _ = _rehearsal_pair(ohs, synth, exp_tuning, slots, S)
+    shards = [nb.shard(i) for i in range(slots)]
+    x = synth.white_noise_torch(5, S, 2 * n, dev)
+    xa, xb = x[:, :, :n].contiguous(), x[:, :, n:].contiguous()
+    torch.cuda.synchronize()
+    ys = [torch.empty_like(xa[f:f + c]) for _, f, c in shards]
+    nb.process([xa[f:f + c].contiguous() for _, f, c in shards], ys); nb.sync()
+    # strides smaller than the processed region, then a block count beyond 2^24: refused by every slot
+    xs = [xb[f:f + c].contiguous() for _, f, c in shards]
+    with pytest.raises(ohs.OhsError) as ei:
+        nb.process_ptrs([t.data_ptr() for t in xs], [t.data_ptr() for t in ys], n // 512, 2 * n, n // 2)
+    assert ei.value.status == _ffi.OHS_ERR_INVALID_ARG
+    with pytest.raises(ohs.OhsError) as ei:
+        nb.process_ptrs([t.data_ptr() for t in xs], [t.data_ptr() for t in ys], (1 << 24) + 1, 1 << 40, 1 << 39)
+    assert ei.value.status == _ffi.OHS_ERR_INVALID_ARG
+    # a NULL coefficient pointer: refused, the tables are not torn
+    L = nb._lib
+    assert L.ohs_node_batch_set_eq_band_coeffs(nb._h, C.c_size_t(0), None, 1) == _ffi.OHS_ERR_INVALID_ARG
+    nb.process(xs, ys); nb.sync()          # continues where the first call stopped: no reset happened
+    ya = bp.process(xa); yb = bp.process(xb)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(ys).view(torch.int32), yb.view(torch.int32))
 
 
 def test_node_batch_refuses_to_process_on_torn_tables(ohs, synth, exp_tuning):
