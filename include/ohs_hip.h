@@ -315,18 +315,41 @@ int  ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable);
 int  ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable);    /* see ohs_eq_set_exact_specials */
 int  ohs_batch_set_flush_denormals(ohs_batch *b, int mode);         /* see ohs_engine_set_flush_denormals (EQ and convolution) */
 int  ohs_batch_set_gain(ohs_batch *b, float gain);
-/* Which kernel plan serves calls in which every path has ONE partition (taps <= 512, BASELINE configs[2] / [4]):
- *   1  block 512 / FFT 1024, overlap-add -- the reference's own blocking (convolution.rs:22-23); output bits do not depend
- *      on where a signal is cut into calls, and are the ones tests/golden/p1_output_sha256.txt records
- *   2  hop 1536 / FFT 2048, overlap-save -- a quarter less transform and product work per frame, 11-12 % less time where
- *      the convolution is what the step waits for; equal to plan 1 up to f32 rounding (2-3e-7 relative RMS against the
- *      oracle, like every FFT path), not bit for bit, and the rounding depends on where the calls cut the signal
- *   0  the library's choice (default): plan 2 for calls of 48 blocks or more on 512 streams or more -- on 256 or more
- *      when the call is out of place and the EQ is off --, plan 1 otherwise (at BASELINE configs[2] the convolution hides
- *      under the EQ either way, and the block-512 bits stay as recorded).
- * Plan 2 needs even strides and 8-byte aligned buffers; calls that do not meet that, longer impulse responses and the
- * single-stream engine are served as before. */
+/* Which kernel plan serves the convolution of a batch call.
+ *   1  block 512 / FFT 1024 -- the reference's own blocking (convolution.rs:22-23,120-132), for every impulse response
+ *      length.  One partition (taps <= 512): output bits do not depend on where a signal is cut into calls, and are the ones
+ *      tests/golden/p1_output_sha256.txt records.
+ *   2  the large-transform plans, wherever their preconditions hold (else plan 1 serves the call):
+ *        every path ONE partition (BASELINE configs[2] / [4]): hop 1536 / FFT 2048, overlap-save -- a quarter less transform
+ *          and product work per frame, 11-12 % less time where the convolution is what the step waits for.  Needs even
+ *          strides and 8-byte aligned buffers, calls of 3 blocks or more.
+ *        longer responses, from 8 partitions (taps > 3584; BASELINE configs[3]): block 2048 / FFT 4096, overlap-save -- a
+ *          quarter of the reference blocking's products and history reads per frame (16 384 taps: 8 partitions instead of
+ *          the 32 of convolution.rs:120-132), product and inverse transform in one kernel.  Needs strides that are multiples
+ *          of 4 floats and 16-byte aligned buffers, and every path either older than its own response or reset together
+ *          with the others (the call right after a per-path set_ir in mid-stream is served by plan 1).
+ *      Equal to plan 1 up to f32 rounding (2-4e-7 relative RMS against the oracle, like every FFT path), not bit for bit,
+ *      and the rounding depends on where the calls cut the signal.  The plans hand the per-stream state over to each other:
+ *      any sequence of calls under any sequence of plans is one continuous signal.
+ *   0  the library's choice (default).  One partition: plan 2 for calls of 48 blocks or more on 512 streams or more -- on
+ *      256 or more when the call is out of place and the EQ is off --, plan 1 otherwise (at BASELINE configs[2] the
+ *      convolution hides under the EQ either way, and the block-512 bits stay as recorded).  Longer responses: plan 2 for
+ *      calls of 16 blocks or more that are at least half as long as the response, plan 1 otherwise.
+ * The single-stream engine is always served by the reference blocking. */
 int  ohs_batch_set_conv_plan(ohs_batch *b, int plan);
+/* What served the handle's most recent convolution launch (of the last time chunk, when a call is cut into several): the
+ * kernel family and the number of independent ranges a stream's frames were cut into for it (one-partition plans: time
+ * chunks per stream; block 2048: output tiles per stream of the last segment; time-parallel block 512: blocks of the
+ * last segment; sequential kernel: 1).  A benchmark or a test asks instead of restating the library's rule. */
+enum ohs_conv_kernel {
+    OHS_CONV_KERNEL_NONE = 0,           /* no convolution launch yet */
+    OHS_CONV_KERNEL_BLOCK512_P1 = 1,    /* k_conv_p1: one partition, block 512 / FFT 1024 */
+    OHS_CONV_KERNEL_HOP1536_P1 = 2,     /* k_conv_p1_os: one partition, hop 1536 / FFT 2048 */
+    OHS_CONV_KERNEL_BLOCK512_TP = 3,    /* k_conv_tp_*: several partitions, block 512, time-parallel */
+    OHS_CONV_KERNEL_BLOCK2048 = 4,      /* k_conv_lb_*: several partitions, block 2048 / FFT 4096 */
+    OHS_CONV_KERNEL_SEQUENTIAL = 5      /* k_conv_general: one wave per stream, blocks in sequence */
+};
+int  ohs_batch_last_conv_plan(const ohs_batch *b, int *kernel, int *ranges_per_stream);
 /* zero every stream's EQ state, history and overlap (IRs and EQ table kept).  Also the way back from a failed handle:
  * a HIP failure in the middle of a processing call leaves the per-stream state advanced for some time chunks only, so
  * the call joins its internal stream, returns OHS_ERR_HIP, and every later processing call on the handle returns

@@ -113,6 +113,7 @@ PROTOTYPES = {
     "ohs_batch_set_eq_enabled": (C.c_int, [vp, C.c_int]),
     "ohs_batch_set_gain": (C.c_int, [vp, C.c_float]),
     "ohs_batch_set_conv_plan": (C.c_int, [vp, C.c_int]),
+    "ohs_batch_last_conv_plan": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ohs_node_batch_set_conv_plan": (C.c_int, [vp, C.c_int]),
     "ohs_batch_reset": (C.c_int, [vp]),
     "ohs_batch_process": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),

@@ -74,9 +74,18 @@ class BatchProcessor:
         self._check(self._lib.ohs_batch_set_gain(self._h, float(gain)))
 
     def set_conv_plan(self, plan: int) -> None:
-        """taps <= 512: 1 = block 512 / FFT 1024 (bit-stable), 2 = hop 1536 / FFT 2048, 0 = the library's choice
+        """1 = block 512 / FFT 1024 (the reference's blocking; bit-stable for taps <= 512), 2 = the large-transform plans
+        (taps <= 512: hop 1536 / FFT 2048; taps > 3584: block 2048 / FFT 4096), 0 = the library's choice
         (ohs_batch_set_conv_plan)"""
         self._check(self._lib.ohs_batch_set_conv_plan(self._h, int(plan)))
+
+    CONV_KERNELS = {0: "none", 1: "block512_p1", 2: "hop1536_p1", 3: "block512_tp", 4: "block2048", 5: "sequential"}
+
+    def last_conv_plan(self):
+        """(kernel family name, ranges per stream) of the most recent convolution launch (ohs_batch_last_conv_plan)"""
+        k, r = C.c_int(), C.c_int()
+        self._check(self._lib.ohs_batch_last_conv_plan(self._h, C.byref(k), C.byref(r)))
+        return self.CONV_KERNELS.get(int(k.value), str(k.value)), int(r.value)
 
     def reset(self) -> None:
         self._check(self._lib.ohs_batch_reset(self._h))

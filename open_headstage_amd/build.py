@@ -54,6 +54,7 @@ def _units():
         # operations are written out (wave_fft.hpp), so that every kernel inlining them rounds alike
         ("conv_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
         ("conv_os_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),   # the overlap-save plan of the P = 1 path
+        ("conv_lb_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),   # block 2048 / FFT 4096 for long impulse responses
         # (experiments builds only: OHS_MAC_TB / OHS_MAC_PI fix the MAC's register tile)
         ("conv_mac_kernels.hip", [f"-D{k}={os.environ[k]}" for k in ("OHS_MAC_TB", "OHS_MAC_PI")
                                   if EXPERIMENTS and k in os.environ]),

@@ -156,8 +156,17 @@ int ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable)
 int ohs_batch_set_conv_plan(ohs_batch *b, int plan)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
-    if (plan < 0 || plan > 2) return fail(OHS_ERR_INVALID_ARG, "plan must be 0 (library's choice), 1 (block 512) or 2 (hop 1536)");
+    if (plan < 0 || plan > 2)
+        return fail(OHS_ERR_INVALID_ARG, "plan must be 0 (library's choice), 1 (block 512) or 2 (large transforms: hop 1536 / block 2048)");
     b->conv.conv_plan = plan;
+    return OHS_OK;
+}
+
+int ohs_batch_last_conv_plan(const ohs_batch *b, int *kernel, int *ranges_per_stream)
+{
+    if (!b || !kernel || !ranges_per_stream) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    *kernel = b->conv.last_kernel;
+    *ranges_per_stream = b->conv.last_ranges;
     return OHS_OK;
 }
 
@@ -178,6 +187,11 @@ int ohs_batch_reset(ohs_batch *b)
     HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), b->st));
     HIP_TRY(hipMemsetAsync(c.d_tails, 0, c.S * 2 * 8 * 64 * sizeof(float2), b->st));
     c.tails_lazy = false;       // (the zeroed per-path overlaps are the state)
+    c.lb_lazy = false; c.lb_valid = 0;
+    if (c.d_xhist) {            // (the block-2048 plan's state: zeros are what every path may see of the past)
+        HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)c.xh_len * sizeof(float), b->st));
+        c.xh_valid = c.xh_len;
+    }
     c.cnt = 0;
     for (int p = 0; p < 4; ++p) c.since[p] = 0;
     int rc = eq_reset(b->eq, b->st);
@@ -697,6 +711,11 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
         // last block's input copy 4 KiB
         const uint64_t state = b->conv.lazy_ok ? 3u * 4096u : 2u * 8192u;
         *conv_bytes = nbk * S * 8192u + S * ((K - 1) * (own_tails ? 1u : 3u) * 4096u + state);
+    } else if (b->conv.d_xhist && P >= kLbMinP &&
+               (b->conv.conv_plan == 2 || (b->conv.conv_plan == 0 && conv_plan_auto_is_lb((size_t)S, (long long)nbk, P)))) {
+        // block-2048 plan: audio in, ring write (16 B per frame), ring read once, audio out -- the product never leaves the
+        // chip; plus the input history copied once per segment (read + write)
+        *conv_bytes = nbk * S * (4096u + 8192u + 8192u + 4096u) + 2u * S * 2u * (uint64_t)b->conv.xh_len * 4u;
     } else {
         *conv_bytes = nbk * S * (4096u + 8192u + 8192u + 8192u + 8192u + 4096u);
     }

@@ -26,6 +26,15 @@ void conv_free(ConvState &c)
     if (c.d_last_in) hipFree(c.d_last_in);
     if (c.d_irt) hipFree(c.d_irt);
     if (c.d_cd_os) hipFree(c.d_cd_os);
+    if (c.d_irl) hipFree(c.d_irl);
+    if (c.d_xhist) hipFree(c.d_xhist);
+    if (c.d_xhist_alt) hipFree(c.d_xhist_alt);
+    if (c.d_lb_ring) hipFree(c.d_lb_ring);
+    if (c.d_lb_cd) hipFree(c.d_lb_cd);
+    if (c.d_lb_ab) hipFree(c.d_lb_ab);
+    c.d_irl = nullptr; c.irl_len = 0; c.d_xhist = nullptr; c.d_xhist_alt = nullptr; c.xh_len = 0; c.xh_valid = 0;
+    c.d_lb_ring = nullptr; c.lb_ring_cap = 0; c.lb_valid = 0; c.d_lb_cd = nullptr; c.d_lb_ab = nullptr; c.lb_p2pad = 0;
+    c.lb_cd_valid = false; c.lb_lazy = false;
     c.d_irt = nullptr; c.d_cd_os = nullptr; c.cd_os_valid = false;
     c.d_merged = nullptr; c.d_merged_alt = nullptr; c.d_last_in = nullptr; c.tails_lazy = false; c.lazy_ok = false;
     c.d_cdm = nullptr; c.d_W = nullptr; c.d_W1 = nullptr;
@@ -75,8 +84,45 @@ int conv_enable_lazy_state(ConvState &c)
 
 // the per-path overlaps (d_tails) from the lazy state: whoever reads or edits d_tails calls this first -- a per-path
 // set_ir (with the OLD spectra still in place: the overlaps belong to them), the general and the long-IR kernels
+// The block-2048 plan leaves no spectra and no overlaps behind: its state is the streams' last input frames (d_xhist).  The
+// block-512 state -- the ring's last Pmax spectra and the four per-path overlaps behind the last block -- is what the
+// reference's engine would hold after those frames (convolution.rs:258,279-284): replay the last R = min(Pmax, cnt) blocks
+// through the sequential kernel from zero overlaps, nothing stored (block t - i of the replay is visible to path p under
+// the same `since` rule as ever; what lies further back than R blocks cannot reach the last block's overlap).
+static int conv_materialise_from_xhist(ConvState &c, DeviceCtx *ctx, hipStream_t st)
+{
+    if (!c.lb_lazy) return OHS_OK;
+    int Pmax = 1;
+    for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
+    const long long R = std::min<long long>(std::min<long long>(Pmax, (long long)c.cnt), c.xh_len / BS);
+    if (R > 0) {
+        int rc = conv_grow_ring(c, (int)R, st);
+        if (rc) return rc;
+        ConvGeneralArgs a;
+        a.in = c.d_xhist + (c.xh_len - R * BS); a.out = c.d_xhist_alt;     // (nothing is stored: skip_store = R)
+        a.in_stream_stride = 2 * c.xh_len; a.in_ch_stride = c.xh_len;
+        a.out_stream_stride = 2 * c.xh_len; a.out_ch_stride = c.xh_len;
+        a.n_blocks = (int)R;
+        for (int p = 0; p < 4; ++p) { a.H[p] = c.d_H[p]; a.P[p] = c.P[p]; a.since[p] = c.since[p] - R; }
+        a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt - (unsigned long long)R;
+        a.tails = c.d_tails; a.tails_out = c.d_tails;
+        a.skip_store = (int)R; a.zero_tails_in = 1;
+        a.tw = ctx->d_tw; a.gain = 1.0f; a.fp_mode = c.fp_mode;
+        hipError_t e = launch_conv_general(a, (int)c.S, st);
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("state replay launch: ") + hipGetErrorString(e));
+    } else {
+        HIP_TRY(hipMemsetAsync(c.d_tails, 0, c.S * 2 * 8 * 64 * sizeof(float2), st));
+    }
+    c.lb_lazy = false;
+    return OHS_OK;
+}
+
 int conv_materialise_state(ConvState &c, DeviceCtx *ctx, hipStream_t st)
 {
+    if (c.lb_lazy) {
+        const int rc = conv_materialise_from_xhist(c, ctx, st);
+        if (rc) return rc;
+    }
     if (!c.tails_lazy) return OHS_OK;
     ConvP1Args a;
     std::memset(&a, 0, sizeof(a));
@@ -115,6 +161,183 @@ int conv_grow_ring(ConvState &c, int need, hipStream_t st)
     hipFree(c.d_hist);
     c.d_hist = nh;
     c.cap = ncap;
+    return OHS_OK;
+}
+
+// ---- block-2048 plan: the host side of its state (api_internal.h: ConvState) -----------------------------------------
+static long long lb_p2pad_for(int Pmax) { return ((((long long)Pmax + 3) / 4) + 3) / 4 * 4; }    // 2048-tap partitions, multiple of 4
+
+// the time-domain copy of path `path`'s response (batch objects): [4][irl_len], grown as needed
+int conv_lb_store_ir(ConvState &c, int path, const float *d_src, const float *h_src, size_t len, int P, hipStream_t st)
+{
+    const long long need = lb_p2pad_for(P) * kLbBlock;
+    if (need > c.irl_len) {
+        DeviceWideSection dws;
+        float *n = nullptr;
+        HIP_TRY(hipMalloc(&n, 4 * (size_t)need * sizeof(float)));
+        hipError_t e = hipMemsetAsync(n, 0, 4 * (size_t)need * sizeof(float), st);
+        if (e == hipSuccess && c.d_irl)
+            e = hipMemcpy2DAsync(n, (size_t)need * sizeof(float), c.d_irl, (size_t)c.irl_len * sizeof(float),
+                                 (size_t)c.irl_len * sizeof(float), 4, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { hipFree(n); return fail(OHS_ERR_HIP, std::string("impulse response copy: ") + hipGetErrorString(e)); }
+        if (c.d_irl) hipFree(c.d_irl);
+        c.d_irl = n; c.irl_len = need;
+    }
+    if (!c.d_irl) return OHS_OK;
+    float *dst = c.d_irl + (size_t)path * c.irl_len;
+    HIP_TRY(hipMemsetAsync(dst, 0, (size_t)c.irl_len * sizeof(float), st));
+    if (len && d_src) HIP_TRY(hipMemcpyAsync(dst, d_src, len * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (len && h_src) HIP_TRY(hipMemcpyAsync(dst, h_src, len * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c.lb_cd_valid = false;
+    return OHS_OK;
+}
+
+// after a set_ir has updated P[] and since[]: the input history exists exactly while some response is long enough for the
+// block-2048 plan (the one-partition fast path never pays for it); its length follows the longest response
+int conv_lb_after_set_ir(ConvState &c, hipStream_t st)
+{
+    if (!c.lazy_ok) return OHS_OK;
+    int Pmax = 1;
+    for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
+    const long long want = Pmax >= kLbMinP ? lb_p2pad_for(Pmax) * kLbBlock : 0;
+    if (want != c.xh_len) {
+        DeviceWideSection dws;
+        HIP_TRY(hipStreamSynchronize(st));
+        float *n = nullptr, *n2 = nullptr;
+        if (want) {
+            const size_t bytes = c.S * 2 * (size_t)want * sizeof(float);
+            HIP_TRY(hipMalloc(&n, bytes));
+            if (hipMalloc(&n2, bytes) != hipSuccess) { hipFree(n); return fail(OHS_ERR_HIP, "hipMalloc(input history) failed"); }
+            hipError_t e = hipMemsetAsync(n, 0, bytes, st);
+            if (e == hipSuccess && c.d_xhist) {     // keep what is there, right-aligned (the newest frame stays the last one)
+                const long long keep = std::min(want, c.xh_len);
+                e = hipMemcpy2DAsync(n + (want - keep), (size_t)want * sizeof(float), c.d_xhist + (c.xh_len - keep),
+                                     (size_t)c.xh_len * sizeof(float), (size_t)keep * sizeof(float), c.S * 2,
+                                     hipMemcpyDeviceToDevice, st);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { hipFree(n); hipFree(n2); return fail(OHS_ERR_HIP, std::string("input history: ") + hipGetErrorString(e)); }
+        }
+        if (c.d_xhist) hipFree(c.d_xhist);
+        if (c.d_xhist_alt) hipFree(c.d_xhist_alt);
+        c.d_xhist = n; c.d_xhist_alt = n2;
+        c.xh_valid = std::min(c.xh_valid, want);
+        c.xh_len = want;
+        c.lb_valid = 0;         // (the ring's depth follows the partition count)
+        c.lb_cd_valid = false;
+    }
+    if (c.d_xhist && c.since[0] == 0 && c.since[1] == 0 && c.since[2] == 0 && c.since[3] == 0) {
+        // every path has forgotten its past (convolution.rs:135-137): so has the input history, and zeros are what every path
+        // may see of it
+        HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)c.xh_len * sizeof(float), st));
+        c.xh_valid = c.xh_len;
+        c.lb_valid = 0;
+    }
+    return OHS_OK;
+}
+
+// ohs_batch_set_conv_plan(0) for long responses: the block-2048 plan costs a call the input-history copy and, when the call
+// does not continue the previous one's window grid, P2pad - 1 warm-up transforms per stream; it pays from calls that are a
+// fair fraction of the response long
+bool conv_plan_auto_is_lb(size_t S, long long n_blocks, int Pmax)
+{
+    (void)S;
+    return Pmax >= kLbMinP && n_blocks >= 16 && 2 * n_blocks >= Pmax;
+}
+
+// segment length of a block-2048 launch sequence, in blocks of 2048: keeps the ring around 128 MiB
+static long long lb_segment_blocks(size_t S)
+{
+    long long seg = 4096 / (long long)std::max<size_t>(S, 1);
+    seg = std::max<long long>(8, std::min<long long>(seg, 256));
+    return seg / kLbTile * kLbTile;
+}
+
+static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs, float *out,
+                          long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st)
+{
+    const int P2pad = (int)(c.xh_len / kLbBlock);
+    // tables: the spectra of A = h_lsl + j h_lsr and B = h_rsl + j h_rsr per 2048-tap partition (the forward kernel in
+    // tables mode, two "streams" of P2pad windows), then (C, D)
+    if (!c.d_lb_cd || c.lb_p2pad != P2pad) {
+        DeviceWideSection dws;
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c.d_lb_cd) hipFree(c.d_lb_cd);
+        if (c.d_lb_ab) hipFree(c.d_lb_ab);
+        c.d_lb_cd = nullptr; c.d_lb_ab = nullptr; c.lb_p2pad = 0; c.lb_cd_valid = false;
+        HIP_TRY(hipMalloc(&c.d_lb_cd, (size_t)P2pad * 2 * kLbBlock * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c.d_lb_ab, (size_t)P2pad * 2 * kLbBlock * sizeof(float4)));
+        c.lb_p2pad = P2pad;
+    }
+    ConvLbArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.tw = ctx->d_tw; a.tw4096 = ctx->d_tw4096; a.fp_mode = c.fp_mode; a.P2pad = P2pad;
+    if (!c.lb_cd_valid) {
+        if (c.irl_len < (long long)P2pad * kLbBlock) return fail(OHS_ERR_HIP, "block-2048 plan: impulse responses not stored");
+        ConvLbArgs t = a;
+        t.in = c.d_irl; t.in_stream_stride = 2 * c.irl_len; t.in_ch_stride = c.irl_len;
+        t.out = nullptr; t.n_streams = 2; t.n_frames = c.irl_len;
+        t.u0 = 0; t.n_fwd = P2pad; t.ring = c.d_lb_ab; t.ring_cap = P2pad; t.ring_base = 0; t.tables_mode = 1;
+        t.fp_mode = 0;      // (tables are built in IEEE arithmetic, like k_ir_spectrum's)
+        hipError_t e = launch_conv_lb_forward(t, st);
+        if (e == hipSuccess) e = launch_conv_lb_build_cd(c.d_lb_ab, P2pad, c.d_lb_cd, st);
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-2048 tables: ") + hipGetErrorString(e));
+        c.lb_cd_valid = true;
+    }
+    const long long SEG = lb_segment_blocks(c.S);
+    const long long frames_total = (long long)n_blocks * BS;
+    const long long nbig_total = (frames_total + kLbBlock - 1) / kLbBlock;
+    const int cap_need = (int)(std::min(SEG, (nbig_total + kLbTile - 1) / kLbTile * kLbTile) + P2pad - 1);
+    if (cap_need > c.lb_ring_cap) {
+        DeviceWideSection dws;
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c.d_lb_ring) hipFree(c.d_lb_ring);
+        c.d_lb_ring = nullptr; c.lb_ring_cap = 0; c.lb_valid = 0;
+        HIP_TRY(hipMalloc(&c.d_lb_ring, c.S * (size_t)cap_need * kLbBlock * sizeof(float4)));
+        c.lb_ring_cap = cap_need;
+    }
+    a.n_streams = (int)c.S; a.gain = gain; a.cd = c.d_lb_cd;
+    a.ring = c.d_lb_ring; a.ring_cap = c.lb_ring_cap;
+    a.in_stream_stride = in_ss; a.in_ch_stride = in_cs; a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+    a.xh_len = c.xh_len;
+    const long long abs0 = (long long)c.cnt * BS;
+    int tiles_last = 0;
+    for (long long off = 0; off < frames_total; off += SEG * kLbBlock) {
+        const long long segf = std::min<long long>(SEG * kLbBlock, frames_total - off);
+        const int n_big = (int)((segf + kLbBlock - 1) / kLbBlock);
+        // does this segment continue the window grid the ring holds?  (same absolute frame, enough windows behind it)
+        const bool cont = c.lb_valid >= P2pad - 1 && c.lb_frame == abs0 + off;
+        const int warm = cont ? 0 : P2pad - 1;
+        if (!cont) c.lb_next = 4ll * c.lb_ring_cap;         // (any base that keeps every slot index positive)
+        a.in = in + off; a.out = out + off;
+        a.xhist = c.d_xhist;
+        a.n_frames = segf;
+        a.u0 = -warm; a.n_fwd = warm + n_big; a.n_big = n_big;
+        a.ring_base = c.lb_next;
+        hipError_t e = launch_conv_lb_forward(a, st);
+        // the segment's frames join the input history before the inverse kernel may overwrite them (in place)
+        if (e == hipSuccess)
+            e = launch_conv_lb_xhist_update(c.d_xhist, a.in, in_ss, in_cs, c.d_xhist_alt, c.xh_len, segf, (int)c.S, st);
+        if (e == hipSuccess) {
+            std::swap(c.d_xhist, c.d_xhist_alt);
+            e = launch_conv_lb_mac_inverse(a, st);
+        }
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-2048 launch: ") + hipGetErrorString(e));
+        c.lb_next += n_big;
+        if (c.lb_next > (1ll << 40)) c.lb_valid = 0;        // (rebase long before the index could overflow)
+        if (segf % kLbBlock == 0) {
+            c.lb_valid = std::min<long long>((cont ? c.lb_valid : warm) + n_big, c.lb_ring_cap);
+            c.lb_frame = abs0 + off + segf;
+        } else {
+            c.lb_valid = 0;     // the last window was padded with zeros: the next call does not continue this grid
+        }
+        tiles_last = (n_big + kLbTile - 1) / kLbTile;
+    }
+    c.xh_valid = std::min(c.xh_len, c.xh_valid + frames_total);
+    c.lb_lazy = true;
+    c.last_kernel = OHS_CONV_KERNEL_BLOCK2048; c.last_ranges = tiles_last;
     return OHS_OK;
 }
 
@@ -164,6 +387,10 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     const int rc0 = body();
     if (d_ir) hipFree(d_ir);
     if (rc0) { if (nH) hipFree(nH); return rc0; }
+    if (c.lazy_ok) {
+        const int rcl = conv_lb_store_ir(c, path, ir_on_device ? ir : nullptr, ir_on_device ? nullptr : ir, len, P, st);
+        if (rcl) { hipFree(nH); return rcl; }
+    }
     hipFree(c.d_H[path]);
     c.d_H[path] = nH;
     c.P[path] = P;
@@ -176,6 +403,10 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
         // every path has forgotten its past: the ring holds nothing any path may still see.  Zeroing
         // it lets the gate-free time-parallel kernels run right away (all `since` equal).
         HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), st));
+    }
+    {
+        const int rcx = conv_lb_after_set_ir(c, st);
+        if (rcx) return rcx;
     }
     // :138 that path's overlap := 0.  Tails are (lsl + j lsr) and (rsl + j rsr).
     const int which = path >> 1, comp = path & 1;
@@ -321,6 +552,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             c.tails_lazy = true;
             c.cnt += (unsigned long long)n_blocks;
             for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;
+            c.last_kernel = OHS_CONV_KERNEL_HOP1536_P1; c.last_ranges = K;
             return OHS_OK;
         }
         const long long target_override = tn.p1_target_waves;
@@ -371,15 +603,48 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         } else {
             std::swap(c.d_tails, c.d_tails_alt);
         }
+        c.last_kernel = OHS_CONV_KERNEL_BLOCK512_P1; c.last_ranges = (int)K;
     } else {
         if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
         ev_scope.armed = true;
+        int Pmax = 1;
+        for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
+        if (allow_fast && c.d_xhist && Pmax >= kLbMinP) {
+            // Block 2048 / FFT 4096 (conv_lb_kernels.hip).  It convolves the input history itself, so every path must be
+            // allowed to see all of its own response's reach of it: older than its response (and the history that deep),
+            // or reset together with all the others (the history was zeroed then).
+            bool deep = true;
+            for (int p = 0; p < 4; ++p) deep = deep && c.since[p] >= c.P[p] && c.xh_valid >= (long long)c.P[p] * BS;
+            const bool together = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3] &&
+                                  c.xh_valid >= c.xh_len;
+            const bool lb_ok = (deep || together) && ((in_ss | in_cs | out_ss | out_cs) & 3) == 0 &&
+                               ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+            if (lb_ok && (c.conv_plan == 2 || (c.conv_plan == 0 && conv_plan_auto_is_lb(c.S, n_blocks, Pmax)))) {
+                const int rcl = conv_lb_launch(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st);
+                if (rcl) return rcl;
+                c.cnt += (unsigned long long)n_blocks;
+                for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;
+                return OHS_OK;
+            }
+        }
         {   // these kernels read and write the per-path overlaps
             const int rcm = conv_materialise_state(c, ctx, st);
             if (rcm) return rcm;
         }
-        int Pmax = 1;
-        for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
+        c.lb_valid = 0;         // (the block-2048 ring does not see the blocks of this call)
+        if (c.d_xhist) {
+            // the call's frames join the input history (before anything below overwrites them in place): what the
+            // block-2048 plan starts from when a later call takes it
+            if (((in_ss | in_cs) & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+                hipError_t e = launch_conv_lb_xhist_update(c.d_xhist, in, in_ss, in_cs, c.d_xhist_alt, c.xh_len,
+                                                           (long long)n_blocks * BS, (int)c.S, st);
+                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("input history update: ") + hipGetErrorString(e));
+                std::swap(c.d_xhist, c.d_xhist_alt);
+                c.xh_valid = std::min(c.xh_len, c.xh_valid + (long long)n_blocks * BS);
+            } else {
+                c.xh_valid = 0;     // (buffers the 16-byte copy cannot read: the history no longer follows the stream)
+            }
+        }
         const bool since_equal = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3];
         bool since_old = true;
         for (int p = 0; p < 4; ++p) since_old = since_old && c.since[p] >= c.P[p] - 1;
@@ -413,6 +678,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         if (!tp) {
             int rc = general(in, out, n_blocks, c.cnt, 0, 0, 0, c.d_tails);
             if (rc) return rc;
+            c.last_kernel = OHS_CONV_KERNEL_SEQUENTIAL; c.last_ranges = 1;
         } else {
             // segment size: keep the MAC scratch around 128 MiB
             long long SEG = 16384 / (long long)c.S;
@@ -483,6 +749,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("conv_tp: ") + hipGetErrorString(e));
                 std::swap(c.d_tails, c.d_tails_alt);
                 done += seg;
+                c.last_kernel = OHS_CONV_KERNEL_BLOCK512_TP; c.last_ranges = seg;
             }
         }
     }

@@ -87,6 +87,16 @@ int get_ctx(int device, DeviceCtx **out)
             return fail(OHS_ERR_HIP, "pair table upload failed");
         }
     }
+    {
+        std::vector<float2> t4(3 * 1024);
+        conv_lb_build_twiddles(t4.data());
+        if (hipMalloc(&c->d_tw4096, t4.size() * sizeof(float2)) != hipSuccess ||
+            hipMemcpy(c->d_tw4096, t4.data(), t4.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(c->d_tw);
+            delete c;
+            return fail(OHS_ERR_HIP, "w4096 table upload failed");
+        }
+    }
     g_ctx.push_back(c);
     *out = c;
     return OHS_OK;

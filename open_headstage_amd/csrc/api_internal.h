@@ -55,6 +55,7 @@ struct DeviceCtx {
     int device = -1;
     float2 *d_tw = nullptr;
     float2 *d_tw2048 = nullptr; // k_conv_p1_os: w2048^bin in the paired layout
+    float2 *d_tw4096 = nullptr; // k_conv_lb_*: w4096^(n1 c), [3][1024]
     int *d_pairs = nullptr;     // k_conv_tp_mac: leaders of the spectrum position pairs {b, mirror(b)}
     int n_pairs = 0;
     int num_cus = 256;
@@ -143,7 +144,28 @@ struct ConvState {
     float *d_irt = nullptr;         // [4][512]
     float4 *d_cd_os = nullptr;      // [2][1024]
     bool cd_os_valid = false;
-    int conv_plan = 0;              // ohs_batch_set_conv_plan: 0 = the library's choice, 1 = block 512 / FFT 1024, 2 = hop 1536 / FFT 2048
+    int conv_plan = 0;              // ohs_batch_set_conv_plan: 0 = the library's choice, 1 = block 512 / FFT 1024, 2 = the large-transform
+                                    // plans (one partition: hop 1536 / FFT 2048; longer responses: block 2048 / FFT 4096)
+    // Block-2048 plan for long impulse responses (conv_lb_kernels.hip; batch objects with a response of kLbMinP partitions
+    // or more).  It is overlap-save on the INPUT: the state it needs and leaves is the last xh_len input frames of every
+    // stream (d_xhist; every P > 1 launch of such an object keeps it current), not spectra and overlaps.  While lb_lazy,
+    // d_hist / d_tails are stale; conv_materialise_state rebuilds them from d_xhist when another plan needs them.
+    float *d_irl = nullptr;         // [4][irl_len] the impulse responses in the time domain, zero-padded
+    long long irl_len = 0;
+    float *d_xhist = nullptr, *d_xhist_alt = nullptr;       // [S][2][xh_len]
+    long long xh_len = 0;           // = P2pad * 2048
+    long long xh_valid = 0;         // trailing frames of d_xhist that are what every path may see of the past (zeros after a reset of all paths count)
+    bool lb_lazy = false;
+    float4 *d_lb_ring = nullptr;    // [S][lb_ring_cap][2048] window spectra, pair layout
+    int lb_ring_cap = 0;
+    long long lb_next = 0;          // ring index of the next window
+    long long lb_valid = 0;         // windows lb_next - lb_valid .. lb_next - 1 are in the ring ...
+    long long lb_frame = -1;        // ... and the block of window lb_next starts at this absolute frame (cnt * 512)
+    float4 *d_lb_cd = nullptr, *d_lb_ab = nullptr;          // [P2pad][2][2048] tables; [2][P2pad][2048] scratch for building them
+    int lb_p2pad = 0;               // what d_lb_cd / d_lb_ab are allocated for
+    bool lb_cd_valid = false;
+    // what served the last convolution launch (ohs_batch_last_conv_plan): OHS_CONV_KERNEL_*, and its ranges per stream
+    int last_kernel = 0, last_ranges = 0;
     // ohs_*_set_speakers: what it last loaded into each path (a set_ir from anywhere else forgets it), so that a
     // change of the speaker angles re-loads only the paths whose impulse response really changed
     std::vector<float> spk_ir[4];
@@ -158,6 +180,8 @@ int conv_grow_ring(ConvState &c, int need, hipStream_t st);
 int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st,
                 bool ir_on_device = false);
 bool conv_plan_auto_is_os(size_t S, long long n_blocks, bool in_place);
+constexpr int kLbMinP = 8;          // 512-tap partitions from which the block-2048 plan is considered (taps > 3584)
+bool conv_plan_auto_is_lb(size_t S, long long n_blocks, int Pmax);
 int conv_os_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, bool in_place);
 // time chunks per stream of the one-partition kernel's launch plan (also what ohs_batch_kernel_bytes prices)
 long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override, int xcd_n = 8);

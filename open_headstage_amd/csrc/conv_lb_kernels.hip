@@ -1,0 +1,408 @@
+// conv_lb_kernels.hip -- long impulse responses in batch mode: block 2048 / FFT 4096, overlap-save ("large block" plan).
+//
+// What it replaces: the reference's uniform blocking (src/dsp/convolution.rs:22-23: block 512 / FFT 1024; :120-132: one
+// spectrum per 512 taps; :261-273: P x 1024 complex products per block).  BASELINE config 4 (16 384 taps, P = 32) spends
+// 61 % of its time in that product and moves 6.4 x its I/O floor through HBM (history ring written and read, product
+// written and read).  With 2048-tap partitions the products and the history reads per frame drop to a quarter, and with
+// the product and the inverse transform in ONE kernel the product never travels through HBM:
+//   per frame (stereo): audio in 8 B + ring write 16 B | ring read 16 B + audio out 8 B   (block 512: 8 + 16 | 16 + 16 | 16 + 8)
+//
+// The 4096-point transform = four of the wave's 1024-point transforms (wave_fft.hpp), one per wave of a 4-wave
+// workgroup, plus a lane-local radix-4 step (tools/proto_lb_conv.py is the index-exact CPU model):
+//   forward, decimation in frequency:  v_c[n1] = w4096^(n1 c) sum_n2 w4^(n2 c) z[n1 + 1024 n2];  Z[4 k1 + c] = FFT1024(v_c)[k1]
+//   inverse, decimation in time:       y_c = IFFT1024(W[4 k1 + c]);  x[n1 + 1024 n2] = sum_c w4^(-n2 c) conj(w4096^(n1 c)) y_c[n1]
+// Overlap-save: window u = frames [(u - 1) 2048, (u + 1) 2048), output block t = the second half of IFFT(W_t) -- only
+// n2 = 2, 3 of the last radix-4 step are computed, and no overlap state exists: the state of a stream at rest is its
+// last P2 x 2048 INPUT frames (ConvState::d_xhist), from which the block-512 state is rebuilt when another plan needs it.
+//
+// Spectra are stored as PAIRS: slot q = (Z[q], Z[4096 - q]), slot 0 = (Z[0], Z[2048]) -- the packed two-channel product
+//   W[k] = Z[k] C[k] + conj(Z[N - k]) D[k]    (C = (A - jB)/2, D = (A + jB)/2, A = H_lsl + j H_lsr, B = H_rsl + j H_rsr)
+// then finds both of its inputs in one 16-byte load, and every global access is lane-contiguous.
+//
+// LDS of a workgroup: the 8.5 KiB twiddle tables + four slabs of 1088 complex values (42.5 KiB in all).  The slabs are the
+// four waves' transform scratch AND the three exchange images (never at the same time; workgroup barriers in between):
+//   X14  class c, sample n1      at  1088 c + 264 (n1 & 3) + (n1 >> 2)      thread (n1 = 4 tid + e) <-> wave c (n1 = 64 a + lane)
+//   X23  bin k                   at  2176 (k >= 2048) + 17 (q >> 4) + (q & 15),  q = k < 2048 ? k : (4096 - k) & 2047
+//                                                                            wave c (k = 16 lane + ..) <-> thread (q = tid + 256 p)
+// Both are conflict-free for the strided side (lane stride 17 complex = 34 dwords; 264 = 8 mod 32 complex) and contiguous
+// for the other.
+#include "kernels.h"
+#include "wave_fft.hpp"
+
+#include <atomic>
+#include <cmath>
+
+namespace ohs {
+
+typedef float lb_v2f __attribute__((ext_vector_type(2)));
+typedef float lb_v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kLbFft = 4096;
+constexpr int kLbPairs = 2048;
+constexpr int kLbSlab = 1088;                   // complex values per wave slab (the 1024-point transform needs 1084)
+constexpr int kLbPlane = 2176;                  // X23: complex values per component plane = 128 rows x 17
+constexpr size_t kLbLdsBytes = (kTabComplex + 4 * (size_t)kLbSlab) * sizeof(float2);
+static_assert(kLbSlab >= kWaveLdsComplex && 2 * kLbSlab == kLbPlane && 3 * 264 + 255 < kLbSlab, "LDS plan");
+
+__device__ __forceinline__ int lb_x14(int c, int n1) { return kLbSlab * c + 264 * (n1 & 3) + (n1 >> 2); }
+__device__ __forceinline__ int lb_x23(int k)
+{
+    const int hi = k >= kLbPairs;
+    const int q = hi ? ((kLbFft - k) & (kLbPairs - 1)) : k;
+    return kLbPlane * hi + 17 * (q >> 4) + (q & 15);
+}
+
+// host: w4096^(n1 c), c = 1 .. 3, from f64 (as the 1024-point tables are)
+void conv_lb_build_twiddles(float2 *out)
+{
+    for (int c = 1; c < 4; ++c)
+        for (int n1 = 0; n1 < 1024; ++n1) {
+            const double ang = -2.0 * 3.14159265358979323846264338327950288 * (double)(n1 * c) / 4096.0;
+            out[(c - 1) * 1024 + n1] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+}
+
+// workgroup -> (stream, index) with all workgroups of a stream on ONE XCD (the dispatcher deals workgroups to the 8 XCDs
+// round-robin by linear id; a stream's windows / tiles share input blocks and ring slots through that XCD's L2)
+__device__ __forceinline__ bool lb_job(int per_stream, int n_streams, size_t &s, int &idx)
+{
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    s = (size_t)(slot / (unsigned)per_stream) * 8 + xcd;
+    idx = (int)(slot % (unsigned)per_stream);
+    return s < (size_t)n_streams;
+}
+static unsigned lb_grid(int per_stream, int n_streams) { return (unsigned)(((n_streams + 7) / 8) * 8 * per_stream); }
+
+// ---------------------------------------------------------------------------------
+// F: one workgroup (4 waves) per (stream, window)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_lb_forward(const ConvLbArgs A)
+{
+    ohs_set_fp_mode(A.fp_mode);
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *X = smem + kTabComplex;
+    const int tid = threadIdx.x;
+    fill_twiddle_tables(tab, A.tw, tid, 256);
+    size_t s;
+    int w;
+    if (!lb_job(A.n_fwd, A.n_streams, s, w)) return;
+    const int u = A.u0 + w;
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+    // the window's four quarters, four consecutive frames per thread and quarter: z[n2][e] = window sample 4 tid + e + 1024 n2
+    float2 z[4][4];
+    {
+        const float *in_l = A.in + s * A.in_stream_stride, *in_r = in_l + A.in_ch_stride;
+        const float *xh_l = A.xhist ? A.xhist + s * 2 * A.xh_len : nullptr, *xh_r = xh_l ? xh_l + A.xh_len : nullptr;
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {
+            // (wave-uniform source choice: a quarter never straddles the segment's start or end -- both are multiples of 512
+            // and a quarter of 1024 frames is cut at 4 tid, inside one 512-frame block)
+            long long f0;
+            bool zero = false;
+            if (A.tables_mode) { f0 = (long long)u * kLbBlock + 1024 * n2; zero = n2 >= 2; }
+            else f0 = ((long long)u - 1) * kLbBlock + 1024 * n2;
+            f0 += 4 * tid;
+            lb_v4f l = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
+            if (!zero) {
+                if (f0 >= 0) {
+                    if (f0 < A.n_frames) {
+                        l = *reinterpret_cast<const lb_v4f *>(in_l + f0);
+                        r = *reinterpret_cast<const lb_v4f *>(in_r + f0);
+                    }
+                } else if (xh_l && A.xh_len + f0 >= 0) {
+                    l = *reinterpret_cast<const lb_v4f *>(xh_l + (A.xh_len + f0));
+                    r = *reinterpret_cast<const lb_v4f *>(xh_r + (A.xh_len + f0));
+                }
+            }
+            z[n2][0] = make_float2(l.x, r.x); z[n2][1] = make_float2(l.y, r.y);
+            z[n2][2] = make_float2(l.z, r.z); z[n2][3] = make_float2(l.w, r.w);
+        }
+    }
+    // radix-4 over the quarters, then w4096^(n1 c): class c of sample n1 = 4 tid + e
+    lb_v4f tw[3][2];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        const lb_v4f *t4 = reinterpret_cast<const lb_v4f *>(A.tw4096 + cc * 1024) + 2 * tid;
+        tw[cc][0] = t4[0]; tw[cc][1] = t4[1];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        dft4<false>(z[0][e], z[1][e], z[2][e], z[3][e]);
+#pragma unroll
+        for (int cc = 1; cc < 4; ++cc) {
+            const lb_v4f t = tw[cc - 1][e >> 1];
+            const float2 wv = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
+            z[cc][e] = cmul(z[cc][e], wv);
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds_st(&X[kLbSlab * cc + 264 * e + tid], z[cc][e]);      // X14: lb_x14(cc, 4 tid + e)
+    __syncthreads();
+
+    // wave c: the 1024-point transform of class c (time layout: lane m, register a holds sample 64 a + m)
+    float2 *slab = X + kLbSlab * c;
+    float2 v[16];
+    {
+        const int base = 264 * (lane & 3) + (lane >> 2);            // lb_x14(c, 64 a + lane) = slab + base + 16 a
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = lds_ld(&slab[base + 16 * a]);
+        wave_lds_sync();
+    }
+    wave_fft_fwd(v, slab, tab, lane);           // bin layout: register 4 r + j holds k1 = 4 lane + j + 256 r, i.e. bin 4 k1 + c
+    __syncthreads();                            // every wave is done with its slab: the slabs become the X23 image
+#pragma unroll
+    for (int R = 0; R < 16; ++R) {
+        const int k = 16 * lane + 4 * (R & 3) + c + 1024 * (R >> 2);
+        lds_st(&X[lb_x23(k)], v[R]);
+    }
+    __syncthreads();
+    // pairs out: slot q = tid + 256 p
+    const long long sl = (A.ring_base + u) % A.ring_cap;
+    float4 *dst = A.ring + (s * (size_t)A.ring_cap + (size_t)sl) * kLbPairs;
+    const int xb = 17 * (tid >> 4) + (tid & 15);                    // lb_x23(tid + 256 p) = xb + 272 p (+ plane)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float2 a = lds_ld(&X[xb + 272 * p]), b = lds_ld(&X[kLbPlane + xb + 272 * p]);
+        dst[tid + 256 * p] = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// MI: one workgroup per (stream, tile of kLbTile output blocks): pair products in registers, then the inverse transforms
+// ---------------------------------------------------------------------------------
+// acc += z c + conj(m) d on (re, im) register pairs: four v_pk_fma_f32 (conv_mac_kernels.hip explains the modifiers)
+__device__ __forceinline__ void lb_cmac(lb_v2f &acc, lb_v2f z, lb_v2f c, lb_v2f m, lb_v2f d)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(z), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(z), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(m), "v"(d));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(acc) : "v"(m), "v"(d));
+}
+
+template <int PI>       // partitions per register window: 8 (P2pad a multiple of 8) or 4
+__global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs A)
+{
+    ohs_set_fp_mode(A.fp_mode);
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *X = smem + kTabComplex;
+    const int tid = threadIdx.x;
+    fill_twiddle_tables(tab, A.tw, tid, 256);
+    const int tiles = (A.n_big + kLbTile - 1) / kLbTile;
+    size_t s;
+    int tile;
+    if (!lb_job(tiles, A.n_streams, s, tile)) return;
+    const int tb0 = tile * kLbTile;
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+    // ---- pair products: thread = 8 pairs (q = tid + 256 p) x 4 output blocks -------------------------------------
+    lb_v2f acc[8][kLbTile][2];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int t = 0; t < kLbTile; ++t) { acc[p][t][0] = (lb_v2f){0.f, 0.f}; acc[p][t][1] = (lb_v2f){0.f, 0.f}; }
+    const lb_v4f *ring = reinterpret_cast<const lb_v4f *>(A.ring) + s * (size_t)A.ring_cap * kLbPairs + tid;
+    const lb_v4f *cd = reinterpret_cast<const lb_v4f *>(A.cd) + tid;
+    const bool special = tid == 0;              // pair slot 0 holds bins 0 and 2048, each its own mirror
+    for (int i0 = 0; i0 < A.P2pad; i0 += PI) {
+        // window of blocks t - i, t in [0, 4), i in [i0, i0 + PI): w = t - (i - i0) + PI - 1 in [0, PI + 3)
+        int slot0 = (int)((A.ring_base + tb0 - i0 - (PI - 1)) % A.ring_cap);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            lb_v4f zw[PI + kLbTile - 1], ca[PI], cb[PI];
+            int sl = slot0;
+#pragma unroll
+            for (int w = 0; w < PI + kLbTile - 1; ++w) {
+                zw[w] = ring[(size_t)sl * kLbPairs + 256 * p];
+                sl = sl + 1 == A.ring_cap ? 0 : sl + 1;
+            }
+#pragma unroll
+            for (int ii = 0; ii < PI; ++ii) {
+                ca[ii] = cd[((size_t)(i0 + ii) * 2 + 0) * kLbPairs + 256 * p];
+                cb[ii] = cd[((size_t)(i0 + ii) * 2 + 1) * kLbPairs + 256 * p];
+            }
+#pragma unroll
+            for (int ii = 0; ii < PI; ++ii)
+#pragma unroll
+                for (int t = 0; t < kLbTile; ++t) {
+                    const lb_v4f zz = zw[t - ii + PI - 1];
+                    const lb_v2f za = zz.lo, zb = zz.hi;
+                    lb_v2f ma = zb, mb = za;
+                    if (p == 0) { ma = special ? za : zb; mb = special ? zb : za; }
+                    lb_cmac(acc[p][t][0], za, ca[ii].lo, ma, ca[ii].hi);
+                    lb_cmac(acc[p][t][1], zb, cb[ii].lo, mb, cb[ii].hi);
+                }
+        }
+    }
+    __syncthreads();            // (the twiddle tables are in place)
+
+    // ---- per output block: X23 -> four 1024-point inverse transforms -> X14 -> radix-4, second half only -> out --------
+    float2 *slab = X + kLbSlab * c;
+    const int xb = 17 * (tid >> 4) + (tid & 15);
+    float *out_l = A.out + s * A.out_stream_stride, *out_r = out_l + A.out_ch_stride;
+    lb_v4f tw[3][2];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+        const lb_v4f *t4 = reinterpret_cast<const lb_v4f *>(A.tw4096 + cc * 1024) + 2 * tid;
+        tw[cc][0] = t4[0]; tw[cc][1] = t4[1];
+    }
+#pragma unroll
+    for (int t = 0; t < kLbTile; ++t) {
+        if (tb0 + t >= A.n_big) break;          // (uniform over the workgroup)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            lds_st(&X[xb + 272 * p], make_float2(acc[p][t][0].x, acc[p][t][0].y));
+            lds_st(&X[kLbPlane + xb + 272 * p], make_float2(acc[p][t][1].x, acc[p][t][1].y));
+        }
+        __syncthreads();
+        float2 v[16];
+#pragma unroll
+        for (int R = 0; R < 16; ++R) {
+            const int k = 16 * lane + 4 * (R & 3) + c + 1024 * (R >> 2);
+            v[R] = lds_ld(&X[lb_x23(k)]);
+        }
+        __syncthreads();        // every wave has its bins: the slabs are transform scratch again
+        wave_fft_inv(v, slab, tab, lane);       // time layout: register a holds y_c[64 a + lane]
+        {
+            const int base = 264 * (lane & 3) + (lane >> 2);
+#pragma unroll
+            for (int a = 0; a < 16; ++a) lds_st(&slab[base + 16 * a], v[a]);
+        }
+        __syncthreads();
+        lb_v4f ol[2], orr[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float2 y[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) y[cc] = lds_ld(&X[kLbSlab * cc + 264 * e + tid]);
+#pragma unroll
+            for (int cc = 1; cc < 4; ++cc) {
+                const lb_v4f tt = tw[cc - 1][e >> 1];
+                const float2 wv = (e & 1) ? make_float2(tt.z, tt.w) : make_float2(tt.x, tt.y);
+                y[cc] = cmulc(y[cc], wv);
+            }
+            // n2 = 2: y0 - y1 + y2 - y3 ; n2 = 3: y0 - j y1 - y2 + j y3
+            const float2 s02 = cadd(y[0], y[2]), d02 = csub(y[0], y[2]), s13 = cadd(y[1], y[3]), d13 = csub(y[1], y[3]);
+            const float2 x2 = csub(s02, s13);
+            const float2 x3 = make_float2(d02.x + d13.y, d02.y - d13.x);
+            ol[0][e] = x2.x * A.gain; orr[0][e] = x2.y * A.gain;
+            ol[1][e] = x3.x * A.gain; orr[1][e] = x3.y * A.gain;
+        }
+        const long long f0 = ((long long)tb0 + t) * kLbBlock + 4 * tid;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long f = f0 + 1024 * h;
+            if (f < A.n_frames) {
+                *reinterpret_cast<lb_v4f *>(out_l + f) = ol[h];
+                *reinterpret_cast<lb_v4f *>(out_r + f) = orr[h];
+            }
+        }
+        __syncthreads();        // X14 has been read: the next block's X23 image may be written
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// tables, state
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_lb_build_cd(const float4 *__restrict__ ab, int P2pad, float4 *__restrict__ cd)
+{
+    const int i = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    const float4 a = ab[((size_t)0 * P2pad + i) * kLbPairs + q], b = ab[((size_t)1 * P2pad + i) * kLbPairs + q];
+    const float h = 0.5f / (float)kLbFft;       // the 1/2 of C, D and the 1/N of the inverse transform (powers of two)
+    // C = (A - jB)/2, D = (A + jB)/2 per component (k_build_cd_multi does the same for the 1024-point spectra)
+    cd[((size_t)i * 2 + 0) * kLbPairs + q] = make_float4(h * (a.x + b.y), h * (a.y - b.x), h * (a.x - b.y), h * (a.y + b.x));
+    cd[((size_t)i * 2 + 1) * kLbPairs + q] = make_float4(h * (a.z + b.w), h * (a.w - b.z), h * (a.z - b.w), h * (a.w + b.z));
+}
+
+__global__ __launch_bounds__(256) void k_conv_lb_xhist_update(const float *__restrict__ old, const float *__restrict__ in,
+                                                              long long in_ss, long long in_cs, float *__restrict__ dst,
+                                                              long long len, long long n_frames, unsigned wgs_per_row)
+{
+    const long long j = 4 * ((long long)(blockIdx.x % wgs_per_row) * 256 + threadIdx.x);
+    if (j >= len) return;
+    const size_t row = blockIdx.x / wgs_per_row;    // stream * 2 + channel
+    const long long f = n_frames - len + j;         // frame of the call that lands at position j (len, n_frames: multiples of 512)
+    lb_v4f v;
+    if (f >= 0) v = *reinterpret_cast<const lb_v4f *>(in + (row >> 1) * in_ss + (row & 1) * in_cs + f);
+    else v = *reinterpret_cast<const lb_v4f *>(old + row * len + (len + f));
+    *reinterpret_cast<lb_v4f *>(dst + row * len + j) = v;
+}
+
+static hipError_t lb_allow_lds(const void *fn, std::atomic<unsigned long long> &done_mask)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLbLdsBytes);
+    if (e == hipSuccess) done_mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
+static bool lb_args_ok(const ConvLbArgs &a)
+{
+    if (a.n_streams <= 0 || a.ring_cap <= 0 || !a.ring || !a.tw || !a.tw4096) return false;
+    if ((a.in_stream_stride | a.in_ch_stride | a.out_stream_stride | a.out_ch_stride | a.xh_len) & 3) return false;
+    if ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.xhist)) & 15) return false;
+    if (a.n_frames < 0 || (a.n_frames & 511)) return false;
+    return true;
+}
+
+hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st)
+{
+    if (a.n_fwd <= 0) return hipSuccess;
+    if (!lb_args_ok(a) || !a.in || a.n_fwd > a.ring_cap || a.ring_base + a.u0 < 0) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> lds_ok{0};
+    const hipError_t e = lb_allow_lds(reinterpret_cast<const void *>(k_conv_lb_forward), lds_ok);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_conv_lb_forward, dim3(lb_grid(a.n_fwd, a.n_streams)), dim3(256), kLbLdsBytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st)
+{
+    if (a.n_big <= 0) return hipSuccess;
+    // the oldest window a tile reads is block 0's partition P2pad - 1; a tile's unused blocks read slots that alias others
+    if (!lb_args_ok(a) || !a.out || !a.cd || a.P2pad < 4 || (a.P2pad & 3) || a.n_big + a.P2pad - 1 > a.ring_cap ||
+        a.ring_base - (a.P2pad - 1) - 8 < 0)
+        return hipErrorInvalidValue;
+    const int tiles = (a.n_big + kLbTile - 1) / kLbTile;
+    const dim3 grid(lb_grid(tiles, a.n_streams));
+    if (a.P2pad % 8 == 0) {
+        static std::atomic<unsigned long long> lds_ok{0};
+        const hipError_t e = lb_allow_lds(reinterpret_cast<const void *>(k_conv_lb_mac_inverse<8>), lds_ok);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_conv_lb_mac_inverse<8>, grid, dim3(256), kLbLdsBytes, st, a);
+    } else {
+        static std::atomic<unsigned long long> lds_ok{0};
+        const hipError_t e = lb_allow_lds(reinterpret_cast<const void *>(k_conv_lb_mac_inverse<4>), lds_ok);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_conv_lb_mac_inverse<4>, grid, dim3(256), kLbLdsBytes, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_conv_lb_build_cd, dim3(kLbPairs / 256, P2pad), dim3(256), 0, st, ab, P2pad, cd);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_lb_xhist_update(const float *old, const float *in, long long in_ss, long long in_cs, float *dst,
+                                       long long len, long long n_frames, int n_streams, hipStream_t st)
+{
+    if (len <= 0 || (len & 511) || (n_frames & 511) || n_streams <= 0) return hipErrorInvalidValue;
+    if ((in_ss | in_cs) & 3 || (reinterpret_cast<uintptr_t>(in) & 15)) return hipErrorInvalidValue;
+    const unsigned long long wpr = (unsigned long long)((len / 4 + 255) / 256), wgs = wpr * 2ull * (unsigned long long)n_streams;
+    if (wgs > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv_lb_xhist_update, dim3((unsigned)wgs), dim3(256), 0, st, old, in, in_ss, in_cs, dst, len, n_frames,
+                       (unsigned)wpr);
+    return hipGetLastError();
+}
+
+}  // namespace ohs

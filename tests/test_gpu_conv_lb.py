@@ -1,0 +1,233 @@
+"""The block-2048 / FFT-4096 plan for long impulse responses (ohs_batch_set_conv_plan(2) with taps > 3584;
+csrc/conv_lb_kernels.hip) against the oracle -- the restatement of the reference's uniform block-512 partitioning
+(src/dsp/convolution.rs:120-132,236-289) -- and against f64 direct convolution: every remainder of the call length modulo
+the 2048-frame block, calls that continue the previous call's window grid and calls that do not, several segments per
+call, paths of different lengths and a muted one, in place, with the EQ in front, across calls that alternate between the
+plans (the block-512 state is rebuilt from the input history and back), across a per-path set_ir in mid-stream, and at
+BASELINE config 4's shape."""
+import numpy as np
+import pytest
+
+from tests.util import assert_parity, rms_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_engines(oracle, irs, S):
+    engs = []
+    for _ in range(S):
+        e = oracle.ConvolutionEngine()
+        for p in range(4):
+            e.set_ir(p, irs[p])
+        engs.append(e)
+    return engs
+
+
+def _make(ohs, S, irs, plan, gain=1.0):
+    bp = ohs.BatchProcessor(S, num_bands=10)
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    bp.set_eq_enabled(False)
+    bp.set_gain(gain)
+    bp.set_conv_plan(plan)
+    return bp
+
+
+@pytest.mark.parametrize("taps,blocks", [(16384, [9, 4, 7, 8, 8, 1, 2, 40]), (4097, [3, 5, 16, 16]), (3600, [6, 6, 12])])
+def test_block_2048_plan_matches_the_oracle_and_f64(oracle, taps, blocks):
+    """call lengths of every remainder modulo 4 blocks (a ragged last 2048-block is padded with zeros and the next call
+    starts a new window grid from the input history), aligned calls that continue the ring, in place"""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    S = 3
+    irs = synth.hrir_set(taps)
+    bp = _make(ohs, S, irs, 2, gain=0.9)
+    engs = _oracle_engines(oracle, irs, S)
+    total = sum(blocks) * 512
+    x = synth.white_noise(range(S), total)
+    got, pos = [], 0
+    for k, nb in enumerate(blocks):
+        xt = torch.from_numpy(np.ascontiguousarray(x[:, :, pos:pos + nb * 512])).cuda()
+        bp.process(xt, out=xt)          # in place
+        assert bp.last_conv_plan()[0] == "block2048", (k, bp.last_conv_plan())
+        got.append(xt.cpu().numpy())
+        pos += nb * 512
+    g = np.concatenate(got, axis=2)
+    for s in range(S):
+        ref = np.stack(engs[s].process_block(x[s, 0], x[s, 1])) * np.float32(0.9)
+        assert_parity(g[s], ref, f"taps {taps}, stream {s}")
+    yl, yr = oracle.binaural_f64(x[0, 0], x[0, 1], irs)
+    a, r = rms_err(g[0], 0.9 * np.stack([yl, yr]))
+    print(f"block-2048 plan vs f64 direct convolution, {taps} taps: {r:.2e}")
+    assert r <= 1e-6
+
+
+def test_paths_of_different_lengths_and_a_muted_path(oracle):
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    S = 2
+    full = synth.hrir_set(9000)
+    irs = [full[0], full[1][:5000], full[2][:700], np.zeros(0, np.float32)]
+    bp = _make(ohs, S, irs, 2)
+    engs = _oracle_engines(oracle, irs, S)
+    x = synth.white_noise(range(7, 7 + S), 2 * 44 * 512)
+    ys = []
+    for c in range(2):
+        xt = torch.from_numpy(np.ascontiguousarray(x[:, :, c * 44 * 512:(c + 1) * 44 * 512])).cuda()
+        ys.append(bp.process(xt).cpu().numpy())
+        assert bp.last_conv_plan()[0] == "block2048"
+    g = np.concatenate(ys, axis=2)
+    for s in range(S):
+        assert_parity(g[s], np.stack(engs[s].process_block(x[s, 0], x[s, 1])), f"mixed lengths, stream {s}")
+
+
+def test_several_segments_per_call(oracle):
+    """600 streams: segments of 8 blocks of 2048, so a 100-block call is four segments (the last one ragged); streams 0, 299
+    and 599 against the oracle, every stream against the stream it repeats"""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    dev = torch.device("cuda:0")
+    S, nb, taps = 600, 100, 4200
+    irs = synth.hrir_set(taps)
+    bp = _make(ohs, S, irs, 2)
+    base = synth.white_noise_torch(21, 3, 2 * nb * 512, dev)
+    x = base[torch.arange(S, device=dev) % 3].contiguous()
+    y = torch.cat([bp.process(x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()) for c in range(2)], dim=2)
+    torch.cuda.synchronize()
+    assert bp.last_conv_plan()[0] == "block2048"
+    for s in range(3, S):
+        assert torch.equal(y[s], y[s % 3]), f"stream {s} differs from stream {s % 3}"
+    engs = _oracle_engines(oracle, irs, 3)
+    xb = base.cpu().numpy()
+    for s in (0, 299, 599):
+        ref = np.stack(engs[s % 3].process_block(xb[s % 3, 0], xb[s % 3, 1]))
+        assert_parity(y[s].cpu().numpy(), ref, f"multi-segment, stream {s}")
+        engs[s % 3] = _oracle_engines(oracle, irs, 1)[0]
+
+
+def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
+    """One continuous signal through a sequence of calls under changing plans: block 2048 -> block 512 time-parallel ->
+    sequential kernel (2 blocks) -> block 2048 ..., with the EQ in front, and a per-path set_ir in mid-stream -- the call
+    right behind it is served by the block-512 kernels (that path must not see the frames before its reset,
+    convolution.rs:135-138), the one after by block 2048 again."""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    S, taps = 3, 8192
+    irs = synth.hrir_set(taps)
+    bands = synth.eq_table()
+    bp = ohs.BatchProcessor(S, num_bands=len(bands))
+    for p in range(4):
+        bp.set_ir(p, irs[p])
+    for i, b in enumerate(bands):
+        bp.update_band_coeffs(i, synth.FS, b)
+    bp.set_eq_enabled(True)
+    bp.set_gain(0.7)
+    engs = _oracle_engines(oracle, irs, S)
+    eqs = []
+    for s in range(S):
+        qo = oracle.StereoParametricEQ(len(bands), synth.FS)
+        for i, b in enumerate(bands):
+            qo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), b.enabled)
+        eqs.append(qo)
+    #      (plan, blocks, kernel family expected of the call's last launch)
+    seq = [(2, 20, "block2048"), (1, 24, "block512_tp"), (2, 8, "block2048"), (1, 2, "sequential"), (2, 16, "block2048"),
+           (2, 16, "block2048"),        # <- set_ir(path 2) in front of this one: served by block 512 (gated), see below
+           (2, 20, "block2048"), (0, 3, "sequential"), (0, 40, "block2048")]
+    for k, (plan, nb, want) in enumerate(seq):
+        if k == 5:
+            h = synth.hrir_set(6000)[2]
+            bp.set_ir(2, h)
+            for e in engs:
+                e.set_ir(2, h)
+            want = "block512_tp"
+        bp.set_conv_plan(plan)
+        x = synth.white_noise(range(10 * k, 10 * k + S), nb * 512)
+        y = bp.process(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert bp.last_conv_plan()[0] == want, (k, bp.last_conv_plan(), want)
+        for s in range(S):
+            l, r = x[s, 0].copy(), x[s, 1].copy()
+            oracle.chain_process(engs[s], eqs[s], l, r, eq_enable=True, gain=0.7)
+            assert_parity(y[s], np.stack([l, r]), f"call {k} (plan {plan}, {nb} blocks), stream {s}")
+
+
+def test_reset_and_a_set_ir_of_all_paths_forget_the_input_history(oracle):
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    S, taps = 2, 5000
+    irs = synth.hrir_set(taps)
+    bp = _make(ohs, S, irs, 2)
+    x = synth.white_noise(range(S), 24 * 512)
+    xt = torch.from_numpy(x).cuda()
+    y0 = bp.process(xt).cpu().numpy()
+    bp.reset()
+    y1 = bp.process(xt).cpu().numpy()           # the same frames from zeroed state: the same bits
+    assert np.array_equal(y0.view(np.int32), y1.view(np.int32))
+    for p in range(4):                          # every path re-loaded: each forgets its past (convolution.rs:135-138)
+        bp.set_ir(p, irs[p])
+    y2 = bp.process(xt).cpu().numpy()
+    assert bp.last_conv_plan()[0] == "block2048"
+    engs = _oracle_engines(oracle, irs, S)
+    for s in range(S):
+        ref = np.stack(engs[s].process_block(x[s, 0], x[s, 1]))
+        assert_parity(y2[s], ref, f"after set_ir of all paths, stream {s}")
+        assert_parity(y0[s], ref, f"first run, stream {s}")
+
+
+def test_the_library_picks_block_2048_for_long_calls_on_long_responses():
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    dev = torch.device("cuda:0")
+    for taps, nb, want in ((16384, 64, "block2048"), (16384, 12, "block512_tp"), (16384, 2, "sequential"),
+                           (3000, 64, "block512_tp"), (4096, 16, "block2048")):
+        bp = _make(ohs, 4, synth.hrir_set(taps), 0)
+        x = synth.white_noise_torch(3, 4, nb * 512, dev)
+        bp.process(x)
+        torch.cuda.synchronize()
+        assert bp.last_conv_plan()[0] == want, (taps, nb, bp.last_conv_plan())
+    # unaligned buffers / strides that are not multiples of 4 floats: served by the block-512 kernels, same signal
+    bp = _make(ohs, 2, synth.hrir_set(8192), 2)
+    ref = _make(ohs, 2, synth.hrir_set(8192), 1)
+    n = 32 * 512
+    buf = torch.zeros(2 * 2 * (n + 1) + 1, device=dev)
+    src = synth.white_noise_torch(5, 2, n, dev)
+    view = buf[1:1 + 2 * 2 * (n + 1)].view(2, 2, n + 1)[:, :, :n]
+    view.copy_(src)
+    out = torch.empty_like(buf)
+    bp.process_ptr(view.data_ptr(), out[1:].data_ptr(), n // 512, 2 * (n + 1), n + 1,
+                   torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert bp.last_conv_plan()[0] == "block512_tp"
+    y = out[1:1 + 2 * 2 * (n + 1)].view(2, 2, n + 1)[:, :, :n]
+    assert torch.equal(y.contiguous().view(torch.int32), ref.process(src).view(torch.int32))
+
+
+def test_config4_shape_both_plans(oracle):
+    """BASELINE config 4: 64 streams, 4 x 16 384 taps, 256-block calls: the block-2048 plan against the block-512 plan on all
+    streams and against the oracle on three, over two calls (the second one continues the first one's window grid)"""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    dev = torch.device("cuda:0")
+    S, nb, taps = 64, 256, 16384
+    irs = synth.hrir_set(taps)
+    a, b = _make(ohs, S, irs, 1), _make(ohs, S, irs, 2)
+    x = synth.white_noise_torch(50, S, 2 * nb * 512, dev)
+    ya = torch.cat([a.process(x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()) for c in range(2)], dim=2)
+    yb = torch.cat([b.process(x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()) for c in range(2)], dim=2)
+    torch.cuda.synchronize()
+    assert a.last_conv_plan()[0] == "block512_tp" and b.last_conv_plan() == ("block2048", 16)
+    d = (ya - yb).double()
+    per_stream = torch.sqrt((d * d).mean(dim=(1, 2))) / torch.sqrt((ya.double() ** 2).mean(dim=(1, 2)))
+    print(f"block 2048 vs block 512 at config 4: worst stream {float(per_stream.max()):.2e}")
+    assert float(per_stream.max()) <= 1e-6
+    xs = x.cpu().numpy()
+    for s in (0, 31, 63):
+        e = _oracle_engines(oracle, irs, 1)[0]
+        ref = np.stack(e.process_block(xs[s, 0], xs[s, 1]))
+        assert_parity(yb[s].cpu().numpy(), ref, f"config 4, block 2048, stream {s}")
