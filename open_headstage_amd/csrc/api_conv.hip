@@ -274,6 +274,9 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     ConvLbArgs a;
     std::memset(&a, 0, sizeof(a));
     a.tw = ctx->d_tw; a.tw4096 = ctx->d_tw4096; a.fp_mode = c.fp_mode; a.P2pad = P2pad;
+#ifdef OHS_EXPERIMENTS
+    a.debug_skip = tuning().lb_skip;
+#endif
     if (!c.lb_cd_valid) {
         if (c.irl_len < (long long)P2pad * kLbBlock) return fail(OHS_ERR_HIP, "block-2048 plan: impulse responses not stored");
         ConvLbArgs t = a;

@@ -36,6 +36,7 @@ namespace ohs {
 
 typedef float lb_v2f __attribute__((ext_vector_type(2)));
 typedef float lb_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned lb_v4u __attribute__((ext_vector_type(4)));
 
 constexpr int kLbFft = 4096;
 constexpr int kLbPairs = 2048;
@@ -205,41 +206,74 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
     for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int t = 0; t < kLbTile; ++t) { acc[p][t][0] = (lb_v2f){0.f, 0.f}; acc[p][t][1] = (lb_v2f){0.f, 0.f}; }
-    const lb_v4f *ring = reinterpret_cast<const lb_v4f *>(A.ring) + s * (size_t)A.ring_cap * kLbPairs + tid;
-    const lb_v4f *cd = reinterpret_cast<const lb_v4f *>(A.cd) + tid;
+    // Operands come through buffer loads: one resource for the stream's ring, one for the tables of the partition window,
+    // the thread's 16 bytes at voffset = 16 tid, everything else -- ring slot, pair group p, partition -- in the SCALAR
+    // offset.  (With flat pointers hipcc kept a 64-bit address pair per window slot and table row alive: ~50 VGPRs, and
+    // with 128 accumulators that left it two loads in flight at a time.)
+    const int voff = tid * 16;
+    const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4 *>(A.ring) + s * (size_t)A.ring_cap * kLbPairs, 0, A.ring_cap * (kLbPairs * 16), 0x00020000);
     const bool special = tid == 0;              // pair slot 0 holds bins 0 and 2048, each its own mirror
-    for (int i0 = 0; i0 < A.P2pad; i0 += PI) {
+#ifdef OHS_EXPERIMENTS
+    const int dskip = A.debug_skip;
+#else
+    constexpr int dskip = 0;
+#endif
+    for (int i0 = 0; i0 < ((dskip & 1) ? 0 : A.P2pad); i0 += PI) {
+        const __amdgpu_buffer_rsrc_t r_cd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float4 *>(A.cd) + (size_t)i0 * 2 * kLbPairs, 0, PI * 2 * (kLbPairs * 16), 0x00020000);
         // window of blocks t - i, t in [0, 4), i in [i0, i0 + PI): w = t - (i - i0) + PI - 1 in [0, PI + 3)
-        int slot0 = (int)((A.ring_base + tb0 - i0 - (PI - 1)) % A.ring_cap);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            lb_v4f zw[PI + kLbTile - 1], ca[PI], cb[PI];
-            int sl = slot0;
+        int so[PI + kLbTile - 1];
+        {
+            int sl = (int)((A.ring_base + tb0 - i0 - (PI - 1)) % A.ring_cap);
 #pragma unroll
             for (int w = 0; w < PI + kLbTile - 1; ++w) {
-                zw[w] = ring[(size_t)sl * kLbPairs + 256 * p];
+                so[w] = __builtin_amdgcn_readfirstlane(sl * (kLbPairs * 16));
                 sl = sl + 1 == A.ring_cap ? 0 : sl + 1;
             }
+        }
 #pragma unroll
-            for (int ii = 0; ii < PI; ++ii) {
-                ca[ii] = cd[((size_t)(i0 + ii) * 2 + 0) * kLbPairs + 256 * p];
-                cb[ii] = cd[((size_t)(i0 + ii) * 2 + 1) * kLbPairs + 256 * p];
-            }
+        for (int p = 0; p < 8; ++p) {
+            // all 11 + 16 loads of the pair group at once, then the 256 products
+            lb_v4f zw[PI + kLbTile - 1], cc[2][PI];
 #pragma unroll
-            for (int ii = 0; ii < PI; ++ii)
+            for (int w = 0; w < PI + kLbTile - 1; ++w)
+                zw[w] = __builtin_bit_cast(lb_v4f, __builtin_amdgcn_raw_buffer_load_b128(r_ring, (dskip & 4) ? 0x7ffffff0 : voff,
+                                                                                         so[w] + p * 4096, 0));
 #pragma unroll
-                for (int t = 0; t < kLbTile; ++t) {
-                    const lb_v4f zz = zw[t - ii + PI - 1];
-                    const lb_v2f za = zz.lo, zb = zz.hi;
-                    lb_v2f ma = zb, mb = za;
-                    if (p == 0) { ma = special ? za : zb; mb = special ? zb : za; }
-                    lb_cmac(acc[p][t][0], za, ca[ii].lo, ma, ca[ii].hi);
-                    lb_cmac(acc[p][t][1], zb, cb[ii].lo, mb, cb[ii].hi);
-                }
+            for (int comp = 0; comp < 2; ++comp)
+#pragma unroll
+                for (int ii = 0; ii < PI; ++ii)
+                    cc[comp][ii] = __builtin_bit_cast(lb_v4f, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                  r_cd, (dskip & 8) ? 0x7ffffff0 : voff,
+                                                                  (ii * 2 + comp) * (kLbPairs * 16) + p * 4096, 0));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int comp = 0; comp < 2; ++comp)
+#pragma unroll
+                for (int ii = 0; ii < PI; ++ii)
+#pragma unroll
+                    for (int t = 0; t < kLbTile; ++t) {
+                        const lb_v4f zz = zw[t - ii + PI - 1];
+                        lb_v2f z = comp ? zz.hi : zz.lo, m = comp ? zz.lo : zz.hi;
+                        if (p == 0) m = special ? z : m;
+                        lb_cmac(acc[p][t][comp], z, cc[comp][ii].lo, m, cc[comp][ii].hi);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();            // (the twiddle tables are in place)
 
+#ifdef OHS_EXPERIMENTS
+    if (dskip & 2) {    // (keep the products alive: one sum per thread)
+        lb_v2f sum = {0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int t = 0; t < kLbTile; ++t) sum += acc[p][t][0] + acc[p][t][1];
+        if (sum.x == 12345.678f) A.out[s * A.out_stream_stride + tid] = sum.y;
+    }
+#endif
     // ---- per output block: X23 -> four 1024-point inverse transforms -> X14 -> radix-4, second half only -> out --------
     float2 *slab = X + kLbSlab * c;
     const int xb = 17 * (tid >> 4) + (tid & 15);
@@ -252,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
     }
 #pragma unroll
     for (int t = 0; t < kLbTile; ++t) {
-        if (tb0 + t >= A.n_big) break;          // (uniform over the workgroup)
+        if (tb0 + t >= A.n_big || (dskip & 2)) break;          // (uniform over the workgroup)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             lds_st(&X[xb + 272 * p], make_float2(acc[p][t][0].x, acc[p][t][0].y));

@@ -288,6 +288,7 @@ struct ConvLbArgs {
     float gain;
     int fp_mode;
     int tables_mode;            // F: 1 = window i is [block i of `in`, 2048 zeros] (impulse-response partitions)
+    int debug_skip;             // experiments build only (Tuning::lb_skip): timing knock-outs, wrong results; 0 in the product
 };
 hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st);
 hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st);

@@ -130,6 +130,7 @@ bool tuning_set(const std::string &key, const std::string &value)
         return true;
     }
     if (key == "mac_no_xcd") return one(&t.mac_no_xcd);
+    if (key == "lb_skip") return one(&t.lb_skip);
     if (key == "host_pipe_trace") return one(&t.host_pipe_trace);
     if (key == "host_pipe_flat_priorities") return one(&t.host_pipe_flat_priorities);
     if (key == "node_shared_device_rehearsal") return one(&t.node_shared_device_rehearsal);

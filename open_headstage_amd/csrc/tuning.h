@@ -36,6 +36,8 @@ struct Tuning {
     std::vector<double> overlap_cuts = {0.0, 0.25, 0.5, 0.75, 0.92, 0.98, 1.0};
     std::vector<unsigned> conv_cu_mask;     // non-empty: the overlapped convolution's stream gets this CU mask
     int mac_no_xcd = 0;                     // plain stream-major workgroup order in k_conv_tp_mac
+    int lb_skip = 0;                        // k_conv_lb_mac_inverse timing knock-outs (WRONG results; experiments build only): 1 = no
+                                            // products, 2 = no inverse transforms, 4 = no ring loads, 8 = no table loads
     // ohs_batch_process_host
     int host_pipe_trace = 0, host_pipe_flat_priorities = 0;
     // ohs_node_batch_create (experiments build only): several device slots may name the SAME device -- a rehearsal of the

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--plans", type=str, default="1,2,0")
+    ap.add_argument("--tune", type=str, default="", help="experiments library, key=value[,key=value...] (e.g. lb_skip=2)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     S, n = a.streams, a.blocks * 512
@@ -29,8 +30,15 @@ def main():
     x = synth.white_noise_torch(0, S, n, dev)
     y = torch.empty_like(x)
     st = torch.cuda.current_stream(dev)
+    library = None
+    if a.tune:
+        from open_headstage_amd import _ffi
+        library = _ffi.experiments_lib()
+        for kv in a.tune.split(","):
+            k, v = kv.split("=")
+            _ffi.set_tuning(k, v)
     for plan in [int(v) for v in a.plans.split(",")]:
-        bp = ohs.BatchProcessor(S, num_bands=10)
+        bp = ohs.BatchProcessor(S, num_bands=10, library=library)
         for p in range(4):
             bp.set_ir(p, irs[p])
         bp.set_eq_enabled(False)
@@ -50,7 +58,7 @@ def main():
         med = ts[len(ts) // 2]
         kern, ranges = bp.last_conv_plan()
         _, cb = bp.kernel_bytes(a.blocks)
-        print(json.dumps({"streams": S, "taps": a.taps, "blocks": a.blocks, "plan": plan, "kernel": kern, "ranges": ranges,
+        print(json.dumps({"tune": a.tune, "streams": S, "taps": a.taps, "blocks": a.blocks, "plan": plan, "kernel": kern, "ranges": ranges,
                           "ms_median": round(med, 4), "ms_min": round(ts[0], 4), "ms_max": round(ts[-1], 4),
                           "Gsamples_per_s": round(S * n / med / 1e6, 2), "design_bytes_MB": round(cb / 1e6, 1),
                           "design_TBps": round(cb / med / 1e9, 3)}), flush=True)
