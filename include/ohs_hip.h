@@ -310,6 +310,23 @@ int  ohs_batch_set_eq_band_coeffs(ohs_batch *b, size_t band, const float coeffs[
 /* convenience (coefficients by ohs_biquad_coeffs: not a parity path, see there) */
 int  ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_type, float fc,
                               float q, float gain_db, int enabled);
+/* Per-stream EQ tables.  In the reference every plugin instance owns its bands (parametric_eq.rs:125-129, lib.rs:316-324:
+ * StereoParametricEQ::update_band_coeffs acts on that instance alone); an offline job of N listeners with N AutoEQ profiles
+ * (ohs_autoeq_*) is N instances.  ohs_batch_set_stream_eq_band_coeffs gives stream `stream` (0 .. n_streams - 1) its own
+ * band `band`: update_band_coeffs semantics for that stream -- coefficients and enable flag replaced, its state kept
+ * (parametric_eq.rs:144-164), band >= num_bands ignored.  The first such call gives every stream a copy of the shared
+ * table; from then on ohs_batch_set_eq_band_coeffs / _update_eq_band set the band of EVERY stream, and
+ * ohs_batch_share_eq_table goes back to the one shared table (the values the shared calls have set).  All streams run in one
+ * launch (each row of the EQ kernel reads its own stream's table when its wave starts; streams may enable different
+ * bands and different NUMBERS of bands) as long as no stream enables more than 12 bands and the exact-specials mode is off;
+ * otherwise every stream is a launch sequence of its own -- correct for any table, slow for many streams.  The tables are
+ * uploaded by the first processing call after an edit, which waits for the work queued on its stream (not for the audio
+ * thread; bit-exact against one StereoParametricEQ per stream either way). */
+int  ohs_batch_set_stream_eq_band_coeffs(ohs_batch *b, size_t stream, size_t band, const float coeffs[5], int enabled);
+/* convenience (coefficients by ohs_biquad_coeffs: not a parity path, see there) */
+int  ohs_batch_update_stream_eq_band(ohs_batch *b, size_t stream, size_t band, float fs, int filter_type, float fc,
+                                     float q, float gain_db, int enabled);
+int  ohs_batch_share_eq_table(ohs_batch *b);
 /* eq_enable / output gain of lib.rs:1179,1202 */
 int  ohs_batch_set_eq_enabled(ohs_batch *b, int eq_enable);
 int  ohs_batch_set_eq_exact_specials(ohs_batch *b, int enable);    /* see ohs_eq_set_exact_specials */
@@ -426,6 +443,11 @@ int  ohs_node_batch_set_speakers(ohs_node_batch *nb, const ohs_sofa *sofa, float
                                  float radius_m, float fs, unsigned *changed_mask);
 /* host-side settings, applied to every device's handle (no device traffic: kernel arguments) */
 int  ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const float coeffs[5], int enabled);
+/* one stream's own band (ohs_batch_set_stream_eq_band_coeffs): `stream` is the job's stream id, 0 .. streams_total - 1; it
+ * is host-side state of the one device handle that holds the stream -- no broadcast */
+int  ohs_node_batch_set_stream_eq_band_coeffs(ohs_node_batch *nb, size_t stream, size_t band, const float coeffs[5],
+                                              int enabled);
+int  ohs_node_batch_share_eq_table(ohs_node_batch *nb);
 int  ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable);
 int  ohs_node_batch_set_gain(ohs_node_batch *nb, float gain);
 int  ohs_node_batch_set_conv_plan(ohs_node_batch *nb, int plan);       /* see ohs_batch_set_conv_plan */

@@ -110,6 +110,12 @@ PROTOTYPES = {
     "ohs_batch_set_eq_band_coeffs": (C.c_int, [vp, C.c_size_t, fp, C.c_int]),
     "ohs_batch_update_eq_band": (C.c_int, [vp, C.c_size_t, C.c_float, C.c_int, C.c_float, C.c_float,
                                            C.c_float, C.c_int]),
+    "ohs_batch_set_stream_eq_band_coeffs": (C.c_int, [vp, C.c_size_t, C.c_size_t, fp, C.c_int]),
+    "ohs_batch_update_stream_eq_band": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_float, C.c_float,
+                                                  C.c_float, C.c_int]),
+    "ohs_batch_share_eq_table": (C.c_int, [vp]),
+    "ohs_node_batch_set_stream_eq_band_coeffs": (C.c_int, [vp, C.c_size_t, C.c_size_t, fp, C.c_int]),
+    "ohs_node_batch_share_eq_table": (C.c_int, [vp]),
     "ohs_batch_set_eq_enabled": (C.c_int, [vp, C.c_int]),
     "ohs_batch_set_gain": (C.c_int, [vp, C.c_float]),
     "ohs_batch_set_conv_plan": (C.c_int, [vp, C.c_int]),

@@ -60,6 +60,23 @@ class BatchProcessor:
         self._check(self._lib.ohs_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp),
                                                  int(bool(enabled))))
 
+    def set_stream_band_coeffs(self, stream: int, band_idx: int, coeffs, enabled: bool) -> None:
+        """stream `stream`'s own band (every plugin instance of the reference owns its bands, parametric_eq.rs:125-129)"""
+        c = np.ascontiguousarray(coeffs, dtype=np.float32).ravel()
+        if c.size != 5:
+            raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
+        self._check(self._lib.ohs_batch_set_stream_eq_band_coeffs(self._h, int(stream), int(band_idx), c.ctypes.data_as(fp),
+                                                                  int(bool(enabled))))
+
+    def update_stream_band_coeffs(self, stream: int, band_idx: int, sample_rate: float, config: BandConfig) -> None:
+        self._check(self._lib.ohs_batch_update_stream_eq_band(self._h, int(stream), int(band_idx), sample_rate,
+                                                              int(config.filter_type), config.center_freq, config.q,
+                                                              config.gain_db, int(bool(config.enabled))))
+
+    def share_eq_table(self) -> None:
+        """back to the one shared EQ table (ohs_batch_share_eq_table)"""
+        self._check(self._lib.ohs_batch_share_eq_table(self._h))
+
     def set_eq_enabled(self, eq_enable: bool) -> None:
         self._check(self._lib.ohs_batch_set_eq_enabled(self._h, int(bool(eq_enable))))
 
@@ -256,6 +273,17 @@ class NodeBatchProcessor:
         if c.size != 5:
             raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
         self._check(self._lib.ohs_node_batch_set_eq_band_coeffs(self._h, int(band_idx), c.ctypes.data_as(fp), int(bool(enabled))))
+
+    def set_stream_band_coeffs(self, stream: int, band_idx: int, coeffs, enabled: bool) -> None:
+        """`stream` is the job's stream id (ohs_node_batch_set_stream_eq_band_coeffs)"""
+        c = np.ascontiguousarray(coeffs, dtype=np.float32).ravel()
+        if c.size != 5:
+            raise ValueError("coeffs must be [b0, b1, b2, a1, a2]")
+        self._check(self._lib.ohs_node_batch_set_stream_eq_band_coeffs(self._h, int(stream), int(band_idx),
+                                                                       c.ctypes.data_as(fp), int(bool(enabled))))
+
+    def share_eq_table(self) -> None:
+        self._check(self._lib.ohs_node_batch_share_eq_table(self._h))
 
     def set_eq_enabled(self, eq_enable: bool) -> None:
         self._check(self._lib.ohs_node_batch_set_eq_enabled(self._h, int(bool(eq_enable))))

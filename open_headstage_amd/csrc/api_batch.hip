@@ -70,7 +70,7 @@ void ohs_batch_destroy(ohs_batch *b)
     DeviceWideSection dws;
     hipDeviceSynchronize();
     conv_free(b->conv);
-    if (b->eq.d_state) hipFree(b->eq.d_state);
+    eq_free(b->eq);
     for (auto &sp : b->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t e : b->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : b->ev_inflight) hipEventDestroy(e);
@@ -112,8 +112,32 @@ int ohs_batch_set_eq_band_coeffs(ohs_batch *b, size_t band, const float coeffs[5
 {
     if (!b || !coeffs) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
     if (band >= b->eq.nb) return OHS_OK;
-    std::memcpy(&b->eq.coeffs[5 * band], coeffs, 5 * sizeof(float));
-    b->eq.en[band] = enabled != 0;
+    eq_set_shared_band(b->eq, band, coeffs, enabled);
+    return OHS_OK;
+}
+
+int ohs_batch_set_stream_eq_band_coeffs(ohs_batch *b, size_t stream, size_t band, const float coeffs[5], int enabled)
+{
+    if (!b || !coeffs) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    return eq_set_stream_band(b->eq, stream, band, coeffs, enabled);
+}
+
+int ohs_batch_update_stream_eq_band(ohs_batch *b, size_t stream, size_t band, float fs, int filter_type, float fc, float q,
+                                    float gain_db, int enabled)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    if (stream >= b->conv.S) return fail(OHS_ERR_INVALID_ARG, "stream index out of range");
+    if (band >= b->eq.nb) return OHS_OK;
+    float c[5];
+    int rc = rbj(filter_type, fs, fc, q, gain_db, c);
+    if (rc) return rc;
+    return eq_set_stream_band(b->eq, stream, band, c, enabled);
+}
+
+int ohs_batch_share_eq_table(ohs_batch *b)
+{
+    if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
+    eq_share_table(b->eq);
     return OHS_OK;
 }
 
@@ -125,8 +149,7 @@ int ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_typ
     float c[5];
     int rc = rbj(filter_type, fs, fc, q, gain_db, c);
     if (rc) return rc;
-    std::memcpy(&b->eq.coeffs[5 * band], c, sizeof(c));
-    b->eq.en[band] = enabled != 0;
+    eq_set_shared_band(b->eq, band, c, enabled);
     return OHS_OK;
 }
 
@@ -281,9 +304,7 @@ static int batch_process_body(ohs_batch *b, const float *d_in, float *d_out, siz
     };
     if (b->profiling) b->prof_calls++;
 
-    bool eq_active = false;
-    if (b->eq_enable)
-        for (size_t i = 0; i < b->eq.nb; ++i) eq_active = eq_active || b->eq.en[i];
+    const bool eq_active = b->eq_enable && eq_any_enabled(b->eq);
 
     const long long ss = (long long)stream_stride, cs = (long long)channel_stride;
     int rc;

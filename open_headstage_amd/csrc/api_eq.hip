@@ -52,18 +52,79 @@ int eq_single_pass_table(const EqState &e, EqPassTable &t)
     return nbp;
 }
 
-// run the cascade over n frames of `chains` chains, in place allowed
-// ev_start / ev_stop (optional): recorded at the start of the first and the completion of the last pass
-int eq_launch(EqState &e, const float *in, float *out, long long ss, long long cs, long long n,
-              hipStream_t st, bool *did_anything, hipEvent_t ev_start, hipEvent_t ev_stop)
+void eq_free(EqState &e)
+{
+    if (e.d_state) hipFree(e.d_state);
+    if (e.d_stabs) hipFree(e.d_stabs);
+    e.d_state = nullptr; e.d_stabs = nullptr;
+}
+
+bool eq_any_enabled(const EqState &e)
+{
+    if (e.per_stream) {
+        for (unsigned char v : e.s_en)
+            if (v) return true;
+        return false;
+    }
+    for (size_t i = 0; i < e.nb; ++i)
+        if (e.en[i]) return true;
+    return false;
+}
+
+void eq_set_shared_band(EqState &e, size_t band, const float coeffs[5], int enabled)
+{
+    std::memcpy(&e.coeffs[5 * band], coeffs, 5 * sizeof(float));
+    e.en[band] = enabled != 0;
+    if (e.per_stream) {         // the shared call sets the band of EVERY stream
+        const size_t S = e.chains / 2;
+        for (size_t s = 0; s < S; ++s) {
+            std::memcpy(&e.s_coeffs[(s * e.nb + band) * 5], coeffs, 5 * sizeof(float));
+            e.s_en[s * e.nb + band] = enabled != 0;
+        }
+        e.stabs_dirty = true;
+    }
+}
+
+int eq_set_stream_band(EqState &e, size_t stream, size_t band, const float coeffs[5], int enabled)
+{
+    const size_t S = e.chains / 2;
+    if (stream >= S) return fail(OHS_ERR_INVALID_ARG, "stream index out of range");
+    if (band >= e.nb) return OHS_OK;            // parametric_eq.rs:144-164 ignores a band index past the last one
+    if (!e.per_stream) {                        // every stream starts from the shared table
+        e.s_coeffs.resize(S * e.nb * 5);
+        e.s_en.resize(S * e.nb);
+        for (size_t s = 0; s < S; ++s) {
+            std::memcpy(&e.s_coeffs[s * e.nb * 5], e.coeffs.data(), e.nb * 5 * sizeof(float));
+            for (size_t b = 0; b < e.nb; ++b) e.s_en[s * e.nb + b] = e.en[b] != 0;
+        }
+        e.per_stream = true;
+    }
+    std::memcpy(&e.s_coeffs[(stream * e.nb + band) * 5], coeffs, 5 * sizeof(float));
+    e.s_en[stream * e.nb + band] = enabled != 0;
+    e.stabs_dirty = true;
+    return OHS_OK;
+}
+
+void eq_share_table(EqState &e)
+{
+    e.per_stream = false;
+    e.s_coeffs.clear(); e.s_coeffs.shrink_to_fit();
+    e.s_en.clear(); e.s_en.shrink_to_fit();
+    e.stabs_dirty = true;
+}
+
+// the cascade of ONE table (coeffs [nb][5], en [nb]) over n frames of `chains` chains: enabled bands only, in cascade order,
+// 16 per pass; a disabled band is the identity and keeps its state (parametric_eq.rs:118-120), so it is simply not given
+// a lane.  ev_start / ev_stop (optional): recorded at the start of the first and the completion of the last pass
+static int eq_launch_table(EqState &e, const float *coeffs, const unsigned char *en8, const int *en32, size_t chains,
+                           float *d_state, const float *in, float *out, long long ss, long long cs, long long n,
+                           hipStream_t st, bool *did_anything, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     bool did = false;
     const float *src = in;
-    // enabled bands only, in cascade order, 16 per pass; a disabled band is the identity and keeps its
-    // state (parametric_eq.rs:118-120), so it is simply not given a lane
     std::vector<size_t> on;
     for (size_t b = 0; b < e.nb; ++b)
-        if (e.en[b]) on.push_back(b);
+        if (en8 ? en8[b] != 0 : en32[b] != 0) on.push_back(b);
     for (size_t p0 = 0; p0 < on.size(); p0 += 16) {
         EqPassTable t;
         std::memset(&t, 0, sizeof(t));
@@ -72,18 +133,107 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
             const size_t b = on[p0 + (size_t)std::min(j, nbp - 1)];      // unused lanes shadow the last band's slot (never stored)
             t.slot[j] = (int)b;
             if (j < nbp) {
-                t.b0[j] = e.coeffs[5 * b + 0]; t.b1[j] = e.coeffs[5 * b + 1]; t.b2[j] = e.coeffs[5 * b + 2];
-                t.a1[j] = e.coeffs[5 * b + 3]; t.a2[j] = e.coeffs[5 * b + 4];
+                t.b0[j] = coeffs[5 * b + 0]; t.b1[j] = coeffs[5 * b + 1]; t.b2[j] = coeffs[5 * b + 2];
+                t.a1[j] = coeffs[5 * b + 3]; t.a2[j] = coeffs[5 * b + 4];
             }
         }
         int xcd_lo = e.xcd_lo, xcd_n = e.xcd_n;
         if (tuning().eq_xcd_n > 0) { xcd_lo = tuning().eq_xcd_lo; xcd_n = tuning().eq_xcd_n; }
         const bool first = p0 == 0, last = p0 + 16 >= on.size();
-        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)e.chains, t, nbp, e.d_state, st, e.exact_specials, e.fp_mode,
+        hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)chains, t, nbp, d_state, st, e.exact_specials, e.fp_mode,
                                         xcd_lo, xcd_n, first ? ev_start : nullptr, last ? ev_stop : nullptr);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
         did = true;
+    }
+    if (did_anything) *did_anything = did;
+    return OHS_OK;
+}
+
+// per-stream tables: compact every stream's enabled bands into its EqStreamTable and upload them.  Not on the audio path:
+// it waits for what the stream has queued (a launch in flight may still be reading the old tables) and copies synchronously.
+static int eq_upload_stream_tables(EqState &e, hipStream_t st)
+{
+    const size_t S = e.chains / 2;
+    std::vector<EqStreamTable> tabs(S);
+    size_t mx = 0;
+    for (size_t s = 0; s < S; ++s) {
+        EqStreamTable &t = tabs[s];
+        std::memset(&t, 0, sizeof(t));
+        int k = 0;
+        size_t count = 0, last = 0;
+        for (size_t b = 0; b < e.nb; ++b) {
+            if (!e.s_en[s * e.nb + b]) continue;
+            ++count;
+            if (k < 12) {
+                const float *c = &e.s_coeffs[(s * e.nb + b) * 5];
+                t.b0[k] = c[0]; t.b1[k] = c[1]; t.b2[k] = c[2]; t.a1[k] = c[3]; t.a2[k] = c[4];
+                t.slot[k] = (int)b;
+                last = b;
+                ++k;
+            }
+        }
+        for (int j = k; j < 12; ++j) t.slot[j] = (int)last;
+        t.nb = k;
+        mx = std::max(mx, count);
+    }
+    e.max_enabled = mx;
+    DeviceWideSection dws;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!e.d_stabs) HIP_TRY(hipMalloc(&e.d_stabs, S * sizeof(EqStreamTable)));
+    HIP_TRY(hipMemcpy(e.d_stabs, tabs.data(), S * sizeof(EqStreamTable), hipMemcpyHostToDevice));
+    e.stabs_dirty = false;
+    return OHS_OK;
+}
+
+// run the cascade over n frames of `chains` chains, in place allowed
+int eq_launch(EqState &e, const float *in, float *out, long long ss, long long cs, long long n,
+              hipStream_t st, bool *did_anything, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    bool did = false;
+    int rc = OHS_OK;
+    if (!e.per_stream) {
+        rc = eq_launch_table(e, e.coeffs.data(), nullptr, e.en.data(), e.chains, e.d_state, in, out, ss, cs, n, st, &did,
+                             ev_start, ev_stop);
+        if (rc) return rc;
+    } else {
+        if (e.stabs_dirty) {
+            rc = eq_upload_stream_tables(e, st);
+            if (rc) return rc;
+        }
+        if (e.max_enabled == 0) {
+            // no stream has an enabled band: identity
+        } else if (e.max_enabled <= 12 && !e.exact_specials && !tuning().eq_conveyor && eq_ring_addressable(ss, cs, n)) {
+            // one launch for all streams: every row reads its own stream's table when its wave starts
+            int xcd_lo = e.xcd_lo, xcd_n = e.xcd_n;
+            if (tuning().eq_xcd_n > 0) { xcd_lo = tuning().eq_xcd_lo; xcd_n = tuning().eq_xcd_n; }
+            hipError_t err = launch_eq_ring_streams(in, out, ss, cs, n, (int)e.chains, e.d_stabs, e.d_state, st, e.fp_mode, xcd_lo,
+                                                    xcd_n, ev_start, ev_stop);
+            if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch (per-stream tables): ") + hipGetErrorString(err));
+            did = true;
+        } else {
+            // A stream with more than 12 enabled bands, the exact-specials mode, strides beyond the ring form's reach: the
+            // conveyor kernel has its band count in its type, so every stream is a launch sequence of its own (correct for any
+            // table; an offline job that needs this at scale groups its streams by table and uses one batch per group).
+            if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
+            const size_t S = e.chains / 2;
+            for (size_t s = 0; s < S; ++s) {
+                bool d1 = false;
+                const float *si = in + (long long)s * ss;
+                float *so = out + (long long)s * ss;
+                rc = eq_launch_table(e, &e.s_coeffs[s * e.nb * 5], &e.s_en[s * e.nb], nullptr, 2,
+                                     e.d_state + s * 2 * (size_t)kEqStateSlots * 2, si, so, ss, cs, n, st, &d1, nullptr, nullptr);
+                if (rc) return rc;
+                if (!d1 && so != si) {      // this stream has no enabled band: its frames still have to arrive in `out`
+                    HIP_TRY(hipMemcpy2DAsync(so, (size_t)cs * sizeof(float), si, (size_t)cs * sizeof(float), (size_t)n * sizeof(float),
+                                             2, hipMemcpyDeviceToDevice, st));
+                }
+                did = did || d1 || so != si;
+            }
+            if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, st));
+            if (did_anything) *did_anything = did;
+            return OHS_OK;
+        }
     }
     if (!did) {     // no enabled band: the events mark this point of the stream
         if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
@@ -132,7 +282,7 @@ void ohs_eq_destroy(ohs_eq *q)
     hipSetDevice(q->device);
     DeviceWideSection dws;
     if (q->st) hipStreamSynchronize(q->st);
-    if (q->eq.d_state) hipFree(q->eq.d_state);
+    eq_free(q->eq);
     if (q->d_buf) hipFree(q->d_buf);
     if (q->h_pin) hipHostFree(q->h_pin);
     if (q->d_pinbuf) hipFree(q->d_pinbuf);
@@ -325,7 +475,7 @@ void ohs_biquad_destroy(ohs_biquad *f)
     hipSetDevice(f->device);
     DeviceWideSection dws;
     if (f->st) hipStreamSynchronize(f->st);
-    if (f->eq.d_state) hipFree(f->eq.d_state);
+    eq_free(f->eq);
     if (f->d_buf) hipFree(f->d_buf);
     if (f->st) hipStreamDestroy(f->st);
     delete f;

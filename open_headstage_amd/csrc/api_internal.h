@@ -220,12 +220,26 @@ struct EqState {
     bool exact_specials = false; // ohs_*_set_eq_exact_specials: conveyor kernel, exact for -0.0 / around non-finite input
     int fp_mode = 0;             // denormal handling (kernels.h: ohs_set_fp_mode)
     int xcd_lo = 0, xcd_n = 8;   // XCDs the ring kernel's launches may use (kernels.h: xcd_grid); set per call by the batch
+    // Per-stream tables (ohs_batch_set_stream_eq_band_coeffs): every stream owns its bands, as every plugin instance of the
+    // reference does (parametric_eq.rs:125-129).  Host copy [streams][nb] of coefficients and enable flags, created from the
+    // shared table by the first per-stream edit; the compacted device tables are uploaded by the next launch.
+    bool per_stream = false;
+    std::vector<float> s_coeffs;         // streams * nb * 5
+    std::vector<unsigned char> s_en;     // streams * nb
+    EqStreamTable *d_stabs = nullptr;    // [streams]
+    bool stabs_dirty = true;
+    size_t max_enabled = 0;              // largest number of enabled bands of any stream (as of the last upload scan)
 };
 
 
 int eq_init(EqState &e, size_t nb, size_t chains, float fs, hipStream_t st);
 int eq_reset(EqState &e, hipStream_t st);
 int eq_single_pass_table(const EqState &e, EqPassTable &t);
+bool eq_any_enabled(const EqState &e);      // some band of the shared table, or of any stream's own table, is enabled
+int eq_set_stream_band(EqState &e, size_t stream, size_t band, const float coeffs[5], int enabled);
+void eq_set_shared_band(EqState &e, size_t band, const float coeffs[5], int enabled);   // ... and of every stream's own table
+void eq_share_table(EqState &e);            // back to the one shared table
+void eq_free(EqState &e);
 int eq_launch(EqState &e, const float *in, float *out, long long ss, long long cs, long long n,
               hipStream_t st, bool *did_anything = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 

@@ -117,9 +117,16 @@ __host__ __device__ __forceinline__ bool eq_ring2_addressable(long long stream_s
 // One WAVE of the ring-form EQ: chains 4 * wave_id .. + 3 (rows beyond n_chains shadow a live row), the whole of
 // n samples, state read at entry and written back at exit.  No barrier, no LDS: callable from any kernel.  The
 // caller must have no vector-memory operation outstanding (the asm blocks count vmcnt by hand).
-__device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long long stream_stride, long long ch_stride,
-                                              long long n, int n_chains, int nb, const EqPassTable &tab,
-                                              float *__restrict__ state, long long wave_id)
+// PER_STREAM: every stream owns its bands (parametric_eq.rs:125-129: each plugin instance does) -- the constants, the
+// state slots and the NUMBER of enabled bands of a row come from stabs[stream of the row] (kernels.h: EqStreamTable)
+// instead of the launch's one table; a row with fewer bands simply has more pass-on lanes, the asm blocks do not know
+// the difference.  The tables are read where the shared form reads its kernel argument: in the head, once more for the
+// ragged end and the state write-back (no per-lane value of the compiler's may cross the asm blocks: 32 VGPRs).
+template <bool PER_STREAM>
+__device__ __forceinline__ void eq_ring2_wave_t(const float *in, float *out, long long stream_stride, long long ch_stride,
+                                                long long n, int n_chains, int nb_shared, const EqPassTable &tab,
+                                                const EqStreamTable *__restrict__ stabs, float *__restrict__ state,
+                                                long long wave_id)
 {
     constexpr int G = 8;            // chunks per group (128 samples per chain)
     if (wave_id * 4 >= n_chains) return;
@@ -136,6 +143,7 @@ __device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long 
     const int live_rows = rows_here < 4 ? rows_here : 4;
     int shadow_mask = __builtin_amdgcn_readfirstlane(live_rows == 2 ? 1 : 0);
     asm volatile("" : "+s"(shadow_mask));       // an opaque SGPR: left to itself hipcc keeps it in a VGPR across the blocks
+    auto stab_of = [&](int row) -> const EqStreamTable * { return stabs + (wave_id * 2 + (row >> 1)); };
     auto ids_of = [&](int lane_) -> Ids {
         Ids d;
         d.j = lane_ & 15;
@@ -143,13 +151,18 @@ __device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long 
         const int r_ = lane_ >> 4;
         // dead rows shadow a live row of the same wave (lock-step: same loads, same stores, no state write-back)
         d.row = r_ < live_rows ? r_ : (r_ & shadow_mask);       // = r_ % live_rows for live_rows in 1..4
+        int nb = nb_shared;
+        if constexpr (PER_STREAM) nb = stab_of(d.row)->nb;
         d.band = d.j >= 1 && d.j <= nb;
         const unsigned row_elems = (unsigned)((d.row >> 1) * stream_stride + (d.row & 1) * ch_stride);
         d.lane_off = (row_elems + (unsigned)d.jp) * 4u;
         return d;
     };
     auto state_offset = [&](const Ids &d) -> unsigned {
-        return (unsigned)((d.row * kEqStateSlots + tab.slot[d.band ? d.j - 1 : 0]) * 2) * 4u;
+        int slot;
+        if constexpr (PER_STREAM) slot = stab_of(d.row)->slot[d.band ? d.j - 1 : 0];
+        else slot = tab.slot[d.band ? d.j - 1 : 0];
+        return (unsigned)((d.row * kEqStateSlots + slot) * 2) * 4u;
     };
     auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
     const int lane = threadIdx.x & 63;
@@ -172,13 +185,24 @@ __device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long 
     int q = 0;
     {   // ---- head: constants, state, the launch's full groups
         const Ids d = ids_of(lane);
-        const bool pre = d.j < nb;
         const int jb = d.band ? d.j - 1 : 0;
-        c.pb0 = pre ? tab.b0[d.j] : 1.0f;
-        c.pb1 = pre ? tab.b1[d.j] : 0.0f;
-        c.b2 = d.band ? tab.b2[jb] : 0.0f;
-        c.a1 = d.band ? tab.a1[jb] : 0.0f;
-        c.a2 = d.band ? tab.a2[jb] : 0.0f;
+        if constexpr (PER_STREAM) {
+            const EqStreamTable *T = stab_of(d.row);
+            const bool pre = d.j < T->nb;
+            const int jp_ = pre ? d.j : 0;
+            c.pb0 = pre ? T->b0[jp_] : 1.0f;
+            c.pb1 = pre ? T->b1[jp_] : 0.0f;
+            c.b2 = d.band ? T->b2[jb] : 0.0f;
+            c.a1 = d.band ? T->a1[jb] : 0.0f;
+            c.a2 = d.band ? T->a2[jb] : 0.0f;
+        } else {
+            const bool pre = d.j < nb_shared;
+            c.pb0 = pre ? tab.b0[d.j] : 1.0f;
+            c.pb1 = pre ? tab.b1[d.j] : 0.0f;
+            c.b2 = d.band ? tab.b2[jb] : 0.0f;
+            c.a1 = d.band ? tab.a1[jb] : 0.0f;
+            c.a2 = d.band ? tab.a2[jb] : 0.0f;
+        }
         const unsigned state_off = state_offset(d);
         r.s.x = d.band ? ring2_ld(state0, state_off) : 0.0f;
         r.s.y = d.band ? ring2_ld(state0, state_off + 4u) : 0.0f;
@@ -219,6 +243,14 @@ __device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long 
             ring2_st(state0, state_off + 4u, r.s.y);
         }
     }
+}
+
+// the shared-table form: what k_eq_ring and the resident real-time kernel run
+__device__ __forceinline__ void eq_ring2_wave(const float *in, float *out, long long stream_stride, long long ch_stride,
+                                              long long n, int n_chains, int nb, const EqPassTable &tab,
+                                              float *__restrict__ state, long long wave_id)
+{
+    eq_ring2_wave_t<false>(in, out, stream_stride, ch_stride, n, n_chains, nb, tab, nullptr, state, wave_id);
 }
 
 }  // namespace ohs

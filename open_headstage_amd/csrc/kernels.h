@@ -32,6 +32,14 @@ struct EqPassTable {
     float b0[16], b1[16], b2[16], a1[16], a2[16];
     int slot[16];
 };
+// Per-stream tables (batch mode, ohs_batch_set_stream_eq_band_coeffs): the ENABLED bands of one stream in cascade order,
+// at most 12 (the ring form); read from device memory by the stream's two rows when their wave starts.
+struct EqStreamTable {
+    float b0[12], b1[12], b2[12], a1[12], a2[12];
+    int slot[12];               // the bands' own indices (state slots); unused entries repeat the last one
+    int nb;                     // enabled bands, 0 .. 12
+    int pad[3];
+};
 constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
 // chains = streams * 2 (L, R); chain c -> stream c>>1, channel c&1.
 // state: [chain][kEqStateSlots][2] (s1, s2), indexed by the band's own index.
@@ -46,6 +54,12 @@ hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, 
 // (ev_start / ev_stop: recorded at the start / completion of THIS launch.  The ring kernel's dispatch carries them
 // itself -- hipExtLaunchKernelGGL -- which spares the queue the marker packets of hipEventRecord and the gap they open
 // between back-to-back launches: 12-13 -> 7 us per chunk boundary of the overlapped batch step with profiling on.)
+
+// the ring form with one table per stream: d_tabs[n_chains / 2] in device memory (every stream <= 12 enabled bands)
+hipError_t launch_eq_ring_streams(const float *in, float *out, long long stream_stride, long long ch_stride, long long n,
+                                  int n_chains, const EqStreamTable *d_tabs, float *state, hipStream_t st, int fp_mode = 0,
+                                  int xcd_lo = 0, int xcd_n = 8, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+bool eq_ring_addressable(long long stream_stride, long long ch_stride, long long n);     // the strides the ring form reaches
 
 // |H(f)| of the enabled bands (parametric_eq.rs:190-209); coeffs [nb][5], en [nb]
 hipError_t launch_eq_freq_response(const float *d_coeffs, const int *d_en, int nb, float fs,

@@ -509,6 +509,18 @@ int ohs_node_batch_set_eq_band_coeffs(ohs_node_batch *nb, size_t band, const flo
     auto each = [&]() -> int { NB_FOR_EACH(ohs_batch_set_eq_band_coeffs(h, band, coeffs, enabled)) };
     return table_result(nb, each());
 }
+// one stream's own band (every plugin instance of the reference owns its bands, parametric_eq.rs:125-129): host-side state of
+// the ONE device handle that holds the stream -- nothing to broadcast, nothing that could tear
+int ohs_node_batch_set_stream_eq_band_coeffs(ohs_node_batch *nb, size_t stream, size_t band, const float coeffs[5], int enabled)
+{
+    if (!nb || !coeffs) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    if (stream >= nb->streams_total) return fail(OHS_ERR_INVALID_ARG, "stream index out of range");
+    for (int i = 0; i < nb->n; ++i)
+        if (stream < nb->first[(size_t)i] + nb->count[(size_t)i])
+            return ohs_batch_set_stream_eq_band_coeffs(nb->b[(size_t)i], stream - nb->first[(size_t)i], band, coeffs, enabled);
+    return fail(OHS_ERR_INVALID_ARG, "stream index out of range");
+}
+int ohs_node_batch_share_eq_table(ohs_node_batch *nb) { NB_FOR_EACH(ohs_batch_share_eq_table(h)) }
 int ohs_node_batch_set_eq_enabled(ohs_node_batch *nb, int eq_enable) { NB_FOR_EACH(ohs_batch_set_eq_enabled(h, eq_enable)) }
 int ohs_node_batch_set_gain(ohs_node_batch *nb, float gain) { NB_FOR_EACH(ohs_batch_set_gain(h, gain)) }
 int ohs_node_batch_set_conv_plan(ohs_node_batch *nb, int plan) { NB_FOR_EACH(ohs_batch_set_conv_plan(h, plan)) }

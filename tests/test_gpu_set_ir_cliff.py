@@ -6,6 +6,10 @@ processed before.  Until round 4 the call after such a set_ir went through k_con
 stream, blocks in sequence: ~290 x the steady call).  Now the time-parallel kernels take it: the old blocks are hidden
 behind a zeroed gap of the ring and k_conv_tp_old adds, under the per-path gate, what each path may still see of them.
 Checked: parity with the oracle across several resets (longer, shorter, muted), and the cost of the call after a reset.
+
+Round 5: the steady call of this shape is served by the block-2048 plan (0.15 ms instead of 0.25); the call right behind a
+per-path set_ir still takes the gated block-512 kernels (0.39 ms as before: 2.6 x the new steady call), the one after that
+is block 2048 again -- the plans hand the state over (tests/test_gpu_conv_lb.py).
 """
 import numpy as np
 import pytest
@@ -90,9 +94,16 @@ def test_the_call_after_a_per_path_set_ir_costs_at_most_three_steady_calls():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
 
+    # (the call after a per-path set_ir is served by the block-512 kernels -- the path must not see the frames in front of
+    # its reset, which the block-2048 plan's input history cannot express: one call under that plan first, so that its
+    # buffers exist and the first timed call does not pay for their allocation)
+    bp.set_conv_plan(1)
+    timed_call()
+    bp.set_conv_plan(0)
     for _ in range(3):
         timed_call()
     steady = sorted(timed_call() for _ in range(7))[3]
+    assert bp.last_conv_plan()[0] == "block2048"
     after = []
     for k in range(6):
         bp.set_ir(k % 4, irs[(k + 1) % 4])
