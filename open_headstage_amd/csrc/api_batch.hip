@@ -212,8 +212,9 @@ int ohs_batch_reset(ohs_batch *b)
     c.tails_lazy = false;       // (the zeroed per-path overlaps are the state)
     c.lb_lazy = false; c.lb_valid = 0;
     if (c.d_xhist) {            // (the block-2048 plan's state: zeros are what every path may see of the past)
-        HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)c.xh_len * sizeof(float), b->st));
+        HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)(2 * c.xh_len) * sizeof(float), b->st));
         c.xh_valid = c.xh_len;
+        c.xh_head = 0;
     }
     c.cnt = 0;
     for (int p = 0; p < 4; ++p) c.since[p] = 0;

@@ -98,8 +98,12 @@ static int conv_materialise_from_xhist(ConvState &c, DeviceCtx *ctx, hipStream_t
     if (R > 0) {
         int rc = conv_grow_ring(c, (int)R, st);
         if (rc) return rc;
+        {   // the ring of input frames in time order
+            hipError_t e = launch_conv_lb_xhist_linearise(c.d_xhist, c.d_xhist_alt, c.xh_len, c.xh_head, (int)c.S, st);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("input history: ") + hipGetErrorString(e));
+        }
         ConvGeneralArgs a;
-        a.in = c.d_xhist + (c.xh_len - R * BS); a.out = c.d_xhist_alt;     // (nothing is stored: skip_store = R)
+        a.in = c.d_xhist_alt + (c.xh_len - R * BS); a.out = c.d_xhist_alt;     // (nothing is stored: skip_store = R)
         a.in_stream_stride = 2 * c.xh_len; a.in_ch_stride = c.xh_len;
         a.out_stream_stride = 2 * c.xh_len; a.out_ch_stride = c.xh_len;
         a.n_blocks = (int)R;
@@ -208,14 +212,16 @@ int conv_lb_after_set_ir(ConvState &c, hipStream_t st)
         float *n = nullptr, *n2 = nullptr;
         if (want) {
             const size_t bytes = c.S * 2 * (size_t)want * sizeof(float);
-            HIP_TRY(hipMalloc(&n, bytes));
+            HIP_TRY(hipMalloc(&n, 2 * bytes));      // (a ring of twice the reach)
             if (hipMalloc(&n2, bytes) != hipSuccess) { hipFree(n); return fail(OHS_ERR_HIP, "hipMalloc(input history) failed"); }
-            hipError_t e = hipMemsetAsync(n, 0, bytes, st);
-            if (e == hipSuccess && c.d_xhist) {     // keep what is there, right-aligned (the newest frame stays the last one)
+            hipError_t e = hipMemsetAsync(n, 0, 2 * bytes, st);
+            if (e == hipSuccess && c.d_xhist) {     // keep what is there: the newest frame ends at position `want` of the new ring
                 const long long keep = std::min(want, c.xh_len);
-                e = hipMemcpy2DAsync(n + (want - keep), (size_t)want * sizeof(float), c.d_xhist + (c.xh_len - keep),
-                                     (size_t)c.xh_len * sizeof(float), (size_t)keep * sizeof(float), c.S * 2,
-                                     hipMemcpyDeviceToDevice, st);
+                e = launch_conv_lb_xhist_linearise(c.d_xhist, c.d_xhist_alt, c.xh_len, c.xh_head, (int)c.S, st);
+                if (e == hipSuccess)
+                    e = hipMemcpy2DAsync(n + (want - keep), (size_t)(2 * want) * sizeof(float), c.d_xhist_alt + (c.xh_len - keep),
+                                         (size_t)c.xh_len * sizeof(float), (size_t)keep * sizeof(float), c.S * 2,
+                                         hipMemcpyDeviceToDevice, st);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { hipFree(n); hipFree(n2); return fail(OHS_ERR_HIP, std::string("input history: ") + hipGetErrorString(e)); }
@@ -225,14 +231,16 @@ int conv_lb_after_set_ir(ConvState &c, hipStream_t st)
         c.d_xhist = n; c.d_xhist_alt = n2;
         c.xh_valid = std::min(c.xh_valid, want);
         c.xh_len = want;
+        c.xh_head = want;           // (the kept frames end at position `want`: the next frame goes there)
         c.lb_valid = 0;         // (the ring's depth follows the partition count)
         c.lb_cd_valid = false;
     }
     if (c.d_xhist && c.since[0] == 0 && c.since[1] == 0 && c.since[2] == 0 && c.since[3] == 0) {
         // every path has forgotten its past (convolution.rs:135-137): so has the input history, and zeros are what every path
         // may see of it
-        HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)c.xh_len * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)(2 * c.xh_len) * sizeof(float), st));
         c.xh_valid = c.xh_len;
+        c.xh_head = 0;
         c.lb_valid = 0;
     }
     return OHS_OK;
@@ -315,16 +323,16 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
         const int warm = cont ? 0 : P2pad - 1;
         if (!cont) c.lb_next = 4ll * c.lb_ring_cap;         // (any base that keeps every slot index positive)
         a.in = in + off; a.out = out + off;
-        a.xhist = c.d_xhist;
+        // (the forward kernel appends the segment's last frames to the input history itself -- before the inverse kernel may
+        // overwrite them in place --, into the half of the ring its windows do not read)
+        const long long xcnt = std::min<long long>(segf, c.xh_len);
+        a.xhist = c.d_xhist; a.xh_append = c.d_xhist; a.xh_head = c.xh_head; a.xh_cnt = xcnt;
         a.n_frames = segf;
         a.u0 = -warm; a.n_fwd = warm + n_big; a.n_big = n_big;
         a.ring_base = c.lb_next;
         hipError_t e = launch_conv_lb_forward(a, st);
-        // the segment's frames join the input history before the inverse kernel may overwrite them (in place)
-        if (e == hipSuccess)
-            e = launch_conv_lb_xhist_update(c.d_xhist, a.in, in_ss, in_cs, c.d_xhist_alt, c.xh_len, segf, (int)c.S, st);
         if (e == hipSuccess) {
-            std::swap(c.d_xhist, c.d_xhist_alt);
+            c.xh_head = (c.xh_head + xcnt) % (2 * c.xh_len);
             e = launch_conv_lb_mac_inverse(a, st);
         }
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-2048 launch: ") + hipGetErrorString(e));
@@ -635,19 +643,28 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             if (rcm) return rcm;
         }
         c.lb_valid = 0;         // (the block-2048 ring does not see the blocks of this call)
-        if (c.d_xhist) {
-            // the call's frames join the input history (before anything below overwrites them in place): what the
-            // block-2048 plan starts from when a later call takes it
-            if (((in_ss | in_cs) & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
-                hipError_t e = launch_conv_lb_xhist_update(c.d_xhist, in, in_ss, in_cs, c.d_xhist_alt, c.xh_len,
-                                                           (long long)n_blocks * BS, (int)c.S, st);
-                if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("input history update: ") + hipGetErrorString(e));
-                std::swap(c.d_xhist, c.d_xhist_alt);
-                c.xh_valid = std::min(c.xh_len, c.xh_valid + (long long)n_blocks * BS);
-            } else {
-                c.xh_valid = 0;     // (buffers the 16-byte copy cannot read: the history no longer follows the stream)
-            }
-        }
+        // The call's frames join the input history of the block-2048 plan (what it starts from when a later call takes it): the
+        // time-parallel forward kernel appends them itself, the sequential kernel's calls get a launch for it -- in front of
+        // anything that overwrites them in place.
+        const long long call_frames = (long long)n_blocks * BS;
+        const bool xh_on = c.d_xhist != nullptr;
+        const bool xh_ok = xh_on && ((in_ss | in_cs) & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+        const long long xh_cnt = xh_on ? std::min(call_frames, c.xh_len) : 0;
+        const long long xh_head0 = c.xh_head;
+        bool xh_lost = false;
+        auto xh_append_launch = [&]() -> int {
+            if (!xh_on) return OHS_OK;
+            if (!xh_ok) { xh_lost = true; return OHS_OK; }      // (buffers the 16-byte copy cannot read: the history no longer follows the stream)
+            hipError_t e = launch_conv_lb_xhist_append(in, in_ss, in_cs, c.d_xhist, c.xh_len, xh_head0, call_frames, (int)c.S, st);
+            if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("input history update: ") + hipGetErrorString(e));
+            return OHS_OK;
+        };
+        auto xh_advance = [&]() {
+            if (!xh_on) return;
+            if (xh_lost) { c.xh_valid = 0; return; }
+            c.xh_head = (xh_head0 + xh_cnt) % (2 * c.xh_len);
+            c.xh_valid = std::min(c.xh_len, c.xh_valid + call_frames);
+        };
         const bool since_equal = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3];
         bool since_old = true;
         for (int p = 0; p < 4; ++p) since_old = since_old && c.since[p] >= c.P[p] - 1;
@@ -660,8 +677,10 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
         // still see of them to the first Pmax - 1 blocks.  The first segment must reach beyond every old block
         // (n_blocks >= Pmax): the state it leaves behind is computed gate-free.  Shorter calls take the general kernel
         // (one wave per stream, blocks in sequence: 290 x slower on BASELINE config 4, which is why long calls do not).
-        const bool tp_gated = allow_fast && !gate_free && n_blocks >= 4 && n_blocks >= Pmax;
-        const bool tp = allow_fast && n_blocks >= 4 && (gate_free || tp_gated);
+        // (calls of 1 .. 3 blocks too: until round 5 they went through the sequential kernel -- one wave per stream, 93 us per
+        // block on BASELINE config 4's shape, whatever the number of streams: profiles/r05_short_calls_before.jsonl)
+        const bool tp_gated = allow_fast && !gate_free && n_blocks >= Pmax;
+        const bool tp = allow_fast && (gate_free || tp_gated);
         auto general = [&](const float *gin, float *gout, int nb, unsigned long long cnt, int since_add,
                            int skip_store, int zero_in, float2 *tails_out) -> int {
             ConvGeneralArgs a;
@@ -679,7 +698,10 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
             return OHS_OK;
         };
         if (!tp) {
-            int rc = general(in, out, n_blocks, c.cnt, 0, 0, 0, c.d_tails);
+            int rc = xh_append_launch();
+            if (rc) return rc;
+            xh_advance();
+            rc = general(in, out, n_blocks, c.cnt, 0, 0, 0, c.d_tails);
             if (rc) return rc;
             c.last_kernel = OHS_CONV_KERNEL_SEQUENTIAL; c.last_ranges = 1;
         } else {
@@ -738,6 +760,9 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 a.W = c.d_W; a.W1 = c.d_W1; a.tails = c.d_tails; a.tails_out = c.d_tails_alt;
                 a.pairs = ctx->d_pairs; a.n_pairs = ctx->n_pairs;
                 a.tw = ctx->d_tw; a.gain = gain; a.fp_mode = c.fp_mode;
+                // (frame i of the segment is frame done * 512 + i of the call; the call's last xh_cnt frames are appended)
+                a.xh_ring = xh_on ? c.d_xhist : nullptr; a.xh_len = c.xh_len; a.xh_head = xh_head0;
+                a.xh_frame0 = done * BS - (call_frames - xh_cnt);
                 hipError_t e = launch_conv_tp_forward(a, st);
                 if (e == hipSuccess) e = launch_conv_tp_mac(a, st);
                 if (e == hipSuccess && tp_gated && done == 0 && Pmax > 1) {
@@ -754,6 +779,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 done += seg;
                 c.last_kernel = OHS_CONV_KERNEL_BLOCK512_TP; c.last_ranges = seg;
             }
+            xh_advance();
         }
     }
     c.cnt += (unsigned long long)n_blocks;

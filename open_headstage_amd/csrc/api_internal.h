@@ -152,8 +152,11 @@ struct ConvState {
     // d_hist / d_tails are stale; conv_materialise_state rebuilds them from d_xhist when another plan needs them.
     float *d_irl = nullptr;         // [4][irl_len] the impulse responses in the time domain, zero-padded
     long long irl_len = 0;
-    float *d_xhist = nullptr, *d_xhist_alt = nullptr;       // [S][2][xh_len]
-    long long xh_len = 0;           // = P2pad * 2048
+    float *d_xhist = nullptr;       // [S][2][2 xh_len], a ring of twice its reach: the frame k <= xh_len frames in front of the next
+                                    // one at (xh_head - k) mod 2 xh_len (the forward kernels append into the half nobody reads)
+    float *d_xhist_alt = nullptr;   // [S][2][xh_len] scratch: the history in time order, when the block-512 state is rebuilt from it
+    long long xh_len = 0;           // the reach = P2pad * 2048
+    long long xh_head = 0;          // where the next frame goes (a multiple of 512, < 2 xh_len)
     long long xh_valid = 0;         // trailing frames of d_xhist that are what every path may see of the past (zeros after a reset of all paths count)
     bool lb_lazy = false;
     float4 *d_lb_ring = nullptr;    // [S][lb_ring_cap][2048] window spectra, pair layout

@@ -1438,6 +1438,15 @@ __global__ __launch_bounds__(64 * kTpWaves) void k_conv_tp_forward(const ConvTpA
         v[a] = make_float2(in_l[idx], in_r[idx]);
         v[a + 8] = make_float2(0.f, 0.f);
     }
+    if (A.xh_ring) {            // the block's frames join the input history (kernels.h: ConvTpArgs::xh_ring); wave-uniform
+        const long long f0 = A.xh_frame0 + (long long)t * kBlock;
+        if (f0 >= 0) {
+            const long long L2 = 2 * A.xh_len;
+            float *xl = A.xh_ring + s * 2 * L2 + (A.xh_head + f0) % L2, *xr = xl + L2;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) { xl[64 * a + lane] = v[a].x; xr[64 * a + lane] = v[a].y; }
+        }
+    }
     wave_fft_fwd_zpad(v, lds, tab, lane);
     float2 *hs = A.hist + (s * (size_t)A.cap + (size_t)((A.cnt + (unsigned long long)t) & (unsigned long long)(A.cap - 1))) * kFft;
 #pragma unroll

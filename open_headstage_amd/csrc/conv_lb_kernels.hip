@@ -13,7 +13,7 @@
 //   inverse, decimation in time:       y_c = IFFT1024(W[4 k1 + c]);  x[n1 + 1024 n2] = sum_c w4^(-n2 c) conj(w4096^(n1 c)) y_c[n1]
 // Overlap-save: window u = frames [(u - 1) 2048, (u + 1) 2048), output block t = the second half of IFFT(W_t) -- only
 // n2 = 2, 3 of the last radix-4 step are computed, and no overlap state exists: the state of a stream at rest is its
-// last P2 x 2048 INPUT frames (ConvState::d_xhist), from which the block-512 state is rebuilt when another plan needs it.
+// last P2 x 2048 INPUT frames (ConvState::d_xhist, a ring), from which the block-512 state is rebuilt when another plan needs it.
 //
 // Spectra are stored as PAIRS: slot q = (Z[q], Z[4096 - q]), slot 0 = (Z[0], Z[2048]) -- the packed two-channel product
 //   W[k] = Z[k] C[k] + conj(Z[N - k]) D[k]    (C = (A - jB)/2, D = (A + jB)/2, A = H_lsl + j H_lsr, B = H_rsl + j H_rsr)
@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void k_conv_lb_forward(const ConvLbArgs A)
     float2 z[4][4];
     {
         const float *in_l = A.in + s * A.in_stream_stride, *in_r = in_l + A.in_ch_stride;
-        const float *xh_l = A.xhist ? A.xhist + s * 2 * A.xh_len : nullptr, *xh_r = xh_l ? xh_l + A.xh_len : nullptr;
+        const long long L2 = 2 * A.xh_len;              // the ring is twice its reach (kernels.h)
+        const float *xh_l = A.xhist ? A.xhist + s * 2 * L2 : nullptr, *xh_r = xh_l ? xh_l + L2 : nullptr;
+        float *xa_l = A.xh_append ? A.xh_append + s * 2 * L2 : nullptr, *xa_r = xa_l ? xa_l + L2 : nullptr;
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) {
             // (wave-uniform source choice: a quarter never straddles the segment's start or end -- both are multiples of 512
@@ -111,10 +113,20 @@ __global__ __launch_bounds__(256) void k_conv_lb_forward(const ConvLbArgs A)
                     if (f0 < A.n_frames) {
                         l = *reinterpret_cast<const lb_v4f *>(in_l + f0);
                         r = *reinterpret_cast<const lb_v4f *>(in_r + f0);
+                        // the window's second half is the block's own frames: the last xh_cnt of the segment join the input
+                        // history, in the half of the ring no window of this launch reads (they reach back xh_len at most)
+                        const long long fa = f0 - (A.n_frames - A.xh_cnt);
+                        if (xa_l && n2 >= 2 && fa >= 0) {
+                            const long long pos = (A.xh_head + fa) % L2;
+                            *reinterpret_cast<lb_v4f *>(xa_l + pos) = l;
+                            *reinterpret_cast<lb_v4f *>(xa_r + pos) = r;
+                        }
                     }
                 } else if (xh_l && A.xh_len + f0 >= 0) {
-                    l = *reinterpret_cast<const lb_v4f *>(xh_l + (A.xh_len + f0));
-                    r = *reinterpret_cast<const lb_v4f *>(xh_r + (A.xh_len + f0));
+                    long long idx = A.xh_head + f0;             // (head and the ring's length are multiples of 512: a
+                    idx = idx < 0 ? idx + L2 : idx;             //  4-frame group does not straddle the wrap)
+                    l = *reinterpret_cast<const lb_v4f *>(xh_l + idx);
+                    r = *reinterpret_cast<const lb_v4f *>(xh_r + idx);
                 }
             }
             z[n2][0] = make_float2(l.x, r.x); z[n2][1] = make_float2(l.y, r.y);
@@ -352,18 +364,26 @@ __global__ __launch_bounds__(256) void k_conv_lb_build_cd(const float4 *__restri
     cd[((size_t)i * 2 + 1) * kLbPairs + q] = make_float4(h * (a.z + b.w), h * (a.w - b.z), h * (a.z - b.w), h * (a.w + b.z));
 }
 
-__global__ __launch_bounds__(256) void k_conv_lb_xhist_update(const float *__restrict__ old, const float *__restrict__ in,
-                                                              long long in_ss, long long in_cs, float *__restrict__ dst,
-                                                              long long len, long long n_frames, unsigned wgs_per_row)
+__global__ __launch_bounds__(256) void k_conv_lb_xhist_append(const float *__restrict__ in, long long in_ss, long long in_cs,
+                                                              float *__restrict__ ring, long long len, long long head,
+                                                              long long n_frames, long long count, unsigned wgs_per_row)
+{
+    const long long j = 4 * ((long long)(blockIdx.x % wgs_per_row) * 256 + threadIdx.x);
+    if (j >= count) return;
+    const size_t row = blockIdx.x / wgs_per_row;    // stream * 2 + channel
+    const long long pos = (head + j) % (2 * len);   // (count = min(n_frames, len); everything a multiple of 512)
+    *reinterpret_cast<lb_v4f *>(ring + row * 2 * len + pos) =
+        *reinterpret_cast<const lb_v4f *>(in + (row >> 1) * in_ss + (row & 1) * in_cs + (n_frames - count + j));
+}
+
+__global__ __launch_bounds__(256) void k_conv_lb_xhist_linearise(const float *__restrict__ ring, float *__restrict__ dst,
+                                                                 long long len, long long head, unsigned wgs_per_row)
 {
     const long long j = 4 * ((long long)(blockIdx.x % wgs_per_row) * 256 + threadIdx.x);
     if (j >= len) return;
-    const size_t row = blockIdx.x / wgs_per_row;    // stream * 2 + channel
-    const long long f = n_frames - len + j;         // frame of the call that lands at position j (len, n_frames: multiples of 512)
-    lb_v4f v;
-    if (f >= 0) v = *reinterpret_cast<const lb_v4f *>(in + (row >> 1) * in_ss + (row & 1) * in_cs + f);
-    else v = *reinterpret_cast<const lb_v4f *>(old + row * len + (len + f));
-    *reinterpret_cast<lb_v4f *>(dst + row * len + j) = v;
+    const size_t row = blockIdx.x / wgs_per_row;
+    const long long pos = (head + len + j) % (2 * len);     // = head - len + j
+    *reinterpret_cast<lb_v4f *>(dst + row * len + j) = *reinterpret_cast<const lb_v4f *>(ring + row * 2 * len + pos);
 }
 
 static hipError_t lb_allow_lds(const void *fn, std::atomic<unsigned long long> &done_mask)
@@ -382,7 +402,11 @@ static bool lb_args_ok(const ConvLbArgs &a)
 {
     if (a.n_streams <= 0 || a.ring_cap <= 0 || !a.ring || !a.tw || !a.tw4096) return false;
     if ((a.in_stream_stride | a.in_ch_stride | a.out_stream_stride | a.out_ch_stride | a.xh_len) & 3) return false;
-    if ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.xhist)) & 15) return false;
+    if ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.xhist) |
+         reinterpret_cast<uintptr_t>(a.xh_append)) & 15)
+        return false;
+    if (a.xhist && (a.xh_len <= 0 || (a.xh_len & 511) || (a.xh_head & 511) || a.xh_head < 0 || a.xh_head >= 2 * a.xh_len)) return false;
+    if (a.xh_append && (a.xh_append != a.xhist || a.xh_cnt < 0 || a.xh_cnt > a.xh_len || a.xh_cnt > a.n_frames || (a.xh_cnt & 511))) return false;
     if (a.n_frames < 0 || (a.n_frames & 511)) return false;
     return true;
 }
@@ -427,15 +451,28 @@ hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_conv_lb_xhist_update(const float *old, const float *in, long long in_ss, long long in_cs, float *dst,
-                                       long long len, long long n_frames, int n_streams, hipStream_t st)
+hipError_t launch_conv_lb_xhist_append(const float *in, long long in_ss, long long in_cs, float *ring, long long len,
+                                       long long head, long long n_frames, int n_streams, hipStream_t st)
 {
-    if (len <= 0 || (len & 511) || (n_frames & 511) || n_streams <= 0) return hipErrorInvalidValue;
+    if (len <= 0 || (len & 511) || (n_frames & 511) || (head & 511) || head < 0 || head >= 2 * len || n_streams <= 0)
+        return hipErrorInvalidValue;
     if ((in_ss | in_cs) & 3 || (reinterpret_cast<uintptr_t>(in) & 15)) return hipErrorInvalidValue;
+    const long long count = n_frames < len ? n_frames : len;
+    if (count <= 0) return hipSuccess;
+    const unsigned long long wpr = (unsigned long long)((count / 4 + 255) / 256), wgs = wpr * 2ull * (unsigned long long)n_streams;
+    if (wgs > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv_lb_xhist_append, dim3((unsigned)wgs), dim3(256), 0, st, in, in_ss, in_cs, ring, len, head, n_frames,
+                       count, (unsigned)wpr);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_lb_xhist_linearise(const float *ring, float *dst, long long len, long long head, int n_streams,
+                                          hipStream_t st)
+{
+    if (len <= 0 || (len & 511) || (head & 511) || head < 0 || head >= 2 * len || n_streams <= 0) return hipErrorInvalidValue;
     const unsigned long long wpr = (unsigned long long)((len / 4 + 255) / 256), wgs = wpr * 2ull * (unsigned long long)n_streams;
     if (wgs > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_conv_lb_xhist_update, dim3((unsigned)wgs), dim3(256), 0, st, old, in, in_ss, in_cs, dst, len, n_frames,
-                       (unsigned)wpr);
+    hipLaunchKernelGGL(k_conv_lb_xhist_linearise, dim3((unsigned)wgs), dim3(256), 0, st, ring, dst, len, head, (unsigned)wpr);
     return hipGetLastError();
 }
 

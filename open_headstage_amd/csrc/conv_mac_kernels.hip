@@ -158,10 +158,13 @@ __device__ __forceinline__ void conv_tp_w1_job(const ConvTpArgs &A, int wg)
 }
 
 // time tile of a segment of n blocks: 32 x 16 runs a block 11 % faster than 16 x 16 (config 4: 0.269 -> 0.250 ms per step
-// in all) but rounds the segment up to a multiple of 32
+// in all) but rounds the segment up to a multiple of 32.  Short calls (a many-stream host that calls with the plugin's
+// 1024-frame block: 2 blocks) take tiles of 4 or 8 blocks: a 16-block tile would compute 16 outputs to store 2.
 static int mac_time_tile(int n)
 {
     if (OHS_MAC_TB != 0) return OHS_MAC_TB;
+    if (n <= 4) return 4;
+    if (n <= 8) return 8;
     const long long c32 = (long long)((n + 31) / 32) * 32 * 89, c16 = (long long)((n + 15) / 16) * 16 * 100;
     return c32 < c16 ? 32 : 16;
 }
@@ -180,6 +183,8 @@ hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st)
     const unsigned w1_wgs = (unsigned)((a.n_pairs + 255) / 256) * (unsigned)a.n_streams;
     const dim3 grid((unsigned)m.main_wgs + w1_wgs);
     switch (kTB) {
+    case 4: hipLaunchKernelGGL(k_conv_tp_mac<4>, grid, dim3(256), 0, st, m); break;
+    case 8: hipLaunchKernelGGL(k_conv_tp_mac<8>, grid, dim3(256), 0, st, m); break;
     case 16: hipLaunchKernelGGL(k_conv_tp_mac<16>, grid, dim3(256), 0, st, m); break;
     case 32: hipLaunchKernelGGL(k_conv_tp_mac<32>, grid, dim3(256), 0, st, m); break;
     default: return hipErrorInvalidValue;

@@ -241,6 +241,10 @@ struct ConvTpArgs {
     const float2 *tw;
     float gain;
     int fp_mode;                // denormal handling, see ohs_set_fp_mode
+    // F appends the call's last frames to the input history of the block-2048 plan (ConvLbArgs: a ring of 2 xh_len per row):
+    // frame i of this segment goes to (xh_head + xh_frame0 + i) mod 2 xh_len when xh_frame0 + i >= 0.  xh_ring == NULL: no history
+    float *xh_ring;
+    long long xh_len, xh_head, xh_frame0;
 };
 hipError_t launch_conv_tp_forward(const ConvTpArgs &a, hipStream_t st);
 hipError_t launch_conv_tp_mac(const ConvTpArgs &a, hipStream_t st);
@@ -286,8 +290,12 @@ struct ConvLbArgs {
     float *out;
     long long in_stream_stride, in_ch_stride;       // floats; multiples of 4 (16-byte accesses)
     long long out_stream_stride, out_ch_stride;
-    const float *xhist;         // [stream][2][xh_len]: the frames in front of the segment (frame -1 at xh_len - 1); may be NULL
-    long long xh_len;
+    // the input history: [stream][2][2 xh_len], a ring of TWICE the reach xh_len: the frame k frames in front of the segment at
+    // (xh_head - k) mod 2 xh_len, k <= xh_len; may be NULL.  xh_append != NULL: F also appends the segment's last
+    // xh_cnt = min(n_frames, xh_len) frames at xh_head .. (the half of the ring nobody reads), the host then advances the head
+    const float *xhist;
+    float *xh_append;
+    long long xh_len, xh_head, xh_cnt;  // multiples of 512
     int n_streams;
     long long n_frames;         // valid frames of `in` from the segment's start; beyond: zeros (in) / not stored (out)
     int u0, n_fwd;              // F: windows u0 .. u0 + n_fwd - 1 (u < 1 reaches into xhist)
@@ -308,9 +316,14 @@ hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st);
 hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st);
 // (C, D) tables from the spectra of A = h_lsl + j h_lsr (ab[0][i]) and B = h_rsl + j h_rsr (ab[1][i]), i < P2pad
 hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st);
-// dst[s][ch][j] = frame (n_frames - len + j) of the stream: from `in` when >= 0, else from old[s][ch][len + that]
-hipError_t launch_conv_lb_xhist_update(const float *old, const float *in, long long in_ss, long long in_cs, float *dst,
-                                       long long len, long long n_frames, int n_streams, hipStream_t st);
+// the input history [stream][2][2 len] (a ring of twice its reach `len`): append the call's last cnt = min(n_frames, len)
+// frames at head .. head + cnt (mod 2 len); the caller then advances head by cnt.  (The forward kernels do this themselves;
+// this launch serves the calls that go through the sequential kernel.)
+hipError_t launch_conv_lb_xhist_append(const float *in, long long in_ss, long long in_cs, float *ring, long long len,
+                                       long long head, long long n_frames, int n_streams, hipStream_t st);
+// dst[row][j] = the frame (len - j) frames in front of the head, j = 0 .. len - 1: oldest first, newest last; dst rows of len
+hipError_t launch_conv_lb_xhist_linearise(const float *ring, float *dst, long long len, long long head, int n_streams,
+                                          hipStream_t st);
 void conv_lb_build_twiddles(float2 *out);       // host: [3][1024]
 constexpr int kLbBlock = 2048;                  // frames per block of this plan
 constexpr int kLbTile = 4;                      // output blocks per MI workgroup

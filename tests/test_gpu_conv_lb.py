@@ -109,8 +109,8 @@ def test_several_segments_per_call(oracle):
 
 
 def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
-    """One continuous signal through a sequence of calls under changing plans: block 2048 -> block 512 time-parallel ->
-    sequential kernel (2 blocks) -> block 2048 ..., with the EQ in front, and a per-path set_ir in mid-stream -- the call
+    """One continuous signal through a sequence of calls under changing plans: block 2048 -> block 512 time-parallel (24
+    blocks, 2 blocks) -> block 2048 ..., with the EQ in front, and a per-path set_ir in mid-stream -- the call
     right behind it is served by the block-512 kernels (that path must not see the frames before its reset,
     convolution.rs:135-138), the one after by block 2048 again."""
     import torch
@@ -134,9 +134,9 @@ def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
             qo.set_band_coeffs(i, ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db), b.enabled)
         eqs.append(qo)
     #      (plan, blocks, kernel family expected of the call's last launch)
-    seq = [(2, 20, "block2048"), (1, 24, "block512_tp"), (2, 8, "block2048"), (1, 2, "sequential"), (2, 16, "block2048"),
+    seq = [(2, 20, "block2048"), (1, 24, "block512_tp"), (2, 8, "block2048"), (1, 2, "block512_tp"), (2, 16, "block2048"),
            (2, 16, "block2048"),        # <- set_ir(path 2) in front of this one: served by block 512 (gated), see below
-           (2, 20, "block2048"), (0, 3, "sequential"), (0, 40, "block2048")]
+           (2, 20, "block2048"), (0, 3, "block512_tp"), (0, 40, "block2048")]
     for k, (plan, nb, want) in enumerate(seq):
         if k == 5:
             h = synth.hrir_set(6000)[2]
@@ -183,7 +183,7 @@ def test_the_library_picks_block_2048_for_long_calls_on_long_responses():
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
     dev = torch.device("cuda:0")
-    for taps, nb, want in ((16384, 64, "block2048"), (16384, 12, "block512_tp"), (16384, 2, "sequential"),
+    for taps, nb, want in ((16384, 64, "block2048"), (16384, 12, "block512_tp"), (16384, 2, "block512_tp"),
                            (3000, 64, "block512_tp"), (4096, 16, "block2048")):
         bp = _make(ohs, 4, synth.hrir_set(taps), 0)
         x = synth.white_noise_torch(3, 4, nb * 512, dev)
