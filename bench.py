@@ -62,6 +62,9 @@ TAPS = 512
 FS = 48000.0
 NOMINAL_CLOCK_GHZ = 2.4        # same guide: max clock; only used to express the EQ's ns per sample in cycles
 EQ_ISSUE_FLOOR_CYCLES = 26.7   # 6.5 VALU per sample x 4.1 cycles per instruction of a lone wave
+# ohs_batch_last_conv_plan's kernel family -> the kernel that dominates it (the name rocprofv3 shows)
+KERNEL_OF_FAMILY = {"block512_p1": "k_conv_p1", "hop1536_p1": "k_conv_p1_os", "block512_tp": "k_conv_tp_mac",
+                    "block2048": "k_conv_lb_mac_inverse", "sequential": "k_conv_general", "none": "none"}
 
 
 def cpu_info():
@@ -608,22 +611,46 @@ def main() -> int:
     def step():
         bp.process(x, out=y, hip_stream=hs, deferred=args.pipelined)
 
+    if distributed or world > 1:
+        # before anything that could hang (the first multi-rank run happens on the driver's box, unattended): which device this
+        # rank sits on, to stderr -- a hang still leaves it behind
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            print(f"[bench rank {rank}/{world}] pid {os.getpid()} local_rank {local_rank} device {dev_index} {pr.name} "
+                  f"pci {getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x} "
+                  f"uuid {getattr(pr, 'uuid', '')} streams {ids.start}..{ids.stop} backend {backend} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench rank {rank}/{world}] device evidence failed: {e}", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
     bp.join(hs)
     torch.cuda.synchronize()
+    if distributed or world > 1:
+        print(f"[bench rank {rank}/{world}] warm-up done, entering the timed region", file=sys.stderr, flush=True)
 
     bp.set_profiling(True)
+    # one event in front of every step and one behind the last, on the stream the steps are queued on: the median / min / max
+    # step beside the contract's mean over the wall clock (a marker packet per 5.6 ms step)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        step_ev[i].record(proc_stream)
         step()
     bp.join(hs)
+    step_ev[args.steps].record(proc_stream)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)) if args.steps else [0.0]
     eq_ms, conv_ms, n_calls, eq_launches, conv_launches = bp.profile_read()
+    try:
+        eq_clock_ghz, eq_wave_us = bp.profile_eq_clock()        # the shader clock the EQ's wave 0 really ran at (last launch)
+    except Exception:       # noqa: BLE001 -- no ring-form launch (more than 12 bands): the nominal clock is used and named
+        eq_clock_ghz, eq_wave_us = None, None
+    conv_kernel_of_step, conv_ranges_of_step = bp.last_conv_plan()
     bp.set_profiling(False)
 
     rank_records = None
@@ -653,8 +680,8 @@ def main() -> int:
     out = None
     if rank == 0:
         eq_b, conv_b = bp.kernel_bytes(n_blocks)
-        # taps <= 512 -> every path has one partition -> the time-parallel k_conv_p1 (+ its edge pre-pass)
-        conv_name = "k_conv_p1"
+        # what served the step's convolution launches: asked of the library (ohs_batch_last_conv_plan), not restated here
+        conv_name = KERNEL_OF_FAMILY.get(conv_kernel_of_step, conv_kernel_of_step)
         # <= 12 enabled bands -> the ring form of the EQ kernel (eq_kernels.hip), else the conveyor form
         eq_name = "k_eq_ring" if int(np.count_nonzero(enabled)) <= 12 else "k_eq_pass"
         # per LAUNCH (a step issues several launches of each kernel when EQ and convolution overlap):
@@ -686,6 +713,8 @@ def main() -> int:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_device": {"median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4),
+                                   "max": round(step_ms[-1], 4), "how": f"HIP events around each of the {args.steps} timed steps"},
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -725,11 +754,17 @@ def main() -> int:
                 "launches_per_step": {eq_name: eq_launches // max(n_calls, 1),
                                       conv_name: conv_launches // max(n_calls, 1)},
                 "kernels_ms_per_step": {k: round(v[2], 4) for k, v in kernels.items()},
+                # cycles per sample at the clock the EQ's wave 0 MEASURED in the timed region's last launch (s_memtime against
+                # s_memrealtime, ohs_batch_profile_eq_clock), not at the nominal 2.4 GHz
                 "issue": {
                     "ns_per_sample": round(ns_per_sample, 3),
+                    "shader_clock_GHz": None if eq_clock_ghz is None else round(eq_clock_ghz, 4),
+                    "clock_source": "measured: s_memtime / s_memrealtime of wave 0 of the last EQ launch of the timed region"
+                                    if eq_clock_ghz else f"NOMINAL {NOMINAL_CLOCK_GHZ} GHz (no ring-form launch to measure)",
+                    "cycles_per_sample": round(ns_per_sample * (eq_clock_ghz or NOMINAL_CLOCK_GHZ), 2),
                     "cycles_per_sample_at_2p4GHz": round(ns_per_sample * NOMINAL_CLOCK_GHZ, 2),
                     "cycles_per_sample_floor": EQ_ISSUE_FLOOR_CYCLES,
-                    "frac_of_floor": round(EQ_ISSUE_FLOOR_CYCLES / max(ns_per_sample * NOMINAL_CLOCK_GHZ, 1e-9), 4),
+                    "frac_of_floor": round(EQ_ISSUE_FLOOR_CYCLES / max(ns_per_sample * (eq_clock_ghz or NOMINAL_CLOCK_GHZ), 1e-9), 4),
                 } if eq_is_dom else None,
                 # the convolution kernel, which runs underneath the EQ here and sets the rate from ~1000 streams up:
                 # bytes it really moves (16 B per frame + chunk tails), NOT the per-block model it does not execute;
@@ -737,6 +772,7 @@ def main() -> int:
                 "conv": {
                     "bound": "hbm",
                     "kernel": conv_name,
+                    "ranges_per_stream": conv_ranges_of_step,
                     "achieved": round(conv_achieved, 3),
                     "frac": round(conv_achieved / HBM_PEAK_GBS, 5),
                     "design_bytes_per_launch": int(conv_launch_bytes),
@@ -800,37 +836,45 @@ def main() -> int:
             for _ in range(40):
                 bp.process(x, out=y)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()                 # (EQ off: the step's kernel is launched on this very stream)
-            for _ in range(16):
-                bp.process(x, out=y)
-            e1.record()
-            torch.cuda.synchronize()
-            dt = e0.elapsed_time(e1) * 1e-3 / 16
+            def timed_steps(k):
+                """-> sorted device ms of k steps, each between two events on the launch stream (EQ off: one kernel per step)"""
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+                for i in range(k):
+                    evs[i].record()
+                    bp.process(x, out=y)
+                evs[k].record()
+                torch.cuda.synchronize()
+                return sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(k))
+
+            ts = timed_steps(32)
+            dt = ts[len(ts) // 2] * 1e-3
             _, cb_alone = bp.kernel_bytes(n_blocks)
+            fam, ranges = bp.last_conv_plan()
             out["roofline"]["conv_alone"] = {
-                "what": "the same batch with the EQ off, out of place, 16 steps back to back after 40 warm-up steps (ONE kernel per "
-                        "step, the plan the library picks for such a call: hop 1536 / FFT 2048, k_conv_p1_os; HIP events)",
-                "kernel": "k_conv_p1_os" if args.streams >= 256 and n_blocks >= 48 else "k_conv_p1",
-                "ms_per_step": round(dt * 1e3, 4), "Msamples_s": round(args.streams * frames / dt / 1e6, 1),
+                "what": "the same batch with the EQ off, out of place: ONE kernel per step, the plan the library picks for such a "
+                        "call; 32 steps after 40 warm-up steps, a HIP event between steps: median, with min and max beside it",
+                "kernel": KERNEL_OF_FAMILY.get(fam, fam), "family": fam, "ranges_per_stream": ranges,
+                "ms_per_step": round(dt * 1e3, 4), "ms_min": round(ts[0], 4), "ms_max": round(ts[-1], 4),
+                "Msamples_s": round(args.streams * frames / dt / 1e6, 1),
                 "design_bytes_per_step": int(cb_alone),
                 "achieved": round(cb_alone / dt / 1e9, 1), "unit": "GB/s",
-                "frac": round(cb_alone / dt / 1e9 / HBM_PEAK_GBS, 5)}
+                "frac": round(cb_alone / dt / 1e9 / HBM_PEAK_GBS, 5),
+                "frac_min_max": [round(cb_alone / (ts[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                 round(cb_alone / (ts[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)]}
             # the block-512 plan forced (k_conv_p1: what serves BASELINE configs[2] underneath the EQ) on the same batch
             try:
                 bp.set_conv_plan(1)
                 for _ in range(10):
                     bp.process(x, out=y)
                 torch.cuda.synchronize()
-                e0.record()
-                for _ in range(16):
-                    bp.process(x, out=y)
-                e1.record()
-                torch.cuda.synchronize()
-                dt1 = e0.elapsed_time(e1) * 1e-3 / 16
+                ts1 = timed_steps(32)
+                dt1 = ts1[len(ts1) // 2] * 1e-3
                 _, cb1 = bp.kernel_bytes(n_blocks)
+                fam1, ranges1 = bp.last_conv_plan()
                 out["roofline"]["conv_alone"]["block_512_plan"] = {
-                    "kernel": "k_conv_p1", "ms_per_step": round(dt1 * 1e3, 4), "design_bytes_per_step": int(cb1),
+                    "kernel": KERNEL_OF_FAMILY.get(fam1, fam1), "family": fam1, "ranges_per_stream": ranges1,
+                    "ms_per_step": round(dt1 * 1e3, 4), "ms_min": round(ts1[0], 4), "ms_max": round(ts1[-1], 4),
+                    "design_bytes_per_step": int(cb1),
                     "achieved": round(cb1 / dt1 / 1e9, 1), "unit": "GB/s", "frac": round(cb1 / dt1 / 1e9 / HBM_PEAK_GBS, 5)}
             except Exception as e:      # noqa: BLE001
                 out["roofline"]["conv_alone"]["block_512_plan"] = {"error": str(e)[:200]}
@@ -871,13 +915,16 @@ def main() -> int:
                 bp2.process(x2, out=y2)
             torch.cuda.synchronize()
             sa, sb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            bp2.conv_plan_counts(reset=True)
             sa.record()                 # (ohs_batch_process joins its second stream back into this one before it returns)
             for _ in range(6):
                 bp2.process(x2, out=y2)
             sb.record()
             torch.cuda.synchronize()
+            plan_counts = {k: v // 6 for k, v in bp2.conv_plan_counts(reset=True).items()}     # per step, by kernel family
             dt = sa.elapsed_time(sb) * 1e-3 / 6
             eb2, cb2 = bp2.kernel_bytes(n_blocks)
+            fam2, ranges2 = bp2.last_conv_plan()         # (of the step's LAST convolution launch: the short last time chunk)
             # the same with the block-512 plan of the one-partition convolution forced (ohs_batch_set_conv_plan(1)); from 512
             # streams on the library picks the hop-1536 plan by itself: profiles/r04_conv_plan_ab_run3.txt
             dt_p1 = None
@@ -895,7 +942,9 @@ def main() -> int:
             except Exception:       # noqa: BLE001
                 pass
             sat.append({"streams": S2, "ms_per_step": round(dt * 1e3, 4), "how": "6 steps after 3, HIP events",
-                        "conv_plan": "library's choice (hop 1536 / FFT 2048 at this stream count)",
+                        "conv_plan": "the library's choice", "conv_launches_per_step_by_family": plan_counts,
+                        "conv_kernel_of_last_chunk": KERNEL_OF_FAMILY.get(fam2, fam2),
+                        "conv_ranges_per_stream_of_last_chunk": ranges2,
                         "ms_per_step_conv_plan_1": None if dt_p1 is None else round(dt_p1 * 1e3, 4),
                         "Msamples_s": round(S2 * frames / dt / 1e6, 1),
                         "hbm_frac_8d_model": round(bp2.algorithmic_bytes(n_blocks) / dt / 1e9 / HBM_PEAK_GBS, 5),
@@ -903,6 +952,46 @@ def main() -> int:
             del bp2, x2, y2
             torch.cuda.empty_cache()
         out["saturation"] = sat
+        # BASELINE configs[3] ("config 4" of SURVEY 8: 64 streams, 4 x 16 384 taps, no EQ), 256-block calls: the reference's
+        # block-512 partitioning (32 partitions) and the block-2048 plan the library picks for such calls (8 partitions,
+        # product and inverse transform in one kernel); per-step HIP events, median of 20 after 3
+        try:
+            S4, taps4, nb4 = 64, 16384, 256
+            x4 = synth.white_noise_torch(0, S4, nb4 * 512, device)
+            y4 = torch.empty_like(x4)
+            irs4 = synth.hrir_set(taps4)
+            long_ir = {"workload": f"{S4} streams x {nb4 * 512} frames, 4 x {taps4} taps, EQ off, out of place",
+                       "io_floor_bytes": S4 * nb4 * 512 * 16}
+            for plan, key in ((1, "block_512_plan"), (0, "library_choice")):
+                bp4 = ohs.BatchProcessor(S4, num_bands=nb, device=dev_index)
+                for p in range(4):
+                    bp4.set_ir(p, irs4[p])
+                bp4.set_eq_enabled(False)
+                bp4.set_conv_plan(plan)
+                for _ in range(3):
+                    bp4.process(x4, out=y4)
+                torch.cuda.synchronize()
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+                for i in range(20):
+                    evs[i].record()
+                    bp4.process(x4, out=y4)
+                evs[20].record()
+                torch.cuda.synchronize()
+                ts4 = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(20))
+                med = ts4[10] * 1e-3
+                fam4, ranges4 = bp4.last_conv_plan()
+                _, cb4 = bp4.kernel_bytes(nb4)
+                long_ir[key] = {"kernel": KERNEL_OF_FAMILY.get(fam4, fam4), "family": fam4, "ranges_per_stream": ranges4,
+                                "ms_per_step": round(med * 1e3, 4), "ms_min": round(ts4[0], 4), "ms_max": round(ts4[-1], 4),
+                                "Msamples_s": round(S4 * nb4 * 512 / med / 1e6, 1),
+                                "design_bytes_per_step": int(cb4), "achieved": round(cb4 / med / 1e9, 1), "unit": "GB/s",
+                                "frac": round(cb4 / med / 1e9 / HBM_PEAK_GBS, 5)}
+                del bp4
+            del x4, y4
+            torch.cuda.empty_cache()
+            out["long_ir"] = long_ir
+        except Exception as e:      # noqa: BLE001 -- never let an extra break the contract line
+            out["long_ir"] = {"error": str(e)[:200]}
         # roofline.traffic measured now (two rocprofv3 --pmc child runs of this script); the committed summary
         # stays the fallback and is named as such
         if not args.no_live_pmc:

@@ -367,6 +367,10 @@ enum ohs_conv_kernel {
     OHS_CONV_KERNEL_SEQUENTIAL = 5      /* k_conv_general: one wave per stream, blocks in sequence */
 };
 int  ohs_batch_last_conv_plan(const ohs_batch *b, int *kernel, int *ranges_per_stream);
+/* convolution launch sequences served per kernel family (counts[OHS_CONV_KERNEL_*]) since the handle was created or since
+ * the last call with reset != 0: a processing call that is cut into time chunks counts once per chunk, and the chunks of
+ * one call need not be served alike (the short last chunk of an overlapped step usually is not) */
+int  ohs_batch_conv_plan_counts(ohs_batch *b, uint64_t counts[6], int reset);
 /* zero every stream's EQ state, history and overlap (IRs and EQ table kept).  Also the way back from a failed handle:
  * a HIP failure in the middle of a processing call leaves the per-stream state advanced for some time chunks only, so
  * the call joins its internal stream, returns OHS_ERR_HIP, and every later processing call on the handle returns
@@ -406,6 +410,11 @@ int  ohs_batch_sync(ohs_batch *b, void *hip_stream);
 int  ohs_batch_set_profiling(ohs_batch *b, int enable);
 int  ohs_batch_profile_read(ohs_batch *b, double *eq_ms, double *conv_ms, uint64_t *n_calls,
                             uint64_t *eq_launches, uint64_t *conv_launches);
+/* With profiling on, wave 0 of every ring-form EQ launch also leaves two counters of its start and end behind (s_memrealtime,
+ * 100 MHz, and s_memtime, the shader clock): the clock the serial recurrence REALLY ran at -- what turns ns per sample into
+ * cycles per sample (the nominal 2.4 GHz is not what a loaded chip runs at) -- and that wave's lifetime, of
+ * the most recent such launch.  Waits for the device. */
+int  ohs_batch_profile_eq_clock(ohs_batch *b, double *shader_ghz, double *wave_us);
 /* HBM bytes of one ohs_batch_process call of n_blocks by SURVEY.md 8d's per-block model (state persisted
  * between 512-frame blocks: 25 112 B per stream-block at P = 1) -- the yardstick of the whole path */
 int  ohs_batch_algorithmic_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *bytes);

@@ -120,6 +120,8 @@ PROTOTYPES = {
     "ohs_batch_set_gain": (C.c_int, [vp, C.c_float]),
     "ohs_batch_set_conv_plan": (C.c_int, [vp, C.c_int]),
     "ohs_batch_last_conv_plan": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ohs_batch_conv_plan_counts": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+    "ohs_batch_profile_eq_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ohs_node_batch_set_conv_plan": (C.c_int, [vp, C.c_int]),
     "ohs_batch_reset": (C.c_int, [vp]),
     "ohs_batch_process": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),

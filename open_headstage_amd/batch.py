@@ -104,6 +104,12 @@ class BatchProcessor:
         self._check(self._lib.ohs_batch_last_conv_plan(self._h, C.byref(k), C.byref(r)))
         return self.CONV_KERNELS.get(int(k.value), str(k.value)), int(r.value)
 
+    def conv_plan_counts(self, reset: bool = False) -> dict:
+        """convolution launch sequences per kernel family since creation / the last reset read (ohs_batch_conv_plan_counts)"""
+        c = (C.c_uint64 * 6)()
+        self._check(self._lib.ohs_batch_conv_plan_counts(self._h, c, int(bool(reset))))
+        return {self.CONV_KERNELS[k]: int(c[k]) for k in range(1, 6) if c[k]}
+
     def reset(self) -> None:
         self._check(self._lib.ohs_batch_reset(self._h))
 
@@ -178,6 +184,12 @@ class BatchProcessor:
         self._check(self._lib.ohs_batch_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n), C.byref(ne),
                                            C.byref(nc)))
         return a.value, b.value, int(n.value), int(ne.value), int(nc.value)
+
+    def profile_eq_clock(self):
+        """(shader clock in GHz, lifetime in us) of wave 0 of the most recent ring-form EQ launch (ohs_batch_profile_eq_clock)"""
+        g, u = C.c_double(), C.c_double()
+        self._check(self._lib.ohs_batch_profile_eq_clock(self._h, C.byref(g), C.byref(u)))
+        return g.value, u.value
 
     def kernel_bytes(self, n_blocks: int):
         a, b = C.c_uint64(), C.c_uint64()

@@ -193,6 +193,15 @@ int ohs_batch_last_conv_plan(const ohs_batch *b, int *kernel, int *ranges_per_st
     return OHS_OK;
 }
 
+int ohs_batch_conv_plan_counts(ohs_batch *b, uint64_t counts[6], int reset)
+{
+    if (!b || !counts) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    for (int k = 0; k < 6; ++k) counts[k] = b->conv.kernel_calls[k];
+    if (reset)
+        for (int k = 0; k < 6; ++k) b->conv.kernel_calls[k] = 0;
+    return OHS_OK;
+}
+
 int ohs_batch_set_gain(ohs_batch *b, float gain)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
@@ -633,6 +642,30 @@ int ohs_batch_set_profiling(ohs_batch *b, int enable)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     b->profiling = enable != 0;
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->profiling && !b->eq.d_stamps) {
+        HIP_TRY(hipMalloc(&b->eq.d_stamps, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(b->eq.d_stamps, 0, 4 * sizeof(unsigned long long)));
+    } else if (!b->profiling && b->eq.d_stamps) {
+        DeviceWideSection dws;
+        HIP_TRY(hipDeviceSynchronize());        // (a launch in flight may still write them)
+        hipFree(b->eq.d_stamps);
+        b->eq.d_stamps = nullptr;
+    }
+    return OHS_OK;
+}
+
+int ohs_batch_profile_eq_clock(ohs_batch *b, double *shader_ghz, double *wave_us)
+{
+    if (!b || !shader_ghz || !wave_us) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
+    *shader_ghz = 0.0; *wave_us = 0.0;
+    if (!b->eq.d_stamps) return fail(OHS_ERR_INVALID_ARG, "profiling is off (ohs_batch_set_profiling)");
+    HIP_TRY(hipSetDevice(b->device));
+    unsigned long long s[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(s, b->eq.d_stamps, sizeof(s), hipMemcpyDeviceToHost));     // (synchronous: waits for the device)
+    if (s[1] <= s[0] || s[3] <= s[2]) return fail(OHS_ERR_INVALID_ARG, "no ring-form EQ launch has run with profiling on");
+    *wave_us = (double)(s[1] - s[0]) / 100.0;                                   // s_memrealtime: 100 MHz
+    *shader_ghz = (double)(s[3] - s[2]) / ((double)(s[1] - s[0]) * 10.0);       // shader clocks per 10 ns
     return OHS_OK;
 }
 

@@ -511,9 +511,22 @@ int conv_os_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, bool in_p
     return K;
 }
 
+static int conv_launch_impl(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
+                            float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
+                            bool allow_fast, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
                 float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
                 bool allow_fast, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const int rc = conv_launch_impl(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st, allow_fast, ev_start, ev_stop);
+    if (rc == OHS_OK && n_blocks > 0 && c.last_kernel >= 0 && c.last_kernel < 6) c.kernel_calls[c.last_kernel]++;
+    return rc;
+}
+
+static int conv_launch_impl(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs,
+                            float *out, long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st,
+                            bool allow_fast, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     // (ev_start / ev_stop: recorded at the start / completion of the call's launches)
     struct EvScope {        // the paths that do not carry the events in a dispatch: recorded around their launches

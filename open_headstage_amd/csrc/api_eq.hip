@@ -56,7 +56,8 @@ void eq_free(EqState &e)
 {
     if (e.d_state) hipFree(e.d_state);
     if (e.d_stabs) hipFree(e.d_stabs);
-    e.d_state = nullptr; e.d_stabs = nullptr;
+    if (e.d_stamps) hipFree(e.d_stamps);
+    e.d_state = nullptr; e.d_stabs = nullptr; e.d_stamps = nullptr;
 }
 
 bool eq_any_enabled(const EqState &e)
@@ -141,7 +142,7 @@ static int eq_launch_table(EqState &e, const float *coeffs, const unsigned char 
         if (tuning().eq_xcd_n > 0) { xcd_lo = tuning().eq_xcd_lo; xcd_n = tuning().eq_xcd_n; }
         const bool first = p0 == 0, last = p0 + 16 >= on.size();
         hipError_t err = launch_eq_pass(src, out, ss, cs, n, (int)chains, t, nbp, d_state, st, e.exact_specials, e.fp_mode,
-                                        xcd_lo, xcd_n, first ? ev_start : nullptr, last ? ev_stop : nullptr);
+                                        xcd_lo, xcd_n, first ? ev_start : nullptr, last ? ev_stop : nullptr, e.d_stamps);
         if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch: ") + hipGetErrorString(err));
         src = out;
         did = true;

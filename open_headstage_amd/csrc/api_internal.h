@@ -169,6 +169,7 @@ struct ConvState {
     bool lb_cd_valid = false;
     // what served the last convolution launch (ohs_batch_last_conv_plan): OHS_CONV_KERNEL_*, and its ranges per stream
     int last_kernel = 0, last_ranges = 0;
+    unsigned long long kernel_calls[6] = {0, 0, 0, 0, 0, 0};     // conv_launch calls served per family (ohs_batch_conv_plan_counts)
     // ohs_*_set_speakers: what it last loaded into each path (a set_ir from anywhere else forgets it), so that a
     // change of the speaker angles re-loads only the paths whose impulse response really changed
     std::vector<float> spk_ir[4];
@@ -232,6 +233,7 @@ struct EqState {
     EqStreamTable *d_stabs = nullptr;    // [streams]
     bool stabs_dirty = true;
     size_t max_enabled = 0;              // largest number of enabled bands of any stream (as of the last upload scan)
+    unsigned long long *d_stamps = nullptr;     // [4] clock stamps of the last ring launch's wave 0 (ohs_batch_set_profiling)
 };
 
 

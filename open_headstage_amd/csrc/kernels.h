@@ -50,7 +50,9 @@ constexpr int kEqStateSlots = 64;       // = OHS_MAX_EQ_BANDS
 hipError_t launch_eq_pass(const float *in, float *out, long long stream_stride, long long ch_stride,
                           long long n, int n_chains, const EqPassTable &tab, int n_bands, float *state,
                           hipStream_t st, bool exact_specials = false, int fp_mode = 0, int xcd_lo = 0, int xcd_n = 8,
-                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, unsigned long long *stamps = nullptr);
+// (stamps, optional, device memory [4]: wave 0 of a RING launch writes {real-time counter at start, at end, shader-clock
+// counter at start, at end}: s_memrealtime runs at 100 MHz, s_memtime at the shader clock)
 // (ev_start / ev_stop: recorded at the start / completion of THIS launch.  The ring kernel's dispatch carries them
 // itself -- hipExtLaunchKernelGGL -- which spares the queue the marker packets of hipEventRecord and the gap they open
 // between back-to-back launches: 12-13 -> 7 us per chunk boundary of the overlapped batch step with profiling on.)
