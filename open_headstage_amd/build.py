@@ -86,6 +86,9 @@ def _hipcc() -> str:
 def _deps(src: str) -> list[str]:
     deps = [os.path.join(CSRC, src)]
     deps += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc")))
+    exp_dir = os.path.join(CSRC, "experiments")         # (included under -DOHS_EXPERIMENTS only)
+    if os.path.isdir(exp_dir):
+        deps += sorted(os.path.join(exp_dir, f) for f in os.listdir(exp_dir) if f.endswith((".h", ".hpp", ".inc")))
     deps.append(os.path.join(os.path.dirname(HERE), "include", "ohs_hip.h"))
     deps.append(os.path.join(CSRC, "exports.map"))
     deps.append(os.path.abspath(__file__))

@@ -99,7 +99,7 @@ int ohs_batch_set_ir(ohs_batch *b, int path, const float *ir, size_t len)
 }
 
 // node_batch.cpp: the same with the IR already on the batch's device (a broadcast buffer)
-extern "C" int ohs_internal_batch_set_ir_device(ohs_batch *b, int path, const float *d_ir, size_t len)
+extern "C" int ohsint_batch_set_ir_device(ohs_batch *b, int path, const float *d_ir, size_t len)
 {
     if (!b) return fail(OHS_ERR_INVALID_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));

@@ -112,7 +112,7 @@ RtRegistry g_rt_reg[kMaxDevices];
 extern "C" {
 
 // shared with sofa_reader.cpp (not part of the public header)
-void ohs_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+void ohsint_set_error(const char *msg) { g_err = msg ? msg : ""; }
 
 int ohs_version(void) { return (0 << 16) | (1 << 8) | 0; }
 

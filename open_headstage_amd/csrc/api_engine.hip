@@ -236,7 +236,7 @@ void rt_stop(ohs_engine *e)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
             e->rt_enabled = false;
             e->rt_wedged = true;
-            ohs_internal_set_error("resident kernel did not leave within 5 s of its stop request; the engine is unusable until it has");
+            ohsint_set_error("resident kernel did not leave within 5 s of its stop request; the engine is unusable until it has");
             return;
         }
         std::this_thread::yield();
@@ -511,7 +511,7 @@ void ohs_engine_destroy(ohs_engine *e)
             std::lock_guard<std::mutex> lk(r.mu);
             r.running.erase(std::remove(r.running.begin(), r.running.end(), e), r.running.end());
         }
-        ohs_internal_set_error("ohs_engine_destroy: a resident kernel never left; its mailbox, stream and device state were leaked");
+        ohsint_set_error("ohs_engine_destroy: a resident kernel never left; its mailbox, stream and device state were leaked");
         delete e;
         return;
     }

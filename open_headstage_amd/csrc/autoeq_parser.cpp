@@ -8,11 +8,11 @@
 #include <string>
 #include <vector>
 
-extern "C" void ohs_internal_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
+extern "C" void ohsint_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
 
 namespace {
 
-int fail(int code, const std::string &m) { ohs_internal_set_error(m.c_str()); return code; }
+int fail(int code, const std::string &m) { ohsint_set_error(m.c_str()); return code; }
 
 }  // namespace
 

@@ -10,7 +10,7 @@
 namespace ohs_host {
 
 namespace {
-int fail(int code, const std::string &m) { ohs_internal_set_error(m.c_str()); return code; }
+int fail(int code, const std::string &m) { ohsint_set_error(m.c_str()); return code; }
 }  // namespace
 
 // biquad 0.4.2 Coefficients::<f32>::from_params, restated (see oracle/ohs_oracle.h for the caveat

@@ -907,14 +907,9 @@ hipError_t launch_build_cd(const float2 *h0, const float2 *h1, const float2 *h2,
 #define OHS_P1_WAVES 16
 #endif
 // The audio of k_conv_p1 is read once and written once: non-temporal loads / stores (-2.7 % on config 3 without EQ,
-// three interleaved runs each: 0.583 / 0.577 / 0.587 against 0.605 / 0.595 / 0.594 ms; -DOHS_P1_NO_NT = plain accesses)
-#ifndef OHS_P1_NO_NT
+// three interleaved runs each: 0.583 / 0.577 / 0.587 against 0.605 / 0.595 / 0.594 ms with plain accesses)
 #define OHS_P1_LD(p) __builtin_nontemporal_load(p)
 #define OHS_P1_ST(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define OHS_P1_LD(p) (*(p))
-#define OHS_P1_ST(p, v) (*(p) = (v))
-#endif
 // waves per workgroup = per CU, four per SIMD.  LDS: 8.5 KiB of twiddle tables + 16 KiB of C / D + 16 slabs of 8672 B
 // = 163 840 B, every byte of the CU's 160 KiB (the w64 table hides in the padding of the w1024 table's rows,
 // wave_fft.hpp, and a slab ends where its last image does).
@@ -1015,22 +1010,12 @@ __device__ __forceinline__ int p1_chunk_begin(int s, int ck, int n_main, int chu
     return (int)(cum(ck) * n_main / cum(chunks));
 }
 
-#ifdef OHS_P1_STAMPS
-// experiment build only (tools/p1_stamps.py): per-wave life span of the last k_conv_p1 launch, 100 MHz clock
-__device__ unsigned long long g_p1_stamps[4 * 32768];
-__device__ unsigned long long g_p1_clk[2 * 32768];       // shader-clock counter at start / end
-extern "C" int ohs_debug_p1_stamps(unsigned long long *out, size_t n_waves)
-{
-    if (n_waves > 32768) n_waves = 32768;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p1_stamps), n_waves * 4 * sizeof(unsigned long long), 0,
-                                    hipMemcpyDeviceToHost);
-}
-extern "C" int ohs_debug_p1_clk(unsigned long long *out, size_t n_waves)
-{
-    if (n_waves > 32768) n_waves = 32768;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p1_clk), n_waves * 2 * sizeof(unsigned long long), 0,
-                                    hipMemcpyDeviceToHost);
-}
+#if defined(OHS_EXPERIMENTS) && defined(OHS_P1_STAMPS)
+#include "experiments/p1_stamps.inc"        // per-wave life spans and placement (tools/p1_stamps.py)
+#else
+#define OHS_P1_STAMP_ENTRY()
+#define OHS_P1_STAMP_START()
+#define OHS_P1_STAMP_END(gw, lane)
 #endif
 // workgroup index inside the launch's XCD set, or -1 for a workgroup on another XCD (kernels.h: xcd_grid)
 __device__ __forceinline__ long long p1_xcd_block(const ConvP1Args &A)
@@ -1049,9 +1034,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     const long long wg = p1_xcd_block(A);
     if (wg < 0) return;
     ohs_set_fp_mode(A.fp_mode);
-#ifdef OHS_P1_STAMPS
-    const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
-#endif
+    OHS_P1_STAMP_ENTRY();
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float2 *tab = smem;
     float2 *cd = smem + kTabComplex;                    // [2][16][64]
@@ -1059,11 +1042,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     {   // C and D interleaved position by position: cd4[i] = (C[i], D[i]) -- i in the layout the block loop computes in
         float4 *dst = reinterpret_cast<float4 *>(cd);
         for (int i = threadIdx.x; i < kFft; i += 64 * kP1Waves) {
-#ifndef OHS_P1_NATURAL
             const int src = paired_to_natural(i & 63, i >> 6);
-#else
-            const int src = i;
-#endif
             const float2 c = A.CD[src], d = A.CD[kFft + src];
             dst[i] = make_float4(c.x, c.y, d.x, d.y);
         }
@@ -1094,10 +1073,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     }
     const bool own_tail = A.own_tails && ck > 0;
     const int t_first = own_tail ? b0 - 1 : b0;
-#ifdef OHS_P1_STAMPS
-    const unsigned long long stamp_start = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long clk_start = __builtin_amdgcn_s_memtime();
-#endif
+    OHS_P1_STAMP_START();
 
     const float *in_l = A.in + (size_t)s * A.in_stream_stride;
     const float *in_r = in_l + A.in_ch_stride;
@@ -1147,9 +1123,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
     // every level a quarter of the time and all sixteen finish together.
     const int age_rank = wave >> 2;
     int prio_phase = age_rank;
-#if !defined(OHS_P1_NATURAL)
     const PairedPlan plan = paired_plan(lane);
-#endif
     for (int t = t_first; t < b1; ++t) {
         const bool dry = t < b0;            // the block in front of the range: its overlap is all that is wanted
         if (A.prio_mode == 1) {
@@ -1173,23 +1147,13 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
             v[a + 8] = make_float2(0.0f, 0.0f);
         }
         float2 w[16];
-#if defined(OHS_P1_NATURAL)
-        wave_fft_fwd_mirror(v, w, lds, tab, lane);
-        p1_spectral_product(v, w, cd, lane);
-#else
         wave_fft_fwd_paired(v, lds, tab, lane, plan);
         p1_spectral_product_paired(v, w, cd, lane);
-#endif
         // the prefetch of block t + 1 needs no guard except behind the launch's last block, where it re-reads that
         // block (its own frames: in bounds; the values are never used)
         const int adv = (t + 1 < A.n_blocks) ? kBlock : 0;
         pl += adv; pr += adv;
-#if defined(OHS_P1_NATURAL)
-#define OHS_P1_INV(w) wave_fft_inv(w, lds, tab, lane)
-#else
-#define OHS_P1_INV(w) wave_fft_inv_paired(w, lds, tab, lane, plan)
-#endif
-        OHS_P1_INV(w);
+        wave_fft_inv_paired(w, lds, tab, lane, plan);
 #pragma unroll
         for (int a = 0; a < 8; ++a) { xl[a] = OHS_P1_LD(&pl[64 * a]); xr[a] = OHS_P1_LD(&pr[64 * a]); }
         if (!dry) {
@@ -1208,20 +1172,7 @@ __global__ __launch_bounds__(64 * kP1Waves) void k_conv_p1(const ConvP1Args A)
 #pragma unroll
         for (int a = 0; a < 8; ++a) mo[a * 64 + lane] = tail[a];
     }
-#ifdef OHS_P1_STAMPS
-    if (lane == 0 && gw < 32768) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_p1_stamps[4 * gw + 0] = stamp_entry;
-        g_p1_stamps[4 * gw + 1] = stamp_start;
-        g_p1_stamps[4 * gw + 2] = __builtin_amdgcn_s_memrealtime();
-        g_p1_stamps[4 * gw + 3] = ((unsigned long long)xcc << 32) | hw;
-        g_p1_clk[2 * gw + 0] = clk_start;
-        g_p1_clk[2 * gw + 1] = __builtin_amdgcn_s_memtime();
-    }
-#endif
+    OHS_P1_STAMP_END(gw, lane);
 }
 
 // pre-pass, two small kernels that read INPUT frames only -- which is why they run before the main kernel stores over

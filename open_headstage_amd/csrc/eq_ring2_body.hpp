@@ -3,7 +3,7 @@
 // Every file that includes this header MUST be built with -ffp-contract=off: the recurrence rounds each product
 // and sum separately, as the reference does (src/dsp/parametric_eq.rs:116-122).
 //
-// Same arithmetic, lane roles and issue order as round 2's form (eq_ring_v1.hpp, experiments build only); see
+// Same arithmetic, lane roles and issue order as round 2's form (experiments/eq_ring_v1.hpp, experiments build only); see
 // eq_ring_body.hpp and tools/gen_eq_ring2_asm.py for the ring, the two-lane split of a band and the I/O port.  What
 // is new here is the register plan: round 2's asm bodies named v100..v113 as temporaries, which made k_eq_ring a
 // 114-VGPR kernel -- and k_conv_p1 takes 4 x 120 of a SIMD's 512 registers, so an EQ wave and a convolution

@@ -1,6 +1,6 @@
 // eq_ring_body.hpp -- what the forms of the DF2T cascade share: DPP helpers, the hand-counted vmcnt wait, the ring's
 // lane roles and its I/O port (the description of the ring form lives here; eq_ring2_body.hpp is the kernel body built
-// on it, eq_ring_v1.hpp -- experiments build only -- round 2's).
+// on it, experiments/eq_ring_v1.hpp -- experiments build only -- round 2's).
 // Every file that includes this header MUST be built with -ffp-contract=off: the recurrence rounds each
 // product and sum separately, as the reference does (src/dsp/parametric_eq.rs:116-122).
 #pragma once

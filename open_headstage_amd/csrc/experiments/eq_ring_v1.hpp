@@ -5,7 +5,7 @@
 #ifndef OHS_EXPERIMENTS
 #error "eq_ring_v1.hpp belongs to the experiments build"
 #endif
-#include "eq_ring_body.hpp"
+#include "../eq_ring_body.hpp"
 
 namespace ohs {
 

@@ -6,11 +6,11 @@
 
 #include <vector>
 
-extern "C" void ohs_internal_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
+extern "C" void ohsint_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
 struct ohs_batch;
 struct ohs_sofa;
 // api_batch.hip: ohs_batch_set_ir with the impulse response already in memory of the batch's device
-extern "C" int ohs_internal_batch_set_ir_device(ohs_batch *b, int path, const float *d_ir, size_t len);
+extern "C" int ohsint_batch_set_ir_device(ohs_batch *b, int path, const float *d_ir, size_t len);
 
 namespace ohs_host {
 

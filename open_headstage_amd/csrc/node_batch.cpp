@@ -29,7 +29,7 @@
 
 namespace {
 
-int fail(int code, const std::string &m) { ohs_internal_set_error(m.c_str()); return code; }
+int fail(int code, const std::string &m) { ohsint_set_error(m.c_str()); return code; }
 
 struct Rccl {
     void *so = nullptr;
@@ -430,7 +430,7 @@ int ohs_node_batch_set_tables(ohs_node_batch *nb, const float *const irs[4], con
             if (ohs::tuning().node_inject_table_failure_slot == i + 1)     // (experiments build only; 0 in the product)
                 return fail(OHS_ERR_HIP, "injected table failure (node_inject_table_failure_slot)");
             for (int p = 0; p < 4; ++p) {
-                rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], p, nb->d_tab[(size_t)i] + off[p], lens[p]);
+                rc = ohsint_batch_set_ir_device(nb->b[(size_t)i], p, nb->d_tab[(size_t)i] + off[p], lens[p]);
                 if (rc) return rc;
             }
             if (eq_floats) {
@@ -465,7 +465,7 @@ int ohs_node_batch_set_ir(ohs_node_batch *nb, int path, const float *ir, size_t 
         int rc = broadcast_from_host(nb, ir, len);
         if (rc) return rc;
         for (int i = 0; i < nb->n; ++i) {
-            rc = ohs_internal_batch_set_ir_device(nb->b[(size_t)i], path, nb->d_tab[(size_t)i], len);
+            rc = ohsint_batch_set_ir_device(nb->b[(size_t)i], path, nb->d_tab[(size_t)i], len);
             if (rc) return rc;
         }
         return OHS_OK;

@@ -24,9 +24,9 @@
 #include <stdexcept>
 #include <string>
 
-extern "C" void ohs_internal_set_error(const char *msg);
+extern "C" void ohsint_set_error(const char *msg);
 namespace {
-int cfail(int code, const std::string &m) { ohs_internal_set_error(m.c_str()); return code; }
+int cfail(int code, const std::string &m) { ohsint_set_error(m.c_str()); return code; }
 const float kPiF = 3.14159265358979323846f;
 
 // libmysofa's mysofa_s2c / mysofa_c2s (degrees), in f32 as there
@@ -198,7 +198,7 @@ int ohs_sofa_neighbors(const ohs_sofa *s, size_t m, int out[6])
 }
 
 // mysofa_getfilter_float: lookup + mysofa_interpolate
-int ohs_sofa_internal_interpolated(const ohs_sofa *s, float az_deg, float el_deg, float radius_m, float *left, float *right,
+int ohsint_sofa_interpolated(const ohs_sofa *s, float az_deg, float el_deg, float radius_m, float *left, float *right,
                                    size_t capacity, float *delay_left, float *delay_right)
 {
     float c[3] = {az_deg, el_deg, radius_m};

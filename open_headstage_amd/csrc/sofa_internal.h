@@ -19,5 +19,5 @@ struct ohs_sofa {
     mutable std::vector<int> neighbors;      // [M][6] (+phi, -phi, +theta, -theta, +r, -r), -2 = not computed yet, -1 = none
 };
 
-extern "C" int ohs_sofa_internal_interpolated(const ohs_sofa *s, float az_deg, float el_deg, float radius_m, float *left,
+extern "C" int ohsint_sofa_interpolated(const ohs_sofa *s, float az_deg, float el_deg, float radius_m, float *left,
                                               float *right, size_t capacity, float *delay_left, float *delay_right);

@@ -439,9 +439,9 @@ struct Reader {
 
 #include "sofa_internal.h"
 
-extern "C" void ohs_internal_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
+extern "C" void ohsint_set_error(const char *msg);     // api_core.hip: feeds ohs_last_error()
 namespace {
-int sfail(int code, const std::string &m) { ohs_internal_set_error(m.c_str()); return code; }
+int sfail(int code, const std::string &m) { ohsint_set_error(m.c_str()); return code; }
 const double kPi = 3.14159265358979323846264338327950288;
 
 // AES69 spherical (degrees, azimuth counter-clockwise from the front, elevation up) -> Cartesian
@@ -635,7 +635,7 @@ int ohs_sofa_get_hrtf_irs(const ohs_sofa *s, float az_deg, float el_deg, float r
     if (s->N == 0) return sfail(OHS_ERR_PARSE, "Filter length is zero.");      // loader.rs:147-149
     if (s->R < 2) return sfail(OHS_ERR_PARSE, "need two receivers (left, right ear)");
     if (s->flags & OHS_SOFA_INTERPOLATE)
-        return ohs_sofa_internal_interpolated(s, az_deg, el_deg, radius_m, left, right, capacity, delay_left, delay_right);
+        return ohsint_sofa_interpolated(s, az_deg, el_deg, radius_m, left, right, capacity, delay_left, delay_right);
     size_t m = 0;
     int rc = ohs_sofa_nearest(s, az_deg, el_deg, radius_m, &m);
     if (rc) return rc;

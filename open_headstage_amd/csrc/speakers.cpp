@@ -56,7 +56,7 @@ extern "C" {
 int ohs_sofa_speaker_irs(const ohs_sofa *sofa, float az_l, float el_l, float az_r, float el_r, float radius_m, float fs,
                          float *const out[4], size_t capacity, size_t lens[4])
 {
-    if (!sofa || !lens) { ohs_internal_set_error("NULL argument"); return OHS_ERR_INVALID_ARG; }
+    if (!sofa || !lens) { ohsint_set_error("NULL argument"); return OHS_ERR_INVALID_ARG; }
     std::vector<float> irs[4];
     const int rc = ohs_host::speaker_irs(sofa, az_l, el_l, az_r, el_r, radius_m, fs, irs);
     if (rc) return rc;

@@ -17,7 +17,7 @@
 static std::vector<unsigned char> slurp(const char *p) { std::vector<unsigned char> b; FILE *f = fopen(p, "rb"); if (!f) return b; unsigned char t[65536]; size_t r; while ((r = fread(t, 1, sizeof t, f)) > 0) b.insert(b.end(), t, t + r); fclose(f); return b; }
 // the two symbols the parsers take from api_core.hip
 static thread_local std::string g_err;
-extern "C" void ohs_internal_set_error(const char *m) { g_err = m ? m : ""; }
+extern "C" void ohsint_set_error(const char *m) { g_err = m ? m : ""; }
 extern "C" const char *ohs_last_error(void) { return g_err.c_str(); }
 
 // open one file and touch every accessor (what a host does with a file it was handed)

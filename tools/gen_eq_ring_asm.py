@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates open_headstage_amd/csrc/eq_ring_v1_asm.inc: the hand-scheduled inline-asm body of
+"""Generates open_headstage_amd/csrc/experiments/eq_ring_v1_asm.inc: the hand-scheduled inline-asm body of
 k_eq_ring's steady-state GROUP = 8 chunks x 16 systolic steps for the 4 chains of a wave.
 
 The 16 lanes of a DPP row form a RING (see eq_kernels.hip).  Register X: lane L holds the sample that
@@ -105,7 +105,7 @@ def gen(first_step=0, loads=True):
 
 
 if __name__ == "__main__":
-    path = sys.argv[1] if len(sys.argv) > 1 else "open_headstage_amd/csrc/eq_ring_v1_asm.inc"
+    path = sys.argv[1] if len(sys.argv) > 1 else "open_headstage_amd/csrc/experiments/eq_ring_v1_asm.inc"
     name = sys.argv[2] if len(sys.argv) > 2 else "EQ_RING_BODY"
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_eq_ring_asm.py -- do not edit.  128-step EQ ring group bodies (see eq_kernels.hip).\n")
