@@ -29,6 +29,7 @@
 #include "kernels.h"
 #include "wave_fft.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 
@@ -75,8 +76,13 @@ __device__ __forceinline__ bool lb_job(int per_stream, int n_streams, size_t &s,
 static unsigned lb_grid(int per_stream, int n_streams) { return (unsigned)(((n_streams + 7) / 8) * 8 * per_stream); }
 
 // ---------------------------------------------------------------------------------
-// F: one workgroup (4 waves) per (stream, window)
+// F: one workgroup (4 waves) per (stream, run of A.run consecutive windows)
 // ---------------------------------------------------------------------------------
+// A window is [block u - 1, block u]: the workgroup keeps the block it has just transformed as the next window's first half
+// (every input frame is loaded once per run, not twice), and requests the block after that before it starts on the
+// current window -- the loads' latency hides behind a whole transform instead of standing in front of one.
+struct LbBlock { lb_v4f l[2], r[2]; };          // one 2048-frame block: quarter q, frames 1024 q + 4 tid .. + 3, both channels
+
 __global__ __launch_bounds__(256) void k_conv_lb_forward(const ConvLbArgs A)
 {
     ohs_set_fp_mode(A.fp_mode);
@@ -85,102 +91,120 @@ __global__ __launch_bounds__(256) void k_conv_lb_forward(const ConvLbArgs A)
     float2 *X = smem + kTabComplex;
     const int tid = threadIdx.x;
     fill_twiddle_tables(tab, A.tw, tid, 256);
+    const int runs = (A.n_fwd + A.run - 1) / A.run;
     size_t s;
-    int w;
-    if (!lb_job(A.n_fwd, A.n_streams, s, w)) return;
-    const int u = A.u0 + w;
+    int chunk;
+    if (!lb_job(runs, A.n_streams, s, chunk)) return;
+    const int w0 = chunk * A.run, w1 = w0 + A.run < A.n_fwd ? w0 + A.run : A.n_fwd;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
-    // the window's four quarters, four consecutive frames per thread and quarter: z[n2][e] = window sample 4 tid + e + 1024 n2
-    float2 z[4][4];
-    {
-        const float *in_l = A.in + s * A.in_stream_stride, *in_r = in_l + A.in_ch_stride;
-        const long long L2 = 2 * A.xh_len;              // the ring is twice its reach (kernels.h)
-        const float *xh_l = A.xhist ? A.xhist + s * 2 * L2 : nullptr, *xh_r = xh_l ? xh_l + L2 : nullptr;
-        float *xa_l = A.xh_append ? A.xh_append + s * 2 * L2 : nullptr, *xa_r = xa_l ? xa_l + L2 : nullptr;
+    const float *in_l = A.in + s * A.in_stream_stride, *in_r = in_l + A.in_ch_stride;
+    const long long L2 = 2 * A.xh_len;              // the input history is a ring of twice its reach (kernels.h)
+    const float *xh_l = A.xhist ? A.xhist + s * 2 * L2 : nullptr, *xh_r = xh_l ? xh_l + L2 : nullptr;
+    float *xa_l = A.xh_append ? A.xh_append + s * 2 * L2 : nullptr, *xa_r = xa_l ? xa_l + L2 : nullptr;
+    // block b of the segment (frames [2048 b, 2048 b + 2048)): from `in`, from the input history in front of the segment, or
+    // zeros behind its end.  own: the block is loaded as the second half of ITS window -- exactly once per launch -- and
+    // the segment's last xh_cnt frames join the input history then, in the half of the ring no window of this launch
+    // reads (they reach back xh_len at most).  (The source choice is wave-uniform: a quarter of 1024 frames cut at 4 tid
+    // never straddles the segment's start or end, both multiples of 512.)
+    auto load_block = [&](long long b, bool own, LbBlock &o) {
 #pragma unroll
-        for (int n2 = 0; n2 < 4; ++n2) {
-            // (wave-uniform source choice: a quarter never straddles the segment's start or end -- both are multiples of 512
-            // and a quarter of 1024 frames is cut at 4 tid, inside one 512-frame block)
-            long long f0;
-            bool zero = false;
-            if (A.tables_mode) { f0 = (long long)u * kLbBlock + 1024 * n2; zero = n2 >= 2; }
-            else f0 = ((long long)u - 1) * kLbBlock + 1024 * n2;
-            f0 += 4 * tid;
+        for (int q = 0; q < 2; ++q) {
+            const long long f0 = b * kLbBlock + 1024 * q + 4 * tid;
             lb_v4f l = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
-            if (!zero) {
-                if (f0 >= 0) {
-                    if (f0 < A.n_frames) {
-                        l = *reinterpret_cast<const lb_v4f *>(in_l + f0);
-                        r = *reinterpret_cast<const lb_v4f *>(in_r + f0);
-                        // the window's second half is the block's own frames: the last xh_cnt of the segment join the input
-                        // history, in the half of the ring no window of this launch reads (they reach back xh_len at most)
-                        const long long fa = f0 - (A.n_frames - A.xh_cnt);
-                        if (xa_l && n2 >= 2 && fa >= 0) {
-                            const long long pos = (A.xh_head + fa) % L2;
-                            *reinterpret_cast<lb_v4f *>(xa_l + pos) = l;
-                            *reinterpret_cast<lb_v4f *>(xa_r + pos) = r;
-                        }
+            if (f0 >= 0) {
+                if (f0 < A.n_frames) {
+                    l = *reinterpret_cast<const lb_v4f *>(in_l + f0);
+                    r = *reinterpret_cast<const lb_v4f *>(in_r + f0);
+                    const long long fa = f0 - (A.n_frames - A.xh_cnt);
+                    if (own && xa_l && fa >= 0) {
+                        const long long pos = (A.xh_head + fa) % L2;
+                        *reinterpret_cast<lb_v4f *>(xa_l + pos) = l;
+                        *reinterpret_cast<lb_v4f *>(xa_r + pos) = r;
                     }
-                } else if (xh_l && A.xh_len + f0 >= 0) {
-                    long long idx = A.xh_head + f0;             // (head and the ring's length are multiples of 512: a
-                    idx = idx < 0 ? idx + L2 : idx;             //  4-frame group does not straddle the wrap)
-                    l = *reinterpret_cast<const lb_v4f *>(xh_l + idx);
-                    r = *reinterpret_cast<const lb_v4f *>(xh_r + idx);
                 }
+            } else if (xh_l && A.xh_len + f0 >= 0) {
+                long long idx = A.xh_head + f0;             // (head and the ring's length are multiples of 512: a
+                idx = idx < 0 ? idx + L2 : idx;             //  4-frame group does not straddle the wrap)
+                l = *reinterpret_cast<const lb_v4f *>(xh_l + idx);
+                r = *reinterpret_cast<const lb_v4f *>(xh_r + idx);
             }
-            z[n2][0] = make_float2(l.x, r.x); z[n2][1] = make_float2(l.y, r.y);
-            z[n2][2] = make_float2(l.z, r.z); z[n2][3] = make_float2(l.w, r.w);
+            o.l[q] = l; o.r[q] = r;
         }
-    }
-    // radix-4 over the quarters, then w4096^(n1 c): class c of sample n1 = 4 tid + e
+    };
+    const LbBlock zero = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+    // tables mode: window i = [block i, 2048 zeros]; else window u = [block u - 1, block u]
+    LbBlock first, second, next = zero;
+    if (A.tables_mode) { load_block(A.u0 + w0, false, first); second = zero; }
+    else { load_block((long long)A.u0 + w0 - 1, false, first); load_block((long long)A.u0 + w0, true, second); }
+    // w4096^(n1 c) for the thread's four samples n1 = 4 tid + e, c = 1 .. 3
     lb_v4f tw[3][2];
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
         const lb_v4f *t4 = reinterpret_cast<const lb_v4f *>(A.tw4096 + cc * 1024) + 2 * tid;
         tw[cc][0] = t4[0]; tw[cc][1] = t4[1];
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        dft4<false>(z[0][e], z[1][e], z[2][e], z[3][e]);
-#pragma unroll
-        for (int cc = 1; cc < 4; ++cc) {
-            const lb_v4f t = tw[cc - 1][e >> 1];
-            const float2 wv = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
-            z[cc][e] = cmul(z[cc][e], wv);
-        }
-    }
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lds_st(&X[kLbSlab * cc + 264 * e + tid], z[cc][e]);      // X14: lb_x14(cc, 4 tid + e)
-    __syncthreads();
-
-    // wave c: the 1024-point transform of class c (time layout: lane m, register a holds sample 64 a + m)
     float2 *slab = X + kLbSlab * c;
-    float2 v[16];
-    {
-        const int base = 264 * (lane & 3) + (lane >> 2);            // lb_x14(c, 64 a + lane) = slab + base + 16 a
-#pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = lds_ld(&slab[base + 16 * a]);
-        wave_lds_sync();
-    }
-    wave_fft_fwd(v, slab, tab, lane);           // bin layout: register 4 r + j holds k1 = 4 lane + j + 256 r, i.e. bin 4 k1 + c
-    __syncthreads();                            // every wave is done with its slab: the slabs become the X23 image
-#pragma unroll
-    for (int R = 0; R < 16; ++R) {
-        const int k = 16 * lane + 4 * (R & 3) + c + 1024 * (R >> 2);
-        lds_st(&X[lb_x23(k)], v[R]);
-    }
-    __syncthreads();
-    // pairs out: slot q = tid + 256 p
-    const long long sl = (A.ring_base + u) % A.ring_cap;
-    float4 *dst = A.ring + (s * (size_t)A.ring_cap + (size_t)sl) * kLbPairs;
     const int xb = 17 * (tid >> 4) + (tid & 15);                    // lb_x23(tid + 256 p) = xb + 272 p (+ plane)
+
+    for (int w = w0; w < w1; ++w) {
+        const int u = A.u0 + w;
+        if (w + 1 < w1) load_block((long long)u + 1, !A.tables_mode, next);       // the block the next window brings in
+        // z[n2][e] = window sample 4 tid + e + 1024 n2
+        float2 z[4][4];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const float2 a = lds_ld(&X[xb + 272 * p]), b = lds_ld(&X[kLbPlane + xb + 272 * p]);
-        dst[tid + 256 * p] = make_float4(a.x, a.y, b.x, b.y);
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z[q][e] = make_float2(first.l[q][e], first.r[q][e]);
+                z[2 + q][e] = make_float2(second.l[q][e], second.r[q][e]);
+            }
+        // radix-4 over the quarters, then w4096^(n1 c): class c of sample n1 = 4 tid + e
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dft4<false>(z[0][e], z[1][e], z[2][e], z[3][e]);
+#pragma unroll
+            for (int cc = 1; cc < 4; ++cc) {
+                const lb_v4f t = tw[cc - 1][e >> 1];
+                const float2 wv = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
+                z[cc][e] = cmul(z[cc][e], wv);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds_st(&X[kLbSlab * cc + 264 * e + tid], z[cc][e]);      // X14: lb_x14(cc, 4 tid + e)
+        __syncthreads();
+
+        // wave c: the 1024-point transform of class c (time layout: lane m, register a holds sample 64 a + m)
+        float2 v[16];
+        {
+            const int base = 264 * (lane & 3) + (lane >> 2);            // lb_x14(c, 64 a + lane) = slab + base + 16 a
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = lds_ld(&slab[base + 16 * a]);
+            wave_lds_sync();
+        }
+        wave_fft_fwd(v, slab, tab, lane);           // bin layout: register 4 r + j holds k1 = 4 lane + j + 256 r, i.e. bin 4 k1 + c
+        __syncthreads();                            // every wave is done with its slab: the slabs become the X23 image
+#pragma unroll
+        for (int R = 0; R < 16; ++R) {
+            const int k = 16 * lane + 4 * (R & 3) + c + 1024 * (R >> 2);
+            lds_st(&X[lb_x23(k)], v[R]);
+        }
+        __syncthreads();
+        // pairs out: slot q = tid + 256 p
+        const long long sl = (A.ring_base + u) % A.ring_cap;
+        float4 *dst = A.ring + (s * (size_t)A.ring_cap + (size_t)sl) * kLbPairs;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float2 a = lds_ld(&X[xb + 272 * p]), b = lds_ld(&X[kLbPlane + xb + 272 * p]);
+            dst[tid + 256 * p] = make_float4(a.x, a.y, b.x, b.y);
+        }
+        if (w + 1 < w1) {
+            __syncthreads();                        // the X23 image has been read: the next window's X14 image may be written
+            if (A.tables_mode) first = next;
+            else { first = second; second = next; }
+        }
     }
 }
 
@@ -418,7 +442,27 @@ hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st)
     static std::atomic<unsigned long long> lds_ok{0};
     const hipError_t e = lb_allow_lds(reinterpret_cast<const void *>(k_conv_lb_forward), lds_ok);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_conv_lb_forward, dim3(lb_grid(a.n_fwd, a.n_streams)), dim3(256), kLbLdsBytes, st, a);
+    // windows per workgroup: as few as fill the chip's workgroup slots ONCE (three per CU: 42.5 KiB of LDS each) -- a
+    // run's first window loads one block more than the others, and a second round of workgroups would start cold
+    ConvLbArgs f = a;
+    {
+        static std::atomic<int> cus_cached{0};
+        int cus = cus_cached.load(std::memory_order_relaxed);
+        if (cus == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            cus_cached.store(cus, std::memory_order_relaxed);
+        }
+        const long long slots = 3ll * cus, windows = (long long)a.n_streams * a.n_fwd;
+        long long run = (windows + slots - 1) / slots;
+        run = std::max<long long>(1, std::min<long long>(run, 16));
+        if (a.run > 0) run = a.run;             // (a caller's choice: tests)
+        f.run = (int)std::min<long long>(run, a.n_fwd);
+    }
+    const int runs = (f.n_fwd + f.run - 1) / f.run;
+    hipLaunchKernelGGL(k_conv_lb_forward, dim3(lb_grid(runs, f.n_streams)), dim3(256), kLbLdsBytes, st, f);
     return hipGetLastError();
 }
 

@@ -301,6 +301,7 @@ struct ConvLbArgs {
     int n_streams;
     long long n_frames;         // valid frames of `in` from the segment's start; beyond: zeros (in) / not stored (out)
     int u0, n_fwd;              // F: windows u0 .. u0 + n_fwd - 1 (u < 1 reaches into xhist)
+    int run;                    // F: consecutive windows per workgroup; 0 = the launcher's choice
     int n_big;                  // MI: output blocks 0 .. n_big - 1
     int P2pad;                  // 2048-tap partitions, padded to a multiple of 4 (zero tables beyond the real count)
     float4 *ring;               // [stream][ring_cap][2048]: slot q = (Z[q], Z[4096 - q]), slot 0 = (Z[0], Z[2048])
