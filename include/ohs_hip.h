@@ -350,8 +350,9 @@ int  ohs_batch_set_gain(ohs_batch *b, float gain);
  *      any sequence of calls under any sequence of plans is one continuous signal.
  *   0  the library's choice (default).  One partition: plan 2 for calls of 48 blocks or more on 512 streams or more -- on
  *      256 or more when the call is out of place and the EQ is off --, plan 1 otherwise (at BASELINE configs[2] the
- *      convolution hides under the EQ either way, and the block-512 bits stay as recorded).  Longer responses: plan 2 for
- *      calls of 16 blocks or more that are at least half as long as the response, plan 1 otherwise.
+ *      convolution hides under the EQ either way, and the block-512 bits stay as recorded).  Longer responses (8 partitions
+ *      or more): plan 2 for every call -- its 2048-frame blocks sit on the stream's absolute grid, so calls of any length
+ *      continue one another.
  * The single-stream engine is always served by the reference blocking. */
 int  ohs_batch_set_conv_plan(ohs_batch *b, int plan);
 /* What served the handle's most recent convolution launch (of the last time chunk, when a call is cut into several): the

@@ -246,13 +246,15 @@ int conv_lb_after_set_ir(ConvState &c, hipStream_t st)
     return OHS_OK;
 }
 
-// ohs_batch_set_conv_plan(0) for long responses: the block-2048 plan costs a call the input-history copy and, when the call
-// does not continue the previous one's window grid, P2pad - 1 warm-up transforms per stream; it pays from calls that are a
-// fair fraction of the response long
+// ohs_batch_set_conv_plan(0) for long responses: the block-2048 plan for every call of an object whose longest response has
+// kLbMinP partitions or more.  Its windows sit on the stream's absolute grid, so a call of any length -- the plugin's
+// 1024-frame block included -- continues the ring the previous call left (one or two windows to transform, no warm-up), and
+// it beats the block-512 kernels at every call length measured (profiles/r05_short_calls_*.jsonl: 64 streams x 16 384 taps,
+// 2-block calls 26 vs 35 us even WITH a warm-up per call; 256-block calls 0.138 vs 0.25 ms).
 bool conv_plan_auto_is_lb(size_t S, long long n_blocks, int Pmax)
 {
-    (void)S;
-    return Pmax >= kLbMinP && n_blocks >= 16 && 2 * n_blocks >= Pmax;
+    (void)S; (void)n_blocks;
+    return Pmax >= kLbMinP;
 }
 
 // segment length of a block-2048 launch sequence, in blocks of 2048: keeps the ring around 128 MiB
@@ -289,7 +291,7 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
         if (c.irl_len < (long long)P2pad * kLbBlock) return fail(OHS_ERR_HIP, "block-2048 plan: impulse responses not stored");
         ConvLbArgs t = a;
         t.in = c.d_irl; t.in_stream_stride = 2 * c.irl_len; t.in_ch_stride = c.irl_len;
-        t.out = nullptr; t.n_streams = 2; t.n_frames = c.irl_len;
+        t.out = nullptr; t.n_streams = 2; t.io_frame0 = 0; t.io_frames = c.irl_len;
         t.u0 = 0; t.n_fwd = P2pad; t.ring = c.d_lb_ab; t.ring_cap = P2pad; t.ring_base = 0; t.tables_mode = 1;
         t.fp_mode = 0;      // (tables are built in IEEE arithmetic, like k_ir_spectrum's)
         hipError_t e = launch_conv_lb_forward(t, st);
@@ -299,7 +301,7 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     }
     const long long SEG = lb_segment_blocks(c.S);
     const long long frames_total = (long long)n_blocks * BS;
-    const long long nbig_total = (frames_total + kLbBlock - 1) / kLbBlock;
+    const long long nbig_total = ((long long)c.cnt * BS + frames_total - 1) / kLbBlock - (long long)c.cnt * BS / kLbBlock + 1;
     const int cap_need = (int)(std::min(SEG, (nbig_total + kLbTile - 1) / kLbTile * kLbTile) + P2pad - 1);
     if (cap_need > c.lb_ring_cap) {
         DeviceWideSection dws;
@@ -313,37 +315,37 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     a.ring = c.d_lb_ring; a.ring_cap = c.lb_ring_cap;
     a.in_stream_stride = in_ss; a.in_ch_stride = in_cs; a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
     a.xh_len = c.xh_len;
-    const long long abs0 = (long long)c.cnt * BS;
+    // The call's frames on the stream's absolute grid of 2048-frame blocks: [abs0, absE) touches blocks Ba .. Bl.  Segments of
+    // at most SEG blocks; the first may start inside a block (its earlier frames come from the input history and its
+    // output frames in front of the call are not stored), the last may end inside one (zeros behind the call; recomputed by
+    // the next call).
+    const long long abs0 = (long long)c.cnt * BS, absE = abs0 + frames_total;
+    const long long Ba = abs0 / kLbBlock, Bl = (absE - 1) / kLbBlock;
     int tiles_last = 0;
-    for (long long off = 0; off < frames_total; off += SEG * kLbBlock) {
-        const long long segf = std::min<long long>(SEG * kLbBlock, frames_total - off);
-        const int n_big = (int)((segf + kLbBlock - 1) / kLbBlock);
-        // does this segment continue the window grid the ring holds?  (same absolute frame, enough windows behind it)
-        const bool cont = c.lb_valid >= P2pad - 1 && c.lb_frame == abs0 + off;
+    for (long long Bs = Ba; Bs <= Bl; Bs += SEG) {
+        const long long Be = std::min<long long>(Bs + SEG, Bl + 1);
+        const int n_big = (int)(Be - Bs);
+        const long long f_lo = std::max(abs0, Bs * kLbBlock), f_hi = std::min(absE, Be * kLbBlock);    // the call's frames in this segment
+        // does the ring hold the complete windows in front of this segment?
+        const bool cont = c.lb_end == Bs && c.lb_valid >= P2pad - 1;
         const int warm = cont ? 0 : P2pad - 1;
-        if (!cont) c.lb_next = 4ll * c.lb_ring_cap;         // (any base that keeps every slot index positive)
-        a.in = in + off; a.out = out + off;
+        a.in = in + (f_lo - abs0); a.out = out + (f_lo - abs0);
+        a.io_frame0 = f_lo - Bs * kLbBlock; a.io_frames = f_hi - f_lo;
         // (the forward kernel appends the segment's last frames to the input history itself -- before the inverse kernel may
         // overwrite them in place --, into the half of the ring its windows do not read)
-        const long long xcnt = std::min<long long>(segf, c.xh_len);
+        const long long xcnt = std::min<long long>(a.io_frames, c.xh_len);
         a.xhist = c.d_xhist; a.xh_append = c.d_xhist; a.xh_head = c.xh_head; a.xh_cnt = xcnt;
-        a.n_frames = segf;
         a.u0 = -warm; a.n_fwd = warm + n_big; a.n_big = n_big;
-        a.ring_base = c.lb_next;
+        a.ring_base = Bs + 4ll * c.lb_ring_cap;
         hipError_t e = launch_conv_lb_forward(a, st);
         if (e == hipSuccess) {
             c.xh_head = (c.xh_head + xcnt) % (2 * c.xh_len);
             e = launch_conv_lb_mac_inverse(a, st);
         }
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-2048 launch: ") + hipGetErrorString(e));
-        c.lb_next += n_big;
-        if (c.lb_next > (1ll << 40)) c.lb_valid = 0;        // (rebase long before the index could overflow)
-        if (segf % kLbBlock == 0) {
-            c.lb_valid = std::min<long long>((cont ? c.lb_valid : warm) + n_big, c.lb_ring_cap);
-            c.lb_frame = abs0 + off + segf;
-        } else {
-            c.lb_valid = 0;     // the last window was padded with zeros: the next call does not continue this grid
-        }
+        const long long complete = f_hi / kLbBlock - Bs;          // blocks of this segment whose last frame is known
+        c.lb_valid = std::min<long long>((cont ? c.lb_valid : warm) + complete, c.lb_ring_cap - 1);
+        c.lb_end = Bs + complete;
         tiles_last = (n_big + kLbTile - 1) / kLbTile;
     }
     c.xh_valid = std::min(c.xh_len, c.xh_valid + frames_total);

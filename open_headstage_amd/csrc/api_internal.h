@@ -161,9 +161,12 @@ struct ConvState {
     bool lb_lazy = false;
     float4 *d_lb_ring = nullptr;    // [S][lb_ring_cap][2048] window spectra, pair layout
     int lb_ring_cap = 0;
-    long long lb_next = 0;          // ring index of the next window
-    long long lb_valid = 0;         // windows lb_next - lb_valid .. lb_next - 1 are in the ring ...
-    long long lb_frame = -1;        // ... and the block of window lb_next starts at this absolute frame (cnt * 512)
+    // The windows sit on the stream's ABSOLUTE grid (block B = frames [2048 B, 2048 B + 2048) counted from the last reset):
+    // window B lives in ring slot (B + 4 lb_ring_cap) % lb_ring_cap.  A call may start and end anywhere on the 512 grid: the
+    // block it starts in is recomputed (its earlier frames come from the input history), the block it ends in is computed
+    // with zeros for the frames to come and recomputed by the next call -- only windows of COMPLETE blocks stay valid.
+    long long lb_end = 0;           // windows lb_end - lb_valid .. lb_end - 1 (complete blocks) are in the ring
+    long long lb_valid = 0;
     float4 *d_lb_cd = nullptr, *d_lb_ab = nullptr;          // [P2pad][2][2048] tables; [2][P2pad][2048] scratch for building them
     int lb_p2pad = 0;               // what d_lb_cd / d_lb_ab are allocated for
     bool lb_cd_valid = false;

@@ -102,21 +102,21 @@ __global__ __launch_bounds__(256) void k_conv_lb_forward(const ConvLbArgs A)
     const long long L2 = 2 * A.xh_len;              // the input history is a ring of twice its reach (kernels.h)
     const float *xh_l = A.xhist ? A.xhist + s * 2 * L2 : nullptr, *xh_r = xh_l ? xh_l + L2 : nullptr;
     float *xa_l = A.xh_append ? A.xh_append + s * 2 * L2 : nullptr, *xa_r = xa_l ? xa_l + L2 : nullptr;
-    // block b of the segment (frames [2048 b, 2048 b + 2048)): from `in`, from the input history in front of the segment, or
-    // zeros behind its end.  own: the block is loaded as the second half of ITS window -- exactly once per launch -- and
-    // the segment's last xh_cnt frames join the input history then, in the half of the ring no window of this launch
-    // reads (they reach back xh_len at most).  (The source choice is wave-uniform: a quarter of 1024 frames cut at 4 tid
-    // never straddles the segment's start or end, both multiples of 512.)
+    // block b of the grid (frames [2048 b, 2048 b + 2048)): from `in` (frames [io_frame0, io_frame0 + io_frames)), from the
+    // input history in front of that, or zeros behind it.  own: the block is loaded as the second half of ITS window --
+    // exactly once per launch -- and the buffer's last xh_cnt frames join the input history then, in the half of the ring
+    // no window of this launch reads (they reach back xh_len at most).  (The source choice is wave-uniform: a quarter of
+    // 1024 frames cut at 4 tid never straddles the buffer's start or end, both multiples of 512.)
     auto load_block = [&](long long b, bool own, LbBlock &o) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const long long f0 = b * kLbBlock + 1024 * q + 4 * tid;
+            const long long f0 = b * kLbBlock + 1024 * q + 4 * tid - A.io_frame0;      // relative to the buffer's first frame
             lb_v4f l = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
             if (f0 >= 0) {
-                if (f0 < A.n_frames) {
+                if (f0 < A.io_frames) {
                     l = *reinterpret_cast<const lb_v4f *>(in_l + f0);
                     r = *reinterpret_cast<const lb_v4f *>(in_r + f0);
-                    const long long fa = f0 - (A.n_frames - A.xh_cnt);
+                    const long long fa = f0 - (A.io_frames - A.xh_cnt);
                     if (own && xa_l && fa >= 0) {
                         const long long pos = (A.xh_head + fa) % L2;
                         *reinterpret_cast<lb_v4f *>(xa_l + pos) = l;
@@ -362,11 +362,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
             ol[0][e] = x2.x * A.gain; orr[0][e] = x2.y * A.gain;
             ol[1][e] = x3.x * A.gain; orr[1][e] = x3.y * A.gain;
         }
-        const long long f0 = ((long long)tb0 + t) * kLbBlock + 4 * tid;
+        const long long f0 = ((long long)tb0 + t) * kLbBlock + 4 * tid - A.io_frame0;      // relative to the buffer's first frame
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const long long f = f0 + 1024 * h;
-            if (f < A.n_frames) {
+            if (f >= 0 && f < A.io_frames) {
                 *reinterpret_cast<lb_v4f *>(out_l + f) = ol[h];
                 *reinterpret_cast<lb_v4f *>(out_r + f) = orr[h];
             }
@@ -430,8 +430,8 @@ static bool lb_args_ok(const ConvLbArgs &a)
          reinterpret_cast<uintptr_t>(a.xh_append)) & 15)
         return false;
     if (a.xhist && (a.xh_len <= 0 || (a.xh_len & 511) || (a.xh_head & 511) || a.xh_head < 0 || a.xh_head >= 2 * a.xh_len)) return false;
-    if (a.xh_append && (a.xh_append != a.xhist || a.xh_cnt < 0 || a.xh_cnt > a.xh_len || a.xh_cnt > a.n_frames || (a.xh_cnt & 511))) return false;
-    if (a.n_frames < 0 || (a.n_frames & 511)) return false;
+    if (a.xh_append && (a.xh_append != a.xhist || a.xh_cnt < 0 || a.xh_cnt > a.xh_len || a.xh_cnt > a.io_frames || (a.xh_cnt & 511))) return false;
+    if (a.io_frames < 0 || (a.io_frames & 511) || a.io_frame0 < 0 || (a.io_frame0 & 511)) return false;
     return true;
 }
 

@@ -293,13 +293,18 @@ struct ConvLbArgs {
     long long in_stream_stride, in_ch_stride;       // floats; multiples of 4 (16-byte accesses)
     long long out_stream_stride, out_ch_stride;
     // the input history: [stream][2][2 xh_len], a ring of TWICE the reach xh_len: the frame k frames in front of the segment at
-    // (xh_head - k) mod 2 xh_len, k <= xh_len; may be NULL.  xh_append != NULL: F also appends the segment's last
-    // xh_cnt = min(n_frames, xh_len) frames at xh_head .. (the half of the ring nobody reads), the host then advances the head
+    // (xh_head - k) mod 2 xh_len, k <= xh_len -- "the segment" here is its first buffer frame, io_frame0 --; may be NULL.
+    // xh_append != NULL: F also appends the buffer's last xh_cnt = min(io_frames, xh_len) frames at xh_head .. (the half of
+    // the ring nobody reads), the host then advances the head
     const float *xhist;
     float *xh_append;
     long long xh_len, xh_head, xh_cnt;  // multiples of 512
     int n_streams;
-    long long n_frames;         // valid frames of `in` from the segment's start; beyond: zeros (in) / not stored (out)
+    // Frames are counted from the segment's grid origin (window u = frames [(u - 1) 2048, (u + 1) 2048)).  The buffers `in` /
+    // `out` hold the frames [io_frame0, io_frame0 + io_frames): earlier ones come from the input history (F) / are not
+    // stored (MI: a call that starts inside a 2048-frame block of the stream's absolute grid recomputes that block and
+    // stores its new frames only); later ones are zeros (F) / not stored (MI).  Multiples of 512.
+    long long io_frame0, io_frames;
     int u0, n_fwd;              // F: windows u0 .. u0 + n_fwd - 1 (u < 1 reaches into xhist)
     int run;                    // F: consecutive windows per workgroup; 0 = the launcher's choice
     int n_big;                  // MI: output blocks 0 .. n_big - 1

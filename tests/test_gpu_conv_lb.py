@@ -35,8 +35,8 @@ def _make(ohs, S, irs, plan, gain=1.0):
 
 @pytest.mark.parametrize("taps,blocks", [(16384, [9, 4, 7, 8, 8, 1, 2, 40]), (4097, [3, 5, 16, 16]), (3600, [6, 6, 12])])
 def test_block_2048_plan_matches_the_oracle_and_f64(oracle, taps, blocks):
-    """call lengths of every remainder modulo 4 blocks (a ragged last 2048-block is padded with zeros and the next call
-    starts a new window grid from the input history), aligned calls that continue the ring, in place"""
+    """call lengths of every remainder modulo 4 blocks: the 2048-frame blocks sit on the stream's absolute grid, a call that ends
+    inside one computes it with zeros behind its frames and the next call recomputes it from the input history; in place"""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
@@ -61,6 +61,37 @@ def test_block_2048_plan_matches_the_oracle_and_f64(oracle, taps, blocks):
     a, r = rms_err(g[0], 0.9 * np.stack([yl, yr]))
     print(f"block-2048 plan vs f64 direct convolution, {taps} taps: {r:.2e}")
     assert r <= 1e-6
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_call_lengths_continue_one_another(oracle, seed):
+    """calls of 1 .. 9 blocks in random order (the plugin's 1024-frame block is 2): every call starts and ends somewhere on the
+    512 grid inside the absolute grid's 2048-frame blocks, continues the ring of window spectra the previous call left and
+    recomputes the block it starts in; a reset and a plan-1 call in between force a fresh start from the input history"""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    rng = np.random.default_rng(seed)
+    S, taps = 2, int(rng.integers(3600, 9000))
+    irs = synth.hrir_set(taps)
+    bp = _make(ohs, S, irs, 0)
+    engs = _oracle_engines(oracle, irs, S)
+    for k in range(34):
+        nb = int(rng.integers(1, 10))
+        if k == 20:
+            bp.set_conv_plan(1)
+        if k == 21:
+            bp.set_conv_plan(0)
+        if k == 27:
+            bp.reset()
+            engs = _oracle_engines(oracle, irs, S)
+        x = synth.white_noise(range(1000 * seed + 10 * k, 1000 * seed + 10 * k + S), nb * 512)
+        xt = torch.from_numpy(x).cuda()
+        y = (bp.process(xt, out=xt) if k % 3 == 0 else bp.process(xt)).cpu().numpy()
+        assert bp.last_conv_plan()[0] == ("block512_tp" if k == 20 else "block2048"), (k, bp.last_conv_plan())
+        for s in range(S):
+            ref = np.stack(engs[s].process_block(x[s, 0], x[s, 1]))
+            assert_parity(y[s], ref, f"seed {seed}, call {k} ({nb} blocks), stream {s}")
 
 
 def test_paths_of_different_lengths_and_a_muted_path(oracle):
@@ -136,7 +167,7 @@ def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
     #      (plan, blocks, kernel family expected of the call's last launch)
     seq = [(2, 20, "block2048"), (1, 24, "block512_tp"), (2, 8, "block2048"), (1, 2, "block512_tp"), (2, 16, "block2048"),
            (2, 16, "block2048"),        # <- set_ir(path 2) in front of this one: served by block 512 (gated), see below
-           (2, 20, "block2048"), (0, 3, "block512_tp"), (0, 40, "block2048")]
+           (2, 20, "block2048"), (0, 3, "block2048"), (0, 40, "block2048")]
     for k, (plan, nb, want) in enumerate(seq):
         if k == 5:
             h = synth.hrir_set(6000)[2]
@@ -183,8 +214,8 @@ def test_the_library_picks_block_2048_for_long_calls_on_long_responses():
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
     dev = torch.device("cuda:0")
-    for taps, nb, want in ((16384, 64, "block2048"), (16384, 12, "block512_tp"), (16384, 2, "block512_tp"),
-                           (3000, 64, "block512_tp"), (4096, 16, "block2048")):
+    for taps, nb, want in ((16384, 64, "block2048"), (16384, 12, "block2048"), (16384, 2, "block2048"),
+                           (3000, 64, "block512_tp"), (3000, 2, "block512_tp"), (4096, 16, "block2048")):
         bp = _make(ohs, 4, synth.hrir_set(taps), 0)
         x = synth.white_noise_torch(3, 4, nb * 512, dev)
         bp.process(x)
