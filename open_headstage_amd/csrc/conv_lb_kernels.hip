@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
         __syncthreads();        // every wave has its bins: the slabs are transform scratch again
         wave_fft_inv(v, slab, tab, lane);       // time layout: register a holds y_c[64 a + lane]
         {
-            const int base = 264 * (lane & 3) + (lane >> 2);
+            // X14 with a row pitch of 260 here (the forward kernel's is 264): this side WRITES with the strided pattern, and
+            // ds_write_b64 goes by 16 lanes over 32 banks -- 2 x 260 = 8 mod 32 spreads a group's four rows, 2 x 264 = 16 does not
+            const int base = 260 * (lane & 3) + (lane >> 2);
 #pragma unroll
             for (int a = 0; a < 16; ++a) lds_st(&slab[base + 16 * a], v[a]);
         }
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
         for (int e = 0; e < 4; ++e) {
             float2 y[4];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) y[cc] = lds_ld(&X[kLbSlab * cc + 264 * e + tid]);
+            for (int cc = 0; cc < 4; ++cc) y[cc] = lds_ld(&X[kLbSlab * cc + 260 * e + tid]);
 #pragma unroll
             for (int cc = 1; cc < 4; ++cc) {
                 const lb_v4f tt = tw[cc - 1][e >> 1];

@@ -94,6 +94,41 @@ def test_random_call_lengths_continue_one_another(oracle, seed):
             assert_parity(y[s], ref, f"seed {seed}, call {k} ({nb} blocks), stream {s}")
 
 
+def test_short_calls_through_the_block_512_kernels_incl_a_per_path_set_ir(oracle):
+    """calls of 1, 2 and 3 blocks on a long response are served by the time-parallel block-512 kernels
+    (MAC tiles of 4 blocks) when the reference blocking is asked for -- until round 5 they took the sequential kernel.
+    Sequences of such calls, a per-path set_ir in mid-stream (short calls right behind it go through the sequential kernel,
+    which carries the per-path gates, until a call reaches past every old block), and long calls in between."""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    S, taps = 4, 16384
+    irs = synth.hrir_set(taps)
+    bp = _make(ohs, S, irs, 1)
+    engs = _oracle_engines(oracle, irs, S)
+    seq = [1, 2, 3, 2, 1, 40, 2, 2, 3, 1, "set_ir", 2, 1, 3, 36, 2, 3, 1]
+    k = 0
+    for item in seq:
+        if item == "set_ir":
+            h = synth.hrir_set(9000)[1]
+            bp.set_ir(1, h)
+            for e in engs:
+                e.set_ir(1, h)
+            continue
+        nb = item
+        x = synth.white_noise(range(7000 + 10 * k, 7000 + 10 * k + S), nb * 512)
+        y = bp.process(torch.from_numpy(x).cuda()).cpu().numpy()
+        fam = bp.last_conv_plan()[0]
+        assert fam in ("block512_tp", "sequential"), (k, fam)
+        if k < 10:
+            assert fam == "block512_tp", (k, nb, fam)       # every call in front of the set_ir, the 1-block ones included
+        for s in range(S):
+            ref = np.stack(engs[s].process_block(x[s, 0], x[s, 1]))
+            assert_parity(y[s], ref, f"call {k} ({nb} blocks, {fam}), stream {s}")
+        k += 1
+    assert bp.last_conv_plan()[0] == "block512_tp"
+
+
 def test_paths_of_different_lengths_and_a_muted_path(oracle):
     import torch
     import open_headstage_amd as ohs

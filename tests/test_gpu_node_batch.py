@@ -187,6 +187,51 @@ def _rehearsal_pair(ohs, synth, exp_tuning, slots, S, taps=512):
     return nb, bp, (irs, coeffs, enabled)
 
 
+def test_default_plan_follows_the_streams_per_device_so_shards_agree_to_rounding_not_bit_for_bit(ohs, synth, exp_tuning):
+    """ADVICE r04 / the header note of ohs_node_batch_process_host: with the library's own plan choice (plan 0) an UNSHARDED
+    batch of 512 streams takes the hop-1536 plan for calls of 48 blocks or more (out of place, EQ off: from 256 streams),
+    its shards of 256 streams or fewer per device may not -- here 3 slots of 171 / 171 / 170 streams keep the block-512
+    plan.  The two plans agree to f32 rounding (both 2-3e-7 from the truth), not bit for bit; with the plan PINNED on both
+    sides the shards and the unsharded batch agree bit for bit again.  This is the documented behaviour, held here."""
+    import torch
+    dev = torch.device("cuda:0")
+    slots, S, n = 3, 512, 48 * 512
+    L = exp_tuning.lib
+    exp_tuning("node_shared_device_rehearsal", "1")
+    irs = synth.hrir_set(512)
+    x = synth.white_noise_torch(33, 4, n, dev)[torch.arange(S, device=dev) % 4].contiguous()
+    out = {}
+    for plan in (0, 1):
+        nb = ohs.NodeBatchProcessor(S, num_bands=10, devices=[0] * slots, library=L)
+        nb.set_tables(irs)
+        nb.set_eq_enabled(False)
+        nb.set_conv_plan(plan)
+        bp = ohs.BatchProcessor(S, num_bands=10, library=L)
+        for p in range(4):
+            bp.set_ir(p, irs[p])
+        bp.set_eq_enabled(False)
+        bp.set_conv_plan(plan)
+        shards = [nb.shard(i) for i in range(slots)]
+        xs = [x[f:f + c].contiguous() for _, f, c in shards]
+        ys = [torch.empty_like(a) for a in xs]
+        torch.cuda.synchronize()
+        nb.process(xs, ys); nb.sync()
+        y_one = torch.empty_like(x)
+        bp.process(x, out=y_one)
+        torch.cuda.synchronize()
+        out[plan] = (torch.cat(ys), y_one, bp.last_conv_plan()[0], nb.device_batch(0).last_conv_plan()[0])
+    ys0, one0, fam_one0, fam_shard0 = out[0]
+    assert fam_one0 == "hop1536_p1" and fam_shard0 == "block512_p1", (fam_one0, fam_shard0)
+    assert not torch.equal(ys0.view(torch.int32), one0.view(torch.int32))       # different plans: different rounding ...
+    d = (ys0 - one0).double()
+    rel = float(torch.sqrt((d * d).mean()) / torch.sqrt((one0.double() ** 2).mean()))
+    assert rel <= 1e-6, rel                                                     # ... inside the parity bar
+    ys1, one1, fam_one1, fam_shard1 = out[1]
+    assert fam_one1 == fam_shard1 == "block512_p1"
+    assert torch.equal(ys1.view(torch.int32), one1.view(torch.int32))           # pinned: bit for bit
+    assert torch.equal(ys1.view(torch.int32), ys0.view(torch.int32))            # (the shards ran the block-512 plan both times)
+
+
 def test_node_batch_fails_closed_when_one_slot_fails(ohs, synth, exp_tuning):
     """A processing call that fails on ONE device slot leaves the other shards advanced: the node handle refuses every
     later processing call (device-resident and host-buffer form) until ohs_node_batch_reset, then answers with the bits
