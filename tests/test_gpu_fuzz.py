@@ -126,12 +126,14 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
     bp = ohs.BatchProcessor(S, num_bands=len(bands))
     eos = [oracle.ConvolutionEngine() for _ in range(S)]
     qos = [oracle.StereoParametricEQ(len(bands), synth.FS) for _ in range(S)]
+    shared = {}                         # the shared EQ table as the shared calls have set it: band -> (coeffs, enabled)
     for i, b in enumerate(bands):
         bp.update_band_coeffs(i, synth.FS, b)
         c = ohs.biquad_coefficients(b.filter_type, synth.FS, b.center_freq, b.q, b.gain_db)
+        shared[i] = (c, b.enabled)
         for q in qos:
             q.set_band_coeffs(i, c, b.enabled)
-    long_ir = bool(seed % 2)            # odd seeds: partitions > 1 (general + time-parallel kernels)
+    long_ir = bool(seed % 2)            # odd seeds: partitions > 1 (sequential, time-parallel and block-2048 kernels)
     lengths = [300, 512, 2000, 5000, 9000] if long_ir else [64, 300, 512]
     cur_irs = [None] * 4
     for p in range(4):
@@ -156,8 +158,21 @@ def test_fuzz_batch(ohs, synth, oracle, seed):
             nb_ = _random_band(ohs, rng)
             bp.update_band_coeffs(i, synth.FS, nb_)
             c = ohs.biquad_coefficients(nb_.filter_type, synth.FS, nb_.center_freq, nb_.q, nb_.gain_db)
+            shared[i] = (c, nb_.enabled)
             for q in qos:
                 q.set_band_coeffs(i, c, nb_.enabled)
+        if call and rng.random() < 0.3:     # ONE stream gets a band of its own (every plugin instance owns its bands) ...
+            s_ = int(rng.integers(0, S))
+            i = int(rng.integers(0, len(bands)))
+            nb_ = _random_band(ohs, rng)
+            c = ohs.biquad_coefficients(nb_.filter_type, synth.FS, nb_.center_freq, nb_.q, nb_.gain_db)
+            bp.set_stream_band_coeffs(s_, i, c, nb_.enabled)
+            qos[s_].set_band_coeffs(i, c, nb_.enabled)
+        if call and rng.random() < 0.08:    # ... and back to the one shared table (what the shared calls have set)
+            bp.share_eq_table()
+            for q in qos:
+                for i, (c, en) in shared.items():
+                    q.set_band_coeffs(i, c, en)
         if call and rng.random() < 0.1:     # zero all DSP state, keep IRs and EQ table
             bp.reset()
             for q in qos:
