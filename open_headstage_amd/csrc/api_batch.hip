@@ -220,6 +220,7 @@ int ohs_batch_reset(ohs_batch *b)
     HIP_TRY(hipMemsetAsync(c.d_tails, 0, c.S * 2 * 8 * 64 * sizeof(float2), b->st));
     c.tails_lazy = false;       // (the zeroed per-path overlaps are the state)
     c.lb_lazy = false; c.lb_valid = 0;
+    c.pt_active = false;        // (pending tails belong to the frames in front of the reset)
     if (c.d_xhist) {            // (the block-2048 plan's state: zeros are what every path may see of the past)
         HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)(2 * c.xh_len) * sizeof(float), b->st));
         c.xh_valid = c.xh_len;

@@ -32,6 +32,10 @@ void conv_free(ConvState &c)
     if (c.d_lb_ring) hipFree(c.d_lb_ring);
     if (c.d_lb_cd) hipFree(c.d_lb_cd);
     if (c.d_lb_ab) hipFree(c.d_lb_ab);
+    if (c.d_lb_cd_alt) hipFree(c.d_lb_cd_alt);
+    if (c.d_ptail) hipFree(c.d_ptail);
+    if (c.d_ptail_alt) hipFree(c.d_ptail_alt);
+    c.d_lb_cd_alt = nullptr; c.lb_cd_alt_p2pad = 0; c.d_ptail = nullptr; c.d_ptail_alt = nullptr; c.pt_len = 0; c.pt_active = false;
     c.d_irl = nullptr; c.irl_len = 0; c.d_xhist = nullptr; c.d_xhist_alt = nullptr; c.xh_len = 0; c.xh_valid = 0;
     c.d_lb_ring = nullptr; c.lb_ring_cap = 0; c.lb_valid = 0; c.d_lb_cd = nullptr; c.d_lb_ab = nullptr; c.lb_p2pad = 0;
     c.lb_cd_valid = false; c.lb_lazy = false;
@@ -265,12 +269,12 @@ static long long lb_segment_blocks(size_t S)
     return seg / kLbTile * kLbTile;
 }
 
-static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs, float *out,
-                          long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st)
+// tables of the block-2048 plan: the spectra of A = h_lsl + j h_lsr and B = h_rsl + j h_rsr per 2048-tap partition (the forward
+// kernel in tables mode, two "streams" of P2pad windows; kept in d_lb_ab), then (C, D).  `a` receives the fields every launch
+// of the plan shares.
+static int conv_lb_prepare(ConvState &c, DeviceCtx *ctx, hipStream_t st, ConvLbArgs &a)
 {
     const int P2pad = (int)(c.xh_len / kLbBlock);
-    // tables: the spectra of A = h_lsl + j h_lsr and B = h_rsl + j h_rsr per 2048-tap partition (the forward kernel in
-    // tables mode, two "streams" of P2pad windows), then (C, D)
     if (!c.d_lb_cd || c.lb_p2pad != P2pad) {
         DeviceWideSection dws;
         HIP_TRY(hipStreamSynchronize(st));
@@ -281,7 +285,6 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
         HIP_TRY(hipMalloc(&c.d_lb_ab, (size_t)P2pad * 2 * kLbBlock * sizeof(float4)));
         c.lb_p2pad = P2pad;
     }
-    ConvLbArgs a;
     std::memset(&a, 0, sizeof(a));
     a.tw = ctx->d_tw; a.tw4096 = ctx->d_tw4096; a.fp_mode = c.fp_mode; a.P2pad = P2pad;
 #ifdef OHS_EXPERIMENTS
@@ -294,22 +297,130 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
         t.out = nullptr; t.n_streams = 2; t.io_frame0 = 0; t.io_frames = c.irl_len;
         t.u0 = 0; t.n_fwd = P2pad; t.ring = c.d_lb_ab; t.ring_cap = P2pad; t.ring_base = 0; t.tables_mode = 1;
         t.fp_mode = 0;      // (tables are built in IEEE arithmetic, like k_ir_spectrum's)
+        t.debug_skip = 0;
         hipError_t e = launch_conv_lb_forward(t, st);
         if (e == hipSuccess) e = launch_conv_lb_build_cd(c.d_lb_ab, P2pad, c.d_lb_cd, st);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-2048 tables: ") + hipGetErrorString(e));
         c.lb_cd_valid = true;
     }
+    return OHS_OK;
+}
+
+static int conv_lb_ring_reserve(ConvState &c, int cap_need, hipStream_t st)
+{
+    if (cap_need <= c.lb_ring_cap) return OHS_OK;
+    DeviceWideSection dws;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (c.d_lb_ring) hipFree(c.d_lb_ring);
+    c.d_lb_ring = nullptr; c.lb_ring_cap = 0; c.lb_valid = 0;
+    HIP_TRY(hipMalloc(&c.d_lb_ring, c.S * (size_t)cap_need * kLbBlock * sizeof(float4)));
+    c.lb_ring_cap = cap_need;
+    return OHS_OK;
+}
+
+// A per-path set_ir in mid-stream on an object that keeps the input history (convolution.rs:135-138: THAT path forgets its
+// past, the others do not).  Instead of gating partitions per path in every kernel that follows, the reset is carried out
+// as "every path forgets its past" plus what the frames in front of the reset still owe the output through each path --
+// the tails: the input history followed by xh_len frames of silence through the plan's own two kernels, once with the
+// L-speaker pair's tables alone (re = the lsl tail, im = the lsr tail) and once with the R-speaker pair's.  The reset path's
+// row is dropped, rows still pending from an earlier reset are carried on, and conv_launch adds the rows to the output of
+// the calls that follow, whatever plan serves them.  Returns taken = false when the history cannot vouch for every path's
+// reach (then the block-512 kernels' per-path gates serve, as before).
+static int conv_lb_tail_route(ConvState &c, DeviceCtx *ctx, int path, hipStream_t st, bool *taken)
+{
+    *taken = false;
+    if (!c.lazy_ok || !c.d_xhist) return OHS_OK;
+    if (c.since[0] == 0 && c.since[1] == 0 && c.since[2] == 0 && c.since[3] == 0) return OHS_OK;     // nothing processed since a full reset
+    bool deep = true;
+    for (int p = 0; p < 4; ++p) deep = deep && c.since[p] >= c.P[p] && c.xh_valid >= (long long)c.P[p] * BS;
+    const bool together = c.since[0] == c.since[1] && c.since[1] == c.since[2] && c.since[2] == c.since[3] && c.xh_valid >= c.xh_len;
+    if (!deep && !together) return OHS_OK;
+    ConvLbArgs a;
+    int rc = conv_lb_prepare(c, ctx, st, a);
+    if (rc) return rc;
+    const int P2pad = a.P2pad;
+    const long long Lt = c.xh_len;
+    DeviceWideSection dws;
+    if (c.lb_cd_alt_p2pad != P2pad) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c.d_lb_cd_alt) hipFree(c.d_lb_cd_alt);
+        c.d_lb_cd_alt = nullptr; c.lb_cd_alt_p2pad = 0;
+        HIP_TRY(hipMalloc(&c.d_lb_cd_alt, (size_t)P2pad * 2 * kLbBlock * sizeof(float4)));
+        c.lb_cd_alt_p2pad = P2pad;
+    }
+    if (c.pt_len != Lt) {       // (a response of another length since the last tails: rows of the old length are re-cut below)
+        HIP_TRY(hipStreamSynchronize(st));
+        float *n1 = nullptr, *n2 = nullptr;
+        const size_t bytes = c.S * 4 * (size_t)Lt * sizeof(float);
+        HIP_TRY(hipMalloc(&n1, bytes));
+        if (hipMalloc(&n2, bytes) != hipSuccess) { hipFree(n1); return fail(OHS_ERR_HIP, "hipMalloc(pending tails) failed"); }
+        hipError_t e = hipMemsetAsync(n1, 0, bytes, st);
+        if (e == hipSuccess && c.pt_active && c.d_ptail) {
+            // carry the rest of the pending rows over, from position 0 of the new buffer
+            const long long rest = std::min(c.pt_len - c.pt_pos, Lt);
+            if (rest > 0)
+                e = hipMemcpy2DAsync(n1, (size_t)Lt * sizeof(float), c.d_ptail + c.pt_pos, (size_t)c.pt_len * sizeof(float),
+                                     (size_t)rest * sizeof(float), c.S * 4, hipMemcpyDeviceToDevice, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { hipFree(n1); hipFree(n2); return fail(OHS_ERR_HIP, std::string("pending tails: ") + hipGetErrorString(e)); }
+        if (c.d_ptail) hipFree(c.d_ptail);
+        if (c.d_ptail_alt) hipFree(c.d_ptail_alt);
+        c.d_ptail = n1; c.d_ptail_alt = n2; c.pt_len = Lt; c.pt_pos = 0;
+    }
+    rc = conv_lb_ring_reserve(c, 2 * P2pad - 1, st);
+    if (rc) return rc;
+    // windows -(P2pad - 1) .. P2pad - 1 of a segment that starts at the reset: the history, then silence (no buffer frames)
+    a.n_streams = (int)c.S; a.gain = 1.0f;
+    a.ring = c.d_lb_ring; a.ring_cap = c.lb_ring_cap; a.ring_base = 4ll * c.lb_ring_cap;
+    a.in = c.d_xhist; a.io_frame0 = 0; a.io_frames = 0;         // (`in` is never read: no frame lies inside the buffer)
+    a.xhist = c.d_xhist; a.xh_append = nullptr; a.xh_len = c.xh_len; a.xh_head = c.xh_head; a.xh_cnt = 0;
+    a.u0 = -(P2pad - 1); a.n_fwd = 2 * P2pad - 1;
+    a.debug_skip = 0;
+    hipError_t e = launch_conv_lb_forward(a, st);
+    const int keep = 0xF & ~(1 << path);
+    for (int pair = 0; pair < 2 && e == hipSuccess; ++pair) {
+        e = launch_conv_lb_build_cd(c.d_lb_ab, P2pad, c.d_lb_cd_alt, st, 1 << pair);
+        if (e != hipSuccess) break;
+        ConvLbArgs m = a;
+        m.cd = c.d_lb_cd_alt; m.n_big = P2pad;
+        m.out = c.d_xhist_alt; m.out_stream_stride = 2 * Lt; m.out_ch_stride = Lt;      // [S][2][Lt]: re -> ch 0, im -> ch 1
+        m.io_frame0 = 0; m.io_frames = Lt;
+        e = launch_conv_lb_mac_inverse(m, st);
+        if (e == hipSuccess)
+            e = launch_conv_lb_tails_merge(c.pt_active ? c.d_ptail : nullptr, c.pt_pos, c.d_xhist_alt, c.d_ptail_alt, Lt, pair, keep,
+                                           (int)c.S, st);
+    }
+    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("pending tails: ") + hipGetErrorString(e));
+    std::swap(c.d_ptail, c.d_ptail_alt);
+    c.pt_pos = 0; c.pt_active = true;
+    // every path forgets its past: the history, the block-512 ring and overlaps, the window ring
+    HIP_TRY(hipMemsetAsync(c.d_xhist, 0, c.S * 2 * (size_t)(2 * c.xh_len) * sizeof(float), st));
+    c.xh_head = 0; c.xh_valid = c.xh_len; c.lb_valid = 0; c.lb_lazy = false; c.tails_lazy = false;
+    HIP_TRY(hipMemsetAsync(c.d_hist, 0, c.S * (size_t)c.cap * NF * sizeof(float2), st));
+    HIP_TRY(hipMemsetAsync(c.d_tails, 0, c.S * 2 * 8 * 64 * sizeof(float2), st));
+    for (int p = 0; p < 4; ++p) c.since[p] = 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    *taken = true;
+    return OHS_OK;
+}
+
+static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs, float *out,
+                          long long out_ss, long long out_cs, int n_blocks, float gain, hipStream_t st)
+{
+    ConvLbArgs a;
+    {
+        const int rcp = conv_lb_prepare(c, ctx, st, a);
+        if (rcp) return rcp;
+    }
+    const int P2pad = a.P2pad;
     const long long SEG = lb_segment_blocks(c.S);
     const long long frames_total = (long long)n_blocks * BS;
     const long long nbig_total = ((long long)c.cnt * BS + frames_total - 1) / kLbBlock - (long long)c.cnt * BS / kLbBlock + 1;
     const int cap_need = (int)(std::min(SEG, (nbig_total + kLbTile - 1) / kLbTile * kLbTile) + P2pad - 1);
-    if (cap_need > c.lb_ring_cap) {
-        DeviceWideSection dws;
-        HIP_TRY(hipStreamSynchronize(st));
-        if (c.d_lb_ring) hipFree(c.d_lb_ring);
-        c.d_lb_ring = nullptr; c.lb_ring_cap = 0; c.lb_valid = 0;
-        HIP_TRY(hipMalloc(&c.d_lb_ring, c.S * (size_t)cap_need * kLbBlock * sizeof(float4)));
-        c.lb_ring_cap = cap_need;
+    {
+        const int rcr = conv_lb_ring_reserve(c, cap_need, st);
+        if (rcr) return rcr;
     }
     a.n_streams = (int)c.S; a.gain = gain; a.cd = c.d_lb_cd;
     a.ring = c.d_lb_ring; a.ring_cap = c.lb_ring_cap;
@@ -364,6 +475,17 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
     DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    {   // an object that keeps the input history turns a reset in mid-stream into "all paths forget" + pending tails
+        bool taken = false;
+        const int rct = conv_lb_tail_route(c, ctx, path, st, &taken);
+        if (rct) return rct;
+        if (!taken && c.pt_active) {
+            // tails still pending from an earlier reset: this path's row is part of the past it now forgets (e.g. the
+            // second of four set_ir calls that re-load every path: nothing has been processed since the first)
+            HIP_TRY(hipMemset2DAsync(c.d_ptail + (size_t)path * c.pt_len, 4 * (size_t)c.pt_len * sizeof(float), 0,
+                                     (size_t)c.pt_len * sizeof(float), c.S, st));
+        }
+    }
     {   // the overlaps at rest belong to the spectra that are about to be replaced
         const int rcm = conv_materialise_state(c, ctx, st);
         if (rcm) return rcm;
@@ -523,6 +645,14 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
 {
     const int rc = conv_launch_impl(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st, allow_fast, ev_start, ev_stop);
     if (rc == OHS_OK && n_blocks > 0 && c.last_kernel >= 0 && c.last_kernel < 6) c.kernel_calls[c.last_kernel]++;
+    if (rc == OHS_OK && n_blocks > 0 && c.pt_active) {
+        // what the frames in front of a per-path set_ir still owe these frames (conv_lb_tail_route)
+        const long long n = (long long)n_blocks * BS;
+        hipError_t e = launch_conv_lb_tails_add(out, out_ss, out_cs, n, c.d_ptail, c.pt_len, c.pt_pos, gain, (int)c.S, st);
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("pending tails: ") + hipGetErrorString(e));
+        c.pt_pos += n;
+        if (c.pt_pos >= c.pt_len) c.pt_active = false;
+    }
     return rc;
 }
 

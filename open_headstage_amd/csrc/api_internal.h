@@ -170,6 +170,15 @@ struct ConvState {
     float4 *d_lb_cd = nullptr, *d_lb_ab = nullptr;          // [P2pad][2][2048] tables; [2][P2pad][2048] scratch for building them
     int lb_p2pad = 0;               // what d_lb_cd / d_lb_ab are allocated for
     bool lb_cd_valid = false;
+    // Pending tails (conv_lb_tail_route): a per-path set_ir on an object that keeps the input history is carried out as "every
+    // path forgets its past" + what the frames in front of the reset still owe the output through the SURVIVING paths,
+    // computed once ([S][4 paths][pt_len], a row per path so that a later reset of that path can drop it) and added to the
+    // output of the calls that follow, whatever plan serves them.  No kernel of such an object ever needs a per-path gate.
+    float *d_ptail = nullptr, *d_ptail_alt = nullptr;
+    long long pt_len = 0, pt_pos = 0;
+    bool pt_active = false;
+    float4 *d_lb_cd_alt = nullptr;  // tables of one speaker pair alone (the tails' two runs)
+    int lb_cd_alt_p2pad = 0;
     // what served the last convolution launch (ohs_batch_last_conv_plan): OHS_CONV_KERNEL_*, and its ranges per stream
     int last_kernel = 0, last_ranges = 0;
     unsigned long long kernel_calls[6] = {0, 0, 0, 0, 0, 0};     // conv_launch calls served per family (ohs_batch_conv_plan_counts)

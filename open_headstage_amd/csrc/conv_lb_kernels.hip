@@ -236,6 +236,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
     const int tb0 = tile * kLbTile;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
+#ifdef OHS_EXPERIMENTS
+    // (timing experiment: debug_skip >> 8 = stagger in units of 64 clocks; bit 4 chooses which workgroups wait -- odd local
+    // index, else local index bit 5)
+    if ((A.debug_skip >> 8) > 0) {
+        const unsigned li = blockIdx.x >> 3;
+        if ((A.debug_skip & 16) ? (li & 1u) : (li & 32u)) {
+            const unsigned long long t0 = __builtin_readcyclecounter(), span = (unsigned long long)(A.debug_skip >> 8) * 64ull;
+            while (__builtin_readcyclecounter() - t0 < span) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#endif
     // ---- pair products: thread = 8 pairs (q = tid + 256 p) x 4 output blocks -------------------------------------
     lb_v2f acc[8][kLbTile][2];
 #pragma unroll
@@ -380,10 +391,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
 // ---------------------------------------------------------------------------------
 // tables, state
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_conv_lb_build_cd(const float4 *__restrict__ ab, int P2pad, float4 *__restrict__ cd)
+__global__ __launch_bounds__(256) void k_conv_lb_build_cd(const float4 *__restrict__ ab, int P2pad, float4 *__restrict__ cd, int mask)
 {
     const int i = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
-    const float4 a = ab[((size_t)0 * P2pad + i) * kLbPairs + q], b = ab[((size_t)1 * P2pad + i) * kLbPairs + q];
+    // mask bit 0: the L-speaker pair (A = H_lsl + j H_lsr) takes part, bit 1: the R-speaker pair (B = H_rsl + j H_rsr)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = (mask & 1) ? ab[((size_t)0 * P2pad + i) * kLbPairs + q] : z4;
+    const float4 b = (mask & 2) ? ab[((size_t)1 * P2pad + i) * kLbPairs + q] : z4;
     const float h = 0.5f / (float)kLbFft;       // the 1/2 of C, D and the 1/N of the inverse transform (powers of two)
     // C = (A - jB)/2, D = (A + jB)/2 per component (k_build_cd_multi does the same for the 1024-point spectra)
     cd[((size_t)i * 2 + 0) * kLbPairs + q] = make_float4(h * (a.x + b.y), h * (a.y - b.x), h * (a.x - b.y), h * (a.y + b.x));
@@ -491,9 +505,66 @@ hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st)
+hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st, int mask)
 {
-    hipLaunchKernelGGL(k_conv_lb_build_cd, dim3(kLbPairs / 256, P2pad), dim3(256), 0, st, ab, P2pad, cd);
+    hipLaunchKernelGGL(k_conv_lb_build_cd, dim3(kLbPairs / 256, P2pad), dim3(256), 0, st, ab, P2pad, cd, mask);
+    return hipGetLastError();
+}
+
+// ---- pending tails (a per-path set_ir in mid-stream; api_conv.hip: conv_lb_tail_route) ---------------------------------
+// dst[s][q][j] = keep(q) ? pend[s][q][pos + j] + fresh[s][q & 1][j] : 0   for the two paths q = 2 pair, 2 pair + 1
+__global__ __launch_bounds__(256) void k_conv_lb_tails_merge(const float *__restrict__ pend, long long pos, const float *__restrict__ fresh,
+                                                             float *__restrict__ dst, long long len, int pair, int keep_mask,
+                                                             unsigned wgs_per_row)
+{
+    const long long j = 4 * ((long long)(blockIdx.x % wgs_per_row) * 256 + threadIdx.x);
+    if (j >= len) return;
+    const size_t row = blockIdx.x / wgs_per_row;        // stream * 2 + (q & 1)
+    const size_t s = row >> 1;
+    const int q = 2 * pair + (int)(row & 1);
+    lb_v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (keep_mask & (1 << q)) {
+        v = *reinterpret_cast<const lb_v4f *>(fresh + row * len + j);
+        if (pend && pos + j < len) v += *reinterpret_cast<const lb_v4f *>(pend + (s * 4 + q) * len + pos + j);
+    }
+    *reinterpret_cast<lb_v4f *>(dst + (s * 4 + q) * len + j) = v;
+}
+
+// out[s][ear][f] += gain * (tails[s][ear][pos + f] + tails[s][2 + ear][pos + f]),  f < min(n_frames, len - pos)
+__global__ __launch_bounds__(256) void k_conv_lb_tails_add(float *__restrict__ out, long long out_ss, long long out_cs, long long count,
+                                                           const float *__restrict__ tails, long long len, long long pos, float gain,
+                                                           unsigned wgs_per_row)
+{
+    const long long f = (long long)(blockIdx.x % wgs_per_row) * 256 + threadIdx.x;
+    if (f >= count) return;
+    const size_t row = blockIdx.x / wgs_per_row;        // stream * 2 + ear
+    const size_t s = row >> 1, ear = row & 1;
+    const float t = tails[(s * 4 + ear) * len + pos + f] + tails[(s * 4 + 2 + ear) * len + pos + f];
+    float *o = out + s * out_ss + ear * out_cs + f;
+    *o = *o + gain * t;
+}
+
+hipError_t launch_conv_lb_tails_merge(const float *pend, long long pos, const float *fresh, float *dst, long long len, int pair,
+                                      int keep_mask, int n_streams, hipStream_t st)
+{
+    if (len <= 0 || (len & 511) || (pos & 511) || pos < 0 || n_streams <= 0 || pair < 0 || pair > 1) return hipErrorInvalidValue;
+    const unsigned long long wpr = (unsigned long long)((len / 4 + 255) / 256), wgs = wpr * 2ull * (unsigned long long)n_streams;
+    if (wgs > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv_lb_tails_merge, dim3((unsigned)wgs), dim3(256), 0, st, pend, pos, fresh, dst, len, pair, keep_mask,
+                       (unsigned)wpr);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_lb_tails_add(float *out, long long out_ss, long long out_cs, long long n_frames, const float *tails,
+                                    long long len, long long pos, float gain, int n_streams, hipStream_t st)
+{
+    if (len <= 0 || pos < 0 || pos >= len || n_streams <= 0) return hipErrorInvalidValue;
+    const long long count = n_frames < len - pos ? n_frames : len - pos;
+    if (count <= 0) return hipSuccess;
+    const unsigned long long wpr = (unsigned long long)((count + 255) / 256), wgs = wpr * 2ull * (unsigned long long)n_streams;
+    if (wgs > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv_lb_tails_add, dim3((unsigned)wgs), dim3(256), 0, st, out, out_ss, out_cs, count, tails, len, pos, gain,
+                       (unsigned)wpr);
     return hipGetLastError();
 }
 

@@ -323,7 +323,16 @@ struct ConvLbArgs {
 hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st);
 hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st);
 // (C, D) tables from the spectra of A = h_lsl + j h_lsr (ab[0][i]) and B = h_rsl + j h_rsr (ab[1][i]), i < P2pad
-hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st);
+// (mask: bit 0 = the L-speaker pair takes part, bit 1 = the R-speaker pair; 3 = the tables of the convolution)
+hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st, int mask = 3);
+// Pending tails [stream][4 paths][len]: what the frames in front of a per-path set_ir still contribute to the frames behind
+// it, per path (a later reset of a path zeroes its row).  merge: dst rows of the pair's two paths = the rest of the pending
+// row (from pos on) + the fresh tail fresh[stream][2][len] (re -> path 2 pair, im -> path 2 pair + 1), or zeros where
+// keep_mask has the path's bit clear; add: out += gain * (ear's two rows) for the call's frames
+hipError_t launch_conv_lb_tails_merge(const float *pend, long long pos, const float *fresh, float *dst, long long len, int pair,
+                                      int keep_mask, int n_streams, hipStream_t st);
+hipError_t launch_conv_lb_tails_add(float *out, long long out_ss, long long out_cs, long long n_frames, const float *tails,
+                                    long long len, long long pos, float gain, int n_streams, hipStream_t st);
 // the input history [stream][2][2 len] (a ring of twice its reach `len`): append the call's last cnt = min(n_frames, len)
 // frames at head .. head + cnt (mod 2 len); the caller then advances head by cnt.  (The forward kernels do this themselves;
 // this launch serves the calls that go through the sequential kernel.)

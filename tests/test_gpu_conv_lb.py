@@ -176,9 +176,10 @@ def test_several_segments_per_call(oracle):
 
 def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
     """One continuous signal through a sequence of calls under changing plans: block 2048 -> block 512 time-parallel (24
-    blocks, 2 blocks) -> block 2048 ..., with the EQ in front, and a per-path set_ir in mid-stream -- the call
-    right behind it is served by the block-512 kernels (that path must not see the frames before its reset,
-    convolution.rs:135-138), the one after by block 2048 again."""
+    blocks, 2 blocks) -> block 2048 ..., with the EQ in front, and a per-path set_ir in mid-stream -- that path
+    must not see the frames before its reset (convolution.rs:135-138), the others must: the reset is carried out as "every
+    path forgets" plus pending tails (what the old frames still owe the output through the surviving paths), so the call
+    right behind it is block 2048 as well."""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
@@ -201,7 +202,7 @@ def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
         eqs.append(qo)
     #      (plan, blocks, kernel family expected of the call's last launch)
     seq = [(2, 20, "block2048"), (1, 24, "block512_tp"), (2, 8, "block2048"), (1, 2, "block512_tp"), (2, 16, "block2048"),
-           (2, 16, "block2048"),        # <- set_ir(path 2) in front of this one: served by block 512 (gated), see below
+           (2, 16, "block2048"),        # <- set_ir(path 2) in front of this one: pending tails carry the other paths' past
            (2, 20, "block2048"), (0, 3, "block2048"), (0, 40, "block2048")]
     for k, (plan, nb, want) in enumerate(seq):
         if k == 5:
@@ -209,7 +210,6 @@ def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
             bp.set_ir(2, h)
             for e in engs:
                 e.set_ir(2, h)
-            want = "block512_tp"
         bp.set_conv_plan(plan)
         x = synth.white_noise(range(10 * k, 10 * k + S), nb * 512)
         y = bp.process(torch.from_numpy(x).cuda()).cpu().numpy()
@@ -218,6 +218,50 @@ def test_the_plans_hand_the_state_over_and_a_midstream_set_ir(oracle):
             l, r = x[s, 0].copy(), x[s, 1].copy()
             oracle.chain_process(engs[s], eqs[s], l, r, eq_enable=True, gain=0.7)
             assert_parity(y[s], np.stack([l, r]), f"call {k} (plan {plan}, {nb} blocks), stream {s}")
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_per_path_resets_in_quick_succession_pending_tails(oracle, seed):
+    """A per-path set_ir on an object that keeps the input history = "every path forgets" + pending tails, one row per path
+    (conv_lb_tail_route).  Resets that come while tails are still pending -- the same path again, another path, a mute, a
+    response that changes the history's reach (and with it the rows' length), all four paths one after the other -- and
+    calls of 1 .. 20 blocks in between, some shorter than the tails, in place, under every plan: one continuous signal
+    against the oracle, call by call."""
+    import torch
+    import open_headstage_amd as ohs
+    from open_headstage_amd import synth
+    rng = np.random.default_rng(seed)
+    S = 3
+    taps0 = [int(rng.integers(4000, 12000)) for _ in range(4)]
+    irs = [synth.hrir_set(t)[p] for p, t in enumerate(taps0)]
+    bp = _make(ohs, S, irs, 0, gain=0.8)
+    engs = _oracle_engines(oracle, irs, S)
+    lengths = [0, 300, 512, 3000, 4100, 9000, 16384, 20000]
+    for k in range(40):
+        r = rng.random()
+        if k in (17, 18, 19, 20):               # every path re-loaded, one call each, no processing in between
+            todo = [(k - 17, int(rng.choice(lengths[3:])))]
+        elif r < 0.45:
+            todo = [(int(rng.integers(0, 4)), int(rng.choice(lengths)))]
+            if rng.random() < 0.3:
+                todo.append((int(rng.integers(0, 4)), int(rng.choice(lengths))))
+        else:
+            todo = []
+        for path, t in todo:
+            h = synth.hrir_set(max(t, 1))[path][:t]
+            bp.set_ir(path, h)
+            for e in engs:
+                e.set_ir(path, h)
+        if k in (17, 18, 19):
+            continue
+        bp.set_conv_plan(int(rng.integers(0, 3)))
+        nb = int(rng.choice([1, 2, 3, 5, 8, 20]))
+        x = synth.white_noise(range(5000 * seed + 10 * k, 5000 * seed + 10 * k + S), nb * 512)
+        xt = torch.from_numpy(x).cuda()
+        y = (bp.process(xt, out=xt) if k % 2 else bp.process(xt)).cpu().numpy()
+        for s in range(S):
+            ref = np.stack(engs[s].process_block(x[s, 0], x[s, 1])) * np.float32(0.8)
+            assert_parity(y[s], ref, f"seed {seed}, call {k} ({nb} blocks, {bp.last_conv_plan()[0]}), stream {s}")
 
 
 def test_reset_and_a_set_ir_of_all_paths_forget_the_input_history(oracle):

@@ -7,9 +7,12 @@ stream, blocks in sequence: ~290 x the steady call).  Now the time-parallel kern
 behind a zeroed gap of the ring and k_conv_tp_old adds, under the per-path gate, what each path may still see of them.
 Checked: parity with the oracle across several resets (longer, shorter, muted), and the cost of the call after a reset.
 
-Round 5: the steady call of this shape is served by the block-2048 plan (0.15 ms instead of 0.25); the call right behind a
-per-path set_ir still takes the gated block-512 kernels (0.39 ms as before: 2.6 x the new steady call), the one after that
-is block 2048 again -- the plans hand the state over (tests/test_gpu_conv_lb.py).
+Round 5: the steady call of this shape is served by the block-2048 plan (0.13 ms instead of 0.25), and an object that keeps
+the input history (every batch object with a response of 8 partitions or more) carries a per-path set_ir out as "every
+path forgets its past" + pending tails -- what the frames in front of the reset still owe the output through the surviving
+paths, computed once at set_ir time and added to the calls that follow (api_conv.hip: conv_lb_tail_route).  The call
+behind the reset is block 2048 as well: 0.16-0.175 ms = 1.3 x the steady call.  The gated block-512 kernels of round 4
+still serve objects without the history (responses of 2-7 partitions): the small-shape tests below.
 """
 import numpy as np
 import pytest
@@ -94,12 +97,13 @@ def test_the_call_after_a_per_path_set_ir_costs_at_most_three_steady_calls():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
 
-    # (the call after a per-path set_ir is served by the block-512 kernels -- the path must not see the frames in front of
-    # its reset, which the block-2048 plan's input history cannot express: one call under that plan first, so that its
-    # buffers exist and the first timed call does not pay for their allocation)
+    # (one call under the block-512 plan and one reset first, so that every buffer either route may want exists and no timed
+    # call pays for an allocation)
     bp.set_conv_plan(1)
     timed_call()
     bp.set_conv_plan(0)
+    bp.set_ir(0, irs[0])
+    timed_call()
     for _ in range(3):
         timed_call()
     steady = sorted(timed_call() for _ in range(7))[3]
@@ -112,7 +116,7 @@ def test_the_call_after_a_per_path_set_ir_costs_at_most_three_steady_calls():
     worst = max(after)
     print(f"steady call {steady:.3f} ms; call after a per-path set_ir: {['%.3f' % v for v in after]} ms "
           f"(worst {worst / steady:.2f} x)")
-    assert worst <= 3.0 * steady, (steady, after)
+    assert worst <= 2.0 * steady, (steady, after)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
