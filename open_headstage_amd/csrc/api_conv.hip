@@ -432,7 +432,7 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     // the next call).
     const long long abs0 = (long long)c.cnt * BS, absE = abs0 + frames_total;
     const long long Ba = abs0 / kLbBlock, Bl = (absE - 1) / kLbBlock;
-    int tiles_last = 0;
+    int tiles_last = 0, tile_blocks = kLbTile;
     for (long long Bs = Ba; Bs <= Bl; Bs += SEG) {
         const long long Be = std::min<long long>(Bs + SEG, Bl + 1);
         const int n_big = (int)(Be - Bs);
@@ -451,13 +451,13 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
         hipError_t e = launch_conv_lb_forward(a, st);
         if (e == hipSuccess) {
             c.xh_head = (c.xh_head + xcnt) % (2 * c.xh_len);
-            e = launch_conv_lb_mac_inverse(a, st);
+            e = launch_conv_lb_mac_inverse(a, st, &tile_blocks);
         }
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-2048 launch: ") + hipGetErrorString(e));
         const long long complete = f_hi / kLbBlock - Bs;          // blocks of this segment whose last frame is known
         c.lb_valid = std::min<long long>((cont ? c.lb_valid : warm) + complete, c.lb_ring_cap - 1);
         c.lb_end = Bs + complete;
-        tiles_last = (n_big + kLbTile - 1) / kLbTile;
+        tiles_last = (n_big + tile_blocks - 1) / tile_blocks;
     }
     c.xh_valid = std::min(c.xh_len, c.xh_valid + frames_total);
     c.lb_lazy = true;

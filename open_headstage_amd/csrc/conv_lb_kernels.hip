@@ -220,7 +220,12 @@ __device__ __forceinline__ void lb_cmac(lb_v2f &acc, lb_v2f z, lb_v2f c, lb_v2f 
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(acc) : "v"(m), "v"(d));
 }
 
-template <int PI>       // partitions per register window: 8 (P2pad a multiple of 8) or 4
+// PI: partitions per register window, 8 (P2pad a multiple of 8) or 4.  TB: output blocks per workgroup -- 4 for calls of
+// several blocks (11 window spectra + 16 table rows per pair group feed 4 x 8 x 2 products: the tile that keeps the loads per
+// product low), 2 or 1 for the short calls of a host that feeds the plugin's 1024-frame block (a 4-block tile would compute
+// three blocks for nothing, and with one block's 32 accumulator registers the next pair group's operands can be in flight
+// while this one's products run: a lone workgroup per CU is a chain of load latencies otherwise).
+template <int PI, int TB>
 __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs A)
 {
     ohs_set_fp_mode(A.fp_mode);
@@ -229,30 +234,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
     float2 *X = smem + kTabComplex;
     const int tid = threadIdx.x;
     fill_twiddle_tables(tab, A.tw, tid, 256);
-    const int tiles = (A.n_big + kLbTile - 1) / kLbTile;
+    const int tiles = (A.n_big + TB - 1) / TB;
     size_t s;
     int tile;
     if (!lb_job(tiles, A.n_streams, s, tile)) return;
-    const int tb0 = tile * kLbTile;
+    const int tb0 = tile * TB;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
-#ifdef OHS_EXPERIMENTS
-    // (timing experiment: debug_skip >> 8 = stagger in units of 64 clocks; bit 4 chooses which workgroups wait -- odd local
-    // index, else local index bit 5)
-    if ((A.debug_skip >> 8) > 0) {
-        const unsigned li = blockIdx.x >> 3;
-        if ((A.debug_skip & 16) ? (li & 1u) : (li & 32u)) {
-            const unsigned long long t0 = __builtin_readcyclecounter(), span = (unsigned long long)(A.debug_skip >> 8) * 64ull;
-            while (__builtin_readcyclecounter() - t0 < span) __builtin_amdgcn_s_sleep(8);
-        }
-    }
-#endif
-    // ---- pair products: thread = 8 pairs (q = tid + 256 p) x 4 output blocks -------------------------------------
-    lb_v2f acc[8][kLbTile][2];
+    // ---- pair products: thread = 8 pairs (q = tid + 256 p) x TB output blocks -------------------------------------
+    lb_v2f acc[8][TB][2];
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
-        for (int t = 0; t < kLbTile; ++t) { acc[p][t][0] = (lb_v2f){0.f, 0.f}; acc[p][t][1] = (lb_v2f){0.f, 0.f}; }
+        for (int t = 0; t < TB; ++t) { acc[p][t][0] = (lb_v2f){0.f, 0.f}; acc[p][t][1] = (lb_v2f){0.f, 0.f}; }
     // Operands come through buffer loads: one resource for the stream's ring, one for the tables of the partition window,
     // the thread's 16 bytes at voffset = 16 tid, everything else -- ring slot, pair group p, partition -- in the SCALAR
     // offset.  (With flat pointers hipcc kept a 64-bit address pair per window slot and table row alive: ~50 VGPRs, and
@@ -269,44 +263,69 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
     for (int i0 = 0; i0 < ((dskip & 1) ? 0 : A.P2pad); i0 += PI) {
         const __amdgpu_buffer_rsrc_t r_cd = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float4 *>(A.cd) + (size_t)i0 * 2 * kLbPairs, 0, PI * 2 * (kLbPairs * 16), 0x00020000);
-        // window of blocks t - i, t in [0, 4), i in [i0, i0 + PI): w = t - (i - i0) + PI - 1 in [0, PI + 3)
-        int so[PI + kLbTile - 1];
+        // window of blocks t - i, t in [0, TB), i in [i0, i0 + PI): w = t - (i - i0) + PI - 1 in [0, PI + TB - 1)
+        int so[PI + TB - 1];
         {
             int sl = (int)((A.ring_base + tb0 - i0 - (PI - 1)) % A.ring_cap);
 #pragma unroll
-            for (int w = 0; w < PI + kLbTile - 1; ++w) {
+            for (int w = 0; w < PI + TB - 1; ++w) {
                 so[w] = __builtin_amdgcn_readfirstlane(sl * (kLbPairs * 16));
                 sl = sl + 1 == A.ring_cap ? 0 : sl + 1;
             }
         }
+        // one pair group's operands: W window spectra + 2 x PI table rows, all requested at once
+        constexpr int W = PI + TB - 1;
+        struct Ops { lb_v4f zw[W], cc[2][PI]; };
+        auto request = [&](int p, Ops &o) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            // all 11 + 16 loads of the pair group at once, then the 256 products
-            lb_v4f zw[PI + kLbTile - 1], cc[2][PI];
-#pragma unroll
-            for (int w = 0; w < PI + kLbTile - 1; ++w)
-                zw[w] = __builtin_bit_cast(lb_v4f, __builtin_amdgcn_raw_buffer_load_b128(r_ring, (dskip & 4) ? 0x7ffffff0 : voff,
-                                                                                         so[w] + p * 4096, 0));
-#pragma unroll
-            for (int comp = 0; comp < 2; ++comp)
-#pragma unroll
-                for (int ii = 0; ii < PI; ++ii)
-                    cc[comp][ii] = __builtin_bit_cast(lb_v4f, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                  r_cd, (dskip & 8) ? 0x7ffffff0 : voff,
-                                                                  (ii * 2 + comp) * (kLbPairs * 16) + p * 4096, 0));
-            __builtin_amdgcn_sched_barrier(0);
+            for (int w = 0; w < W; ++w)
+                o.zw[w] = __builtin_bit_cast(lb_v4f, __builtin_amdgcn_raw_buffer_load_b128(r_ring, (dskip & 4) ? 0x7ffffff0 : voff,
+                                                                                           so[w] + p * 4096, 0));
 #pragma unroll
             for (int comp = 0; comp < 2; ++comp)
 #pragma unroll
                 for (int ii = 0; ii < PI; ++ii)
+                    o.cc[comp][ii] = __builtin_bit_cast(lb_v4f, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                    r_cd, (dskip & 8) ? 0x7ffffff0 : voff,
+                                                                    (ii * 2 + comp) * (kLbPairs * 16) + p * 4096, 0));
+        };
+        auto products = [&](int p, const Ops &o) {
 #pragma unroll
-                    for (int t = 0; t < kLbTile; ++t) {
-                        const lb_v4f zz = zw[t - ii + PI - 1];
+            for (int comp = 0; comp < 2; ++comp)
+#pragma unroll
+                for (int ii = 0; ii < PI; ++ii)
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        const lb_v4f zz = o.zw[t - ii + PI - 1];
                         lb_v2f z = comp ? zz.hi : zz.lo, m = comp ? zz.lo : zz.hi;
                         if (p == 0) m = special ? z : m;
-                        lb_cmac(acc[p][t][comp], z, cc[comp][ii].lo, m, cc[comp][ii].hi);
+                        lb_cmac(acc[p][t][comp], z, o.cc[comp][ii].lo, m, o.cc[comp][ii].hi);
                     }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (TB == 1) {
+            // two operand sets: group p + 1 is in flight while group p's products run
+            Ops oa, ob;
+            request(0, oa);
+#pragma unroll
+            for (int p = 0; p < 8; p += 2) {
+                request(p + 1, ob);
+                __builtin_amdgcn_sched_barrier(0);
+                products(p, oa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (p + 2 < 8) request(p + 2, oa);
+                __builtin_amdgcn_sched_barrier(0);
+                products(p + 1, ob);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                Ops o;
+                request(p, o);
+                __builtin_amdgcn_sched_barrier(0);
+                products(p, o);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     __syncthreads();            // (the twiddle tables are in place)
@@ -317,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
 #pragma unroll
         for (int p = 0; p < 8; ++p)
 #pragma unroll
-            for (int t = 0; t < kLbTile; ++t) sum += acc[p][t][0] + acc[p][t][1];
+            for (int t = 0; t < TB; ++t) sum += acc[p][t][0] + acc[p][t][1];
         if (sum.x == 12345.678f) A.out[s * A.out_stream_stride + tid] = sum.y;
     }
 #endif
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_lb_mac_inverse(const ConvLbArgs
         tw[cc][0] = t4[0]; tw[cc][1] = t4[1];
     }
 #pragma unroll
-    for (int t = 0; t < kLbTile; ++t) {
+    for (int t = 0; t < TB; ++t) {
         if (tb0 + t >= A.n_big || (dskip & 2)) break;          // (uniform over the workgroup)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -482,26 +501,31 @@ hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st)
+hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st, int *tile_blocks)
 {
     if (a.n_big <= 0) return hipSuccess;
     // the oldest window a tile reads is block 0's partition P2pad - 1; a tile's unused blocks read slots that alias others
     if (!lb_args_ok(a) || !a.out || !a.cd || a.P2pad < 4 || (a.P2pad & 3) || a.n_big + a.P2pad - 1 > a.ring_cap ||
         a.ring_base - (a.P2pad - 1) - 8 < 0)
         return hipErrorInvalidValue;
-    const int tiles = (a.n_big + kLbTile - 1) / kLbTile;
+    // output blocks per workgroup: 4, or as many as the call has (1 or 2: the short calls)
+    const int TB = a.n_big >= 3 ? kLbTile : a.n_big;
+    if (tile_blocks) *tile_blocks = TB;
+    const int tiles = (a.n_big + TB - 1) / TB;
     const dim3 grid(lb_grid(tiles, a.n_streams));
+#define OHS_LB_MI(PI_, TB_)                                                                                                  \
+    do {                                                                                                                     \
+        static std::atomic<unsigned long long> lds_ok{0};                                                                    \
+        const hipError_t e = lb_allow_lds(reinterpret_cast<const void *>(k_conv_lb_mac_inverse<PI_, TB_>), lds_ok);          \
+        if (e != hipSuccess) return e;                                                                                       \
+        hipLaunchKernelGGL((k_conv_lb_mac_inverse<PI_, TB_>), grid, dim3(256), kLbLdsBytes, st, a);                          \
+    } while (0)
     if (a.P2pad % 8 == 0) {
-        static std::atomic<unsigned long long> lds_ok{0};
-        const hipError_t e = lb_allow_lds(reinterpret_cast<const void *>(k_conv_lb_mac_inverse<8>), lds_ok);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_conv_lb_mac_inverse<8>, grid, dim3(256), kLbLdsBytes, st, a);
+        if (TB == 1) OHS_LB_MI(8, 1); else if (TB == 2) OHS_LB_MI(8, 2); else OHS_LB_MI(8, 4);
     } else {
-        static std::atomic<unsigned long long> lds_ok{0};
-        const hipError_t e = lb_allow_lds(reinterpret_cast<const void *>(k_conv_lb_mac_inverse<4>), lds_ok);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_conv_lb_mac_inverse<4>, grid, dim3(256), kLbLdsBytes, st, a);
+        if (TB == 1) OHS_LB_MI(4, 1); else if (TB == 2) OHS_LB_MI(4, 2); else OHS_LB_MI(4, 4);
     }
+#undef OHS_LB_MI
     return hipGetLastError();
 }
 

@@ -321,7 +321,7 @@ struct ConvLbArgs {
     int debug_skip;             // experiments build only (Tuning::lb_skip): timing knock-outs, wrong results; 0 in the product
 };
 hipError_t launch_conv_lb_forward(const ConvLbArgs &a, hipStream_t st);
-hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st);
+hipError_t launch_conv_lb_mac_inverse(const ConvLbArgs &a, hipStream_t st, int *tile_blocks = nullptr);   // -> output blocks per workgroup
 // (C, D) tables from the spectra of A = h_lsl + j h_lsr (ab[0][i]) and B = h_rsl + j h_rsr (ab[1][i]), i < P2pad
 // (mask: bit 0 = the L-speaker pair takes part, bit 1 = the R-speaker pair; 3 = the tables of the convolution)
 hipError_t launch_conv_lb_build_cd(const float4 *ab, int P2pad, float4 *cd, hipStream_t st, int mask = 3);
@@ -343,7 +343,7 @@ hipError_t launch_conv_lb_xhist_linearise(const float *ring, float *dst, long lo
                                           hipStream_t st);
 void conv_lb_build_twiddles(float2 *out);       // host: [3][1024]
 constexpr int kLbBlock = 2048;                  // frames per block of this plan
-constexpr int kLbTile = 4;                      // output blocks per MI workgroup
+constexpr int kLbTile = 4;                      // output blocks per MI workgroup (calls of 1 or 2 blocks: that many)
 
 // IR chunk -> spectrum: dst[part][16][64], one wave per partition.
 hipError_t launch_ir_spectrum(const float *d_ir, int len, int n_parts, float2 *dst,
