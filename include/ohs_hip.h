@@ -340,19 +340,17 @@ int  ohs_batch_set_gain(ohs_batch *b, float gain);
  *        every path ONE partition (BASELINE configs[2] / [4]): hop 1536 / FFT 2048, overlap-save -- a quarter less transform
  *          and product work per frame, 11-12 % less time where the convolution is what the step waits for.  Needs even
  *          strides and 8-byte aligned buffers, calls of 3 blocks or more.
- *        longer responses, from 8 partitions (taps > 3584; BASELINE configs[3]): block 2048 / FFT 4096, overlap-save -- a
- *          quarter of the reference blocking's products and history reads per frame (16 384 taps: 8 partitions instead of
- *          the 32 of convolution.rs:120-132), product and inverse transform in one kernel.  Needs strides that are multiples
- *          of 4 floats and 16-byte aligned buffers, and every path either older than its own response or reset together
- *          with the others (the call right after a per-path set_ir in mid-stream is served by plan 1).
+ *        longer responses (taps > 512; BASELINE configs[3]): block 2048 / FFT 4096, overlap-save -- a quarter of the
+ *          reference blocking's products and history reads per frame (16 384 taps: 8 partitions instead of the 32 of
+ *          convolution.rs:120-132), product and inverse transform in one kernel.  Needs strides that are multiples of 4
+ *          floats and 16-byte aligned buffers.
  *      Equal to plan 1 up to f32 rounding (2-4e-7 relative RMS against the oracle, like every FFT path), not bit for bit,
  *      and the rounding depends on where the calls cut the signal.  The plans hand the per-stream state over to each other:
  *      any sequence of calls under any sequence of plans is one continuous signal.
  *   0  the library's choice (default).  One partition: plan 2 for calls of 48 blocks or more on 512 streams or more -- on
  *      256 or more when the call is out of place and the EQ is off --, plan 1 otherwise (at BASELINE configs[2] the
- *      convolution hides under the EQ either way, and the block-512 bits stay as recorded).  Longer responses (8 partitions
- *      or more): plan 2 for every call -- its 2048-frame blocks sit on the stream's absolute grid, so calls of any length
- *      continue one another.
+ *      convolution hides under the EQ either way, and the block-512 bits stay as recorded).  Longer responses: plan 2 for every
+ *      call -- its 2048-frame blocks sit on the stream's absolute grid, so calls of any length continue one another.
  * The single-stream engine is always served by the reference blocking. */
 int  ohs_batch_set_conv_plan(ohs_batch *b, int plan);
 /* What served the handle's most recent convolution launch (of the last time chunk, when a call is cut into several): the

@@ -767,7 +767,7 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
         // last block's input copy 4 KiB
         const uint64_t state = b->conv.lazy_ok ? 3u * 4096u : 2u * 8192u;
         *conv_bytes = nbk * S * 8192u + S * ((K - 1) * (own_tails ? 1u : 3u) * 4096u + state);
-    } else if (b->conv.d_xhist && P >= kLbMinP &&
+    } else if (b->conv.d_xhist && P >= lb_min_p() &&
                (b->conv.conv_plan == 2 || (b->conv.conv_plan == 0 && conv_plan_auto_is_lb((size_t)S, (long long)nbk, P)))) {
         // block-2048 plan: audio in, ring write (16 B per frame), ring read once, audio out -- the product never leaves the
         // chip; plus the input history copied once per segment (read + write)

@@ -175,22 +175,30 @@ int conv_grow_ring(ConvState &c, int need, hipStream_t st)
 // ---- block-2048 plan: the host side of its state (api_internal.h: ConvState) -----------------------------------------
 static long long lb_p2pad_for(int Pmax) { return ((((long long)Pmax + 3) / 4) + 3) / 4 * 4; }    // 2048-tap partitions, multiple of 4
 
-// the time-domain copy of path `path`'s response (batch objects): [4][irl_len], grown as needed
+// the time-domain copies of the four responses (batch objects): [4][irl_len], zero-padded, grown as needed
+static int conv_lb_irl_reserve(ConvState &c, long long need, hipStream_t st)
+{
+    if (need <= c.irl_len) return OHS_OK;
+    DeviceWideSection dws;
+    float *n = nullptr;
+    HIP_TRY(hipMalloc(&n, 4 * (size_t)need * sizeof(float)));
+    hipError_t e = hipMemsetAsync(n, 0, 4 * (size_t)need * sizeof(float), st);
+    if (e == hipSuccess && c.d_irl)
+        e = hipMemcpy2DAsync(n, (size_t)need * sizeof(float), c.d_irl, (size_t)c.irl_len * sizeof(float),
+                             (size_t)c.irl_len * sizeof(float), 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { hipFree(n); return fail(OHS_ERR_HIP, std::string("impulse response copy: ") + hipGetErrorString(e)); }
+    if (c.d_irl) hipFree(c.d_irl);
+    c.d_irl = n; c.irl_len = need;
+    c.lb_cd_valid = false;
+    return OHS_OK;
+}
+
 int conv_lb_store_ir(ConvState &c, int path, const float *d_src, const float *h_src, size_t len, int P, hipStream_t st)
 {
-    const long long need = lb_p2pad_for(P) * kLbBlock;
-    if (need > c.irl_len) {
-        DeviceWideSection dws;
-        float *n = nullptr;
-        HIP_TRY(hipMalloc(&n, 4 * (size_t)need * sizeof(float)));
-        hipError_t e = hipMemsetAsync(n, 0, 4 * (size_t)need * sizeof(float), st);
-        if (e == hipSuccess && c.d_irl)
-            e = hipMemcpy2DAsync(n, (size_t)need * sizeof(float), c.d_irl, (size_t)c.irl_len * sizeof(float),
-                                 (size_t)c.irl_len * sizeof(float), 4, hipMemcpyDeviceToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { hipFree(n); return fail(OHS_ERR_HIP, std::string("impulse response copy: ") + hipGetErrorString(e)); }
-        if (c.d_irl) hipFree(c.d_irl);
-        c.d_irl = n; c.irl_len = need;
+    {
+        const int rcr = conv_lb_irl_reserve(c, lb_p2pad_for(P) * kLbBlock, st);
+        if (rcr) return rcr;
     }
     if (!c.d_irl) return OHS_OK;
     float *dst = c.d_irl + (size_t)path * c.irl_len;
@@ -209,7 +217,7 @@ int conv_lb_after_set_ir(ConvState &c, hipStream_t st)
     if (!c.lazy_ok) return OHS_OK;
     int Pmax = 1;
     for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
-    const long long want = Pmax >= kLbMinP ? lb_p2pad_for(Pmax) * kLbBlock : 0;
+    const long long want = Pmax >= lb_min_p() ? lb_p2pad_for(Pmax) * kLbBlock : 0;
     if (want != c.xh_len) {
         DeviceWideSection dws;
         HIP_TRY(hipStreamSynchronize(st));
@@ -251,14 +259,14 @@ int conv_lb_after_set_ir(ConvState &c, hipStream_t st)
 }
 
 // ohs_batch_set_conv_plan(0) for long responses: the block-2048 plan for every call of an object whose longest response has
-// kLbMinP partitions or more.  Its windows sit on the stream's absolute grid, so a call of any length -- the plugin's
+// lb_min_p() partitions or more.  Its windows sit on the stream's absolute grid, so a call of any length -- the plugin's
 // 1024-frame block included -- continues the ring the previous call left (one or two windows to transform, no warm-up), and
 // it beats the block-512 kernels at every call length measured (profiles/r05_short_calls_*.jsonl: 64 streams x 16 384 taps,
 // 2-block calls 26 vs 35 us even WITH a warm-up per call; 256-block calls 0.138 vs 0.25 ms).
 bool conv_plan_auto_is_lb(size_t S, long long n_blocks, int Pmax)
 {
     (void)S; (void)n_blocks;
-    return Pmax >= kLbMinP;
+    return Pmax >= lb_min_p();
 }
 
 // segment length of a block-2048 launch sequence, in blocks of 2048: keeps the ring around 128 MiB
@@ -475,6 +483,34 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
     DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    if (c.lazy_ok && !c.d_xhist && c.tails_lazy && c.d_last_in) {
+        // The first response of several partitions on an object that has run the one-partition fast path so far: no input
+        // history was kept, but one-partition paths reach back 511 frames only, and the fast path's state at rest holds
+        // the last block's 512 input frames.  Seeded with those, the history vouches for every path's reach, and the
+        // reset below can carry the other paths' past as pending tails.
+        int Pmax_after = P;
+        for (int p = 0; p < 4; ++p)
+            if (p != path) Pmax_after = std::max(Pmax_after, c.P[p]);
+        bool all_one = true;
+        for (int p = 0; p < 4; ++p) all_one = all_one && c.P[p] == 1;
+        if (all_one && Pmax_after >= lb_min_p()) {
+            const long long want = lb_p2pad_for(Pmax_after) * kLbBlock;
+            const size_t bytes = c.S * 2 * (size_t)want * sizeof(float);
+            float *n = nullptr, *n2 = nullptr;
+            HIP_TRY(hipMalloc(&n, 2 * bytes));
+            if (hipMalloc(&n2, bytes) != hipSuccess) { hipFree(n); return fail(OHS_ERR_HIP, "hipMalloc(input history) failed"); }
+            hipError_t e = hipMemsetAsync(n, 0, 2 * bytes, st);
+            if (e == hipSuccess)        // frames -512 .. -1 at ring positions 0 .. 511, the next frame goes to 512
+                e = hipMemcpy2DAsync(n, (size_t)(2 * want) * sizeof(float), c.d_last_in, (size_t)BS * sizeof(float),
+                                     (size_t)BS * sizeof(float), c.S * 2, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { hipFree(n); hipFree(n2); return fail(OHS_ERR_HIP, std::string("input history: ") + hipGetErrorString(e)); }
+            c.d_xhist = n; c.d_xhist_alt = n2; c.xh_len = want; c.xh_head = BS; c.xh_valid = BS;
+            c.lb_valid = 0; c.lb_cd_valid = false;
+            const int rcr = conv_lb_irl_reserve(c, want, st);       // (the tails' tables span the new reach)
+            if (rcr) return rcr;
+        }
+    }
     {   // an object that keeps the input history turns a reset in mid-stream into "all paths forget" + pending tails
         bool taken = false;
         const int rct = conv_lb_tail_route(c, ctx, path, st, &taken);
@@ -765,7 +801,7 @@ static int conv_launch_impl(ConvState &c, DeviceCtx *ctx, const float *in, long 
         ev_scope.armed = true;
         int Pmax = 1;
         for (int p = 0; p < 4; ++p) Pmax = std::max(Pmax, c.P[p]);
-        if (allow_fast && c.d_xhist && Pmax >= kLbMinP) {
+        if (allow_fast && c.d_xhist && Pmax >= lb_min_p()) {
             // Block 2048 / FFT 4096 (conv_lb_kernels.hip).  It convolves the input history itself, so every path must be
             // allowed to see all of its own response's reach of it: older than its response (and the history that deep),
             // or reset together with all the others (the history was zeroed then).

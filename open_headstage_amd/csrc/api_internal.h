@@ -146,7 +146,7 @@ struct ConvState {
     bool cd_os_valid = false;
     int conv_plan = 0;              // ohs_batch_set_conv_plan: 0 = the library's choice, 1 = block 512 / FFT 1024, 2 = the large-transform
                                     // plans (one partition: hop 1536 / FFT 2048; longer responses: block 2048 / FFT 4096)
-    // Block-2048 plan for long impulse responses (conv_lb_kernels.hip; batch objects with a response of kLbMinP partitions
+    // Block-2048 plan for long impulse responses (conv_lb_kernels.hip; batch objects with a response of lb_min_p() partitions
     // or more).  It is overlap-save on the INPUT: the state it needs and leaves is the last xh_len input frames of every
     // stream (d_xhist; every P > 1 launch of such an object keeps it current), not spectra and overlaps.  While lb_lazy,
     // d_hist / d_tails are stale; conv_materialise_state rebuilds them from d_xhist when another plan needs them.
@@ -196,7 +196,7 @@ int conv_grow_ring(ConvState &c, int need, hipStream_t st);
 int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st,
                 bool ir_on_device = false);
 bool conv_plan_auto_is_os(size_t S, long long n_blocks, bool in_place);
-constexpr int kLbMinP = 8;          // 512-tap partitions from which the block-2048 plan is considered (taps > 3584)
+inline int lb_min_p() { return tuning().lb_min_p; }     // 512-tap partitions from which the block-2048 plan is considered (2: taps > 512)
 bool conv_plan_auto_is_lb(size_t S, long long n_blocks, int Pmax);
 int conv_os_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, bool in_place);
 // time chunks per stream of the one-partition kernel's launch plan (also what ohs_batch_kernel_bytes prices)

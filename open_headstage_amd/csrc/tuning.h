@@ -36,6 +36,9 @@ struct Tuning {
     std::vector<double> overlap_cuts = {0.0, 0.25, 0.5, 0.75, 0.92, 0.98, 1.0};
     std::vector<unsigned> conv_cu_mask;     // non-empty: the overlapped convolution's stream gets this CU mask
     int mac_no_xcd = 0;                     // plain stream-major workgroup order in k_conv_tp_mac
+    int lb_min_p = 2;                       // 512-tap partitions of the longest response from which the block-2048 plan is considered:
+                                            // every response longer than one partition (64 streams x 256 blocks: taps 1024 0.122 vs 0.189 ms for
+                                            // block 512, taps 3000 0.123 vs 0.191; 256 streams 0.50 vs 0.79 -- LABNOTES round 5)
     int lb_skip = 0;                        // k_conv_lb_mac_inverse timing knock-outs (WRONG results; experiments build only): 1 = no
                                             // products, 2 = no inverse transforms, 4 = no ring loads, 8 = no table loads
     // ohs_batch_process_host

@@ -1,4 +1,4 @@
-"""The block-2048 / FFT-4096 plan for long impulse responses (ohs_batch_set_conv_plan(2) with taps > 3584;
+"""The block-2048 / FFT-4096 plan for long impulse responses (ohs_batch_set_conv_plan(2) with taps > 512;
 csrc/conv_lb_kernels.hip) against the oracle -- the restatement of the reference's uniform block-512 partitioning
 (src/dsp/convolution.rs:120-132,236-289) -- and against f64 direct convolution: every remainder of the call length modulo
 the 2048-frame block, calls that continue the previous call's window grid and calls that do not, several segments per
@@ -294,7 +294,8 @@ def test_the_library_picks_block_2048_for_long_calls_on_long_responses():
     from open_headstage_amd import synth
     dev = torch.device("cuda:0")
     for taps, nb, want in ((16384, 64, "block2048"), (16384, 12, "block2048"), (16384, 2, "block2048"),
-                           (3000, 64, "block512_tp"), (3000, 2, "block512_tp"), (4096, 16, "block2048")):
+                           (3000, 64, "block2048"), (1024, 2, "block2048"), (513, 7, "block2048"), (512, 64, "block512_p1"),
+                           (512, 7, "block512_p1"), (4096, 16, "block2048")):
         bp = _make(ohs, 4, synth.hrir_set(taps), 0)
         x = synth.white_noise_torch(3, 4, nb * 512, dev)
         bp.process(x)
