@@ -269,10 +269,10 @@ bool conv_plan_auto_is_lb(size_t S, long long n_blocks, int Pmax)
     return Pmax >= lb_min_p();
 }
 
-// segment length of a block-2048 launch sequence, in blocks of 2048: keeps the ring around 128 MiB
+// segment length of a block-2048 launch sequence, in blocks of 2048 (the ring holds a segment's windows: 32 KiB each)
 static long long lb_segment_blocks(size_t S)
 {
-    long long seg = 4096 / (long long)std::max<size_t>(S, 1);
+    long long seg = (long long)tuning().lb_seg_windows / (long long)std::max<size_t>(S, 1);
     seg = std::max<long long>(8, std::min<long long>(seg, 256));
     return seg / kLbTile * kLbTile;
 }

@@ -39,6 +39,9 @@ struct Tuning {
     int lb_min_p = 2;                       // 512-tap partitions of the longest response from which the block-2048 plan is considered:
                                             // every response longer than one partition (64 streams x 256 blocks: taps 1024 0.122 vs 0.189 ms for
                                             // block 512, taps 3000 0.123 vs 0.191; 256 streams 0.50 vs 0.79 -- LABNOTES round 5)
+    int lb_seg_windows = 131072;            // windows (streams x blocks of 2048) per block-2048 launch pair, i.e. a ring of at most 4 GiB (a call's
+                                            // own I/O at that size: 4 GiB): 512 streams x 256 blocks 1.16 ms at 4 096 -> 0.84, 2 048 streams 2.97 ms
+                                            // (profiles/r05_lb_seg_sweep.txt)
     int lb_skip = 0;                        // k_conv_lb_mac_inverse timing knock-outs (WRONG results; experiments build only): 1 = no
                                             // products, 2 = no inverse transforms, 4 = no ring loads, 8 = no table loads
     // ohs_batch_process_host

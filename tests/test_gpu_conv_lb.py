@@ -150,13 +150,14 @@ def test_paths_of_different_lengths_and_a_muted_path(oracle):
 
 
 def test_several_segments_per_call(oracle):
-    """600 streams: segments of 8 blocks of 2048, so a 100-block call is four segments (the last one ragged); streams 0, 299
-    and 599 against the oracle, every stream against the stream it repeats"""
+    """A launch pair serves at most 256 blocks of 2048 per stream (131 072 windows over all streams: the ring stays within
+    4 GiB), so a 1 102-block call is two segments, the second one short and ragged; streams 0, 19 and 39 against the oracle, every
+    stream against the stream it repeats"""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
     dev = torch.device("cuda:0")
-    S, nb, taps = 600, 100, 4200
+    S, nb, taps = 40, 1102, 4200
     irs = synth.hrir_set(taps)
     bp = _make(ohs, S, irs, 2)
     base = synth.white_noise_torch(21, 3, 2 * nb * 512, dev)
@@ -168,7 +169,7 @@ def test_several_segments_per_call(oracle):
         assert torch.equal(y[s], y[s % 3]), f"stream {s} differs from stream {s % 3}"
     engs = _oracle_engines(oracle, irs, 3)
     xb = base.cpu().numpy()
-    for s in (0, 299, 599):
+    for s in (0, 19, 39):
         ref = np.stack(engs[s % 3].process_block(xb[s % 3, 0], xb[s % 3, 1]))
         assert_parity(y[s].cpu().numpy(), ref, f"multi-segment, stream {s}")
         engs[s % 3] = _oracle_engines(oracle, irs, 1)[0]

@@ -8,11 +8,12 @@ behind a zeroed gap of the ring and k_conv_tp_old adds, under the per-path gate,
 Checked: parity with the oracle across several resets (longer, shorter, muted), and the cost of the call after a reset.
 
 Round 5: the steady call of this shape is served by the block-2048 plan (0.13 ms instead of 0.25), and an object that keeps
-the input history (every batch object with a response of 8 partitions or more) carries a per-path set_ir out as "every
+the input history (every batch object with a response of two partitions or more) carries a per-path set_ir out as "every
 path forgets its past" + pending tails -- what the frames in front of the reset still owe the output through the surviving
 paths, computed once at set_ir time and added to the calls that follow (api_conv.hip: conv_lb_tail_route).  The call
 behind the reset is block 2048 as well: 0.16-0.175 ms = 1.3 x the steady call.  The gated block-512 kernels of round 4
-still serve objects without the history (responses of 2-7 partitions): the small-shape tests below.
+still serve objects told to keep the reference blocking (ohs_batch_set_conv_plan(1)) and calls whose buffers the block-2048
+kernels cannot address (odd strides, 4-byte alignment).
 """
 import numpy as np
 import pytest
@@ -119,11 +120,13 @@ def test_the_call_after_a_per_path_set_ir_costs_at_most_three_steady_calls():
     assert worst <= 2.0 * steady, (steady, after)
 
 
+@pytest.mark.parametrize("plan", [1, 0])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_gated_time_parallel_calls_small_shapes_vs_oracle(oracle, seed):
-    """The same plan at small, odd shapes: per-path partition counts that differ, calls of exactly Pmax blocks (the
-    shortest the gated time-parallel plan takes), shorter ones (general kernel) in between, resets before the previous
-    reset has aged out, a ring that wraps."""
+def test_gated_time_parallel_calls_small_shapes_vs_oracle(oracle, seed, plan):
+    """Small, odd shapes: per-path partition counts that differ, calls of exactly Pmax blocks (the shortest the gated
+    time-parallel kernels take), shorter ones in between, resets before the previous reset has aged out, a ring that
+    wraps.  plan 1: the reference blocking with the per-path gate; plan 0: what the library picks (block 2048 + pending
+    tails while some response has two partitions or more)."""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
@@ -132,6 +135,7 @@ def test_gated_time_parallel_calls_small_shapes_vs_oracle(oracle, seed):
     taps = [int(rng.integers(513, 5200)) for _ in range(4)]
     irs = [synth.hrir_set(t)[p] for p, t in enumerate(taps)]
     bp = ohs.BatchProcessor(Sx, num_bands=10)
+    bp.set_conv_plan(plan)
     engs = [oracle.ConvolutionEngine() for _ in range(Sx)]
     for p in range(4):
         bp.set_ir(p, irs[p])
@@ -139,7 +143,7 @@ def test_gated_time_parallel_calls_small_shapes_vs_oracle(oracle, seed):
             e.set_ir(p, irs[p])
     pmax = lambda: max(int(bp_P[p]) for p in range(4))          # noqa: E731
     bp_P = [(t + 511) // 512 for t in taps]
-    got, ref = [], []
+    got, ref, served = [], [], set()
     for step in range(9):
         if step % 2 == 1:       # a per-path reset before every other call
             path = int(rng.integers(0, 4))
@@ -152,7 +156,9 @@ def test_gated_time_parallel_calls_small_shapes_vs_oracle(oracle, seed):
         n = [pmax(), pmax() + 1, 3, 2 * pmax() + 5, 1][int(rng.integers(0, 5))]
         x = synth.white_noise(range(100 * step, 100 * step + Sx), n * 512)
         got.append(bp.process(torch.from_numpy(x).cuda()).cpu().numpy())
+        served.add(bp.last_conv_plan()[0])
         ref.append(np.stack([np.stack(engs[s].process_block(x[s, 0], x[s, 1])) for s in range(Sx)]))
+    assert ("block2048" in served) == (plan == 0), served
     g, r = np.concatenate(got, axis=2), np.concatenate(ref, axis=2)
     for s in range(Sx):
         assert_parity(g[s], r[s], f"seed {seed} stream {s}")
