@@ -363,13 +363,15 @@ enum ohs_conv_kernel {
     OHS_CONV_KERNEL_HOP1536_P1 = 2,     /* k_conv_p1_os: one partition, hop 1536 / FFT 2048 */
     OHS_CONV_KERNEL_BLOCK512_TP = 3,    /* k_conv_tp_*: several partitions, block 512, time-parallel */
     OHS_CONV_KERNEL_BLOCK2048 = 4,      /* k_conv_lb_*: several partitions, block 2048 / FFT 4096 */
-    OHS_CONV_KERNEL_SEQUENTIAL = 5      /* k_conv_general: one wave per stream, blocks in sequence */
+    OHS_CONV_KERNEL_SEQUENTIAL = 5,     /* k_conv_general: one wave per stream, blocks in sequence */
+    /* 6: never reported by this library (the experiments build's block 8192 / FFT 16384 kernel: slower, not shipped) */
+    OHS_CONV_KERNEL_COUNT = 8           /* length of ohs_batch_conv_plan_counts' array (6 and 7 are not reported by this library) */
 };
 int  ohs_batch_last_conv_plan(const ohs_batch *b, int *kernel, int *ranges_per_stream);
 /* convolution launch sequences served per kernel family (counts[OHS_CONV_KERNEL_*]) since the handle was created or since
  * the last call with reset != 0: a processing call that is cut into time chunks counts once per chunk, and the chunks of
  * one call need not be served alike (the short last chunk of an overlapped step usually is not) */
-int  ohs_batch_conv_plan_counts(ohs_batch *b, uint64_t counts[6], int reset);
+int  ohs_batch_conv_plan_counts(ohs_batch *b, uint64_t counts[8] /* OHS_CONV_KERNEL_COUNT */, int reset);
 /* zero every stream's EQ state, history and overlap (IRs and EQ table kept).  Also the way back from a failed handle:
  * a HIP failure in the middle of a processing call leaves the per-stream state advanced for some time chunks only, so
  * the call joins its internal stream, returns OHS_ERR_HIP, and every later processing call on the handle returns

@@ -96,7 +96,7 @@ class BatchProcessor:
         (ohs_batch_set_conv_plan)"""
         self._check(self._lib.ohs_batch_set_conv_plan(self._h, int(plan)))
 
-    CONV_KERNELS = {0: "none", 1: "block512_p1", 2: "hop1536_p1", 3: "block512_tp", 4: "block2048", 5: "sequential"}
+    CONV_KERNELS = {0: "none", 1: "block512_p1", 2: "hop1536_p1", 3: "block512_tp", 4: "block2048", 5: "sequential", 6: "block8192"}
 
     def last_conv_plan(self):
         """(kernel family name, ranges per stream) of the most recent convolution launch (ohs_batch_last_conv_plan)"""
@@ -106,9 +106,9 @@ class BatchProcessor:
 
     def conv_plan_counts(self, reset: bool = False) -> dict:
         """convolution launch sequences per kernel family since creation / the last reset read (ohs_batch_conv_plan_counts)"""
-        c = (C.c_uint64 * 6)()
+        c = (C.c_uint64 * 8)()
         self._check(self._lib.ohs_batch_conv_plan_counts(self._h, c, int(bool(reset))))
-        return {self.CONV_KERNELS[k]: int(c[k]) for k in range(1, 6) if c[k]}
+        return {self.CONV_KERNELS[k]: int(c[k]) for k in range(1, 7) if c[k]}
 
     def reset(self) -> None:
         self._check(self._lib.ohs_batch_reset(self._h))

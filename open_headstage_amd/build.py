@@ -69,7 +69,10 @@ def _units():
         # host-only C++ (RBJ coefficient formulas + the musl restatement of sinf / cosf / powf: every operation rounds
         # by itself)
         ("biquad_coeffs.cpp", ["-x", "hip", "-ffp-contract=off"]),
-    ]
+    ] + ([
+        # experiments builds only: block 8192 / FFT 16384 in one kernel -- parity-green, slower than the block-2048 plan (LABNOTES.md)
+        ("experiments/conv_xb_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
+    ] if EXPERIMENTS else [])
 
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -135,7 +138,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objs = []
     for src, extra in units:
-        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(OBJ, os.path.splitext(src)[0].replace("/", "_") + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or _read_obj_hash(obj) != want[src]:
             cmd = [hipcc, *COMMON, *extra, *EXTRA_DEFS, "-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics", "-c",

@@ -193,12 +193,12 @@ int ohs_batch_last_conv_plan(const ohs_batch *b, int *kernel, int *ranges_per_st
     return OHS_OK;
 }
 
-int ohs_batch_conv_plan_counts(ohs_batch *b, uint64_t counts[6], int reset)
+int ohs_batch_conv_plan_counts(ohs_batch *b, uint64_t counts[OHS_CONV_KERNEL_COUNT], int reset)
 {
     if (!b || !counts) return fail(OHS_ERR_INVALID_ARG, "NULL argument");
-    for (int k = 0; k < 6; ++k) counts[k] = b->conv.kernel_calls[k];
+    for (int k = 0; k < OHS_CONV_KERNEL_COUNT; ++k) counts[k] = b->conv.kernel_calls[k];
     if (reset)
-        for (int k = 0; k < 6; ++k) b->conv.kernel_calls[k] = 0;
+        for (int k = 0; k < OHS_CONV_KERNEL_COUNT; ++k) b->conv.kernel_calls[k] = 0;
     return OHS_OK;
 }
 

@@ -33,12 +33,15 @@ void conv_free(ConvState &c)
     if (c.d_lb_cd) hipFree(c.d_lb_cd);
     if (c.d_lb_ab) hipFree(c.d_lb_ab);
     if (c.d_lb_cd_alt) hipFree(c.d_lb_cd_alt);
+    if (c.d_xb_cd) hipFree(c.d_xb_cd);
+    if (c.d_xb_ab) hipFree(c.d_xb_ab);
+    c.d_xb_cd = nullptr; c.d_xb_ab = nullptr; c.xb_p2 = 0; c.xb_cd_gen = 0;
     if (c.d_ptail) hipFree(c.d_ptail);
     if (c.d_ptail_alt) hipFree(c.d_ptail_alt);
     c.d_lb_cd_alt = nullptr; c.lb_cd_alt_p2pad = 0; c.d_ptail = nullptr; c.d_ptail_alt = nullptr; c.pt_len = 0; c.pt_active = false;
     c.d_irl = nullptr; c.irl_len = 0; c.d_xhist = nullptr; c.d_xhist_alt = nullptr; c.xh_len = 0; c.xh_valid = 0;
     c.d_lb_ring = nullptr; c.lb_ring_cap = 0; c.lb_valid = 0; c.d_lb_cd = nullptr; c.d_lb_ab = nullptr; c.lb_p2pad = 0;
-    c.lb_cd_valid = false; c.lb_lazy = false;
+    c.lb_cd_valid = false; c.lb_tables_gen++; c.lb_lazy = false;
     c.d_irt = nullptr; c.d_cd_os = nullptr; c.cd_os_valid = false;
     c.d_merged = nullptr; c.d_merged_alt = nullptr; c.d_last_in = nullptr; c.tails_lazy = false; c.lazy_ok = false;
     c.d_cdm = nullptr; c.d_W = nullptr; c.d_W1 = nullptr;
@@ -190,7 +193,7 @@ static int conv_lb_irl_reserve(ConvState &c, long long need, hipStream_t st)
     if (e != hipSuccess) { hipFree(n); return fail(OHS_ERR_HIP, std::string("impulse response copy: ") + hipGetErrorString(e)); }
     if (c.d_irl) hipFree(c.d_irl);
     c.d_irl = n; c.irl_len = need;
-    c.lb_cd_valid = false;
+    c.lb_cd_valid = false; c.lb_tables_gen++;
     return OHS_OK;
 }
 
@@ -206,7 +209,7 @@ int conv_lb_store_ir(ConvState &c, int path, const float *d_src, const float *h_
     if (len && d_src) HIP_TRY(hipMemcpyAsync(dst, d_src, len * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (len && h_src) HIP_TRY(hipMemcpyAsync(dst, h_src, len * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    c.lb_cd_valid = false;
+    c.lb_cd_valid = false; c.lb_tables_gen++;
     return OHS_OK;
 }
 
@@ -245,7 +248,7 @@ int conv_lb_after_set_ir(ConvState &c, hipStream_t st)
         c.xh_len = want;
         c.xh_head = want;           // (the kept frames end at position `want`: the next frame goes there)
         c.lb_valid = 0;         // (the ring's depth follows the partition count)
-        c.lb_cd_valid = false;
+        c.lb_cd_valid = false; c.lb_tables_gen++;
     }
     if (c.d_xhist && c.since[0] == 0 && c.since[1] == 0 && c.since[2] == 0 && c.since[3] == 0) {
         // every path has forgotten its past (convolution.rs:135-137): so has the input history, and zeros are what every path
@@ -288,7 +291,7 @@ static int conv_lb_prepare(ConvState &c, DeviceCtx *ctx, hipStream_t st, ConvLbA
         HIP_TRY(hipStreamSynchronize(st));
         if (c.d_lb_cd) hipFree(c.d_lb_cd);
         if (c.d_lb_ab) hipFree(c.d_lb_ab);
-        c.d_lb_cd = nullptr; c.d_lb_ab = nullptr; c.lb_p2pad = 0; c.lb_cd_valid = false;
+        c.d_lb_cd = nullptr; c.d_lb_ab = nullptr; c.lb_p2pad = 0; c.lb_cd_valid = false; c.lb_tables_gen++;
         HIP_TRY(hipMalloc(&c.d_lb_cd, (size_t)P2pad * 2 * kLbBlock * sizeof(float4)));
         HIP_TRY(hipMalloc(&c.d_lb_ab, (size_t)P2pad * 2 * kLbBlock * sizeof(float4)));
         c.lb_p2pad = P2pad;
@@ -473,6 +476,58 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     return OHS_OK;
 }
 
+#ifdef OHS_EXPERIMENTS
+// Block 8192 / FFT 16384, one kernel (experiments/conv_xb_kernels.hip; experiments build only, off by default: slower than block 2048): long out-of-place calls on responses of at most two 8192-tap
+// partitions.  It starts from the input history like the block-2048 plan and leaves the same state behind (the history
+// advanced; the block-2048 window ring does not see the call's blocks).
+static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs, float *out,
+                          long long out_ss, long long out_cs, int n_blocks, int P2, float gain, hipStream_t st)
+{
+    if (c.xb_p2 != P2 || !c.d_xb_cd) {
+        DeviceWideSection dws;
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c.d_xb_cd) hipFree(c.d_xb_cd);
+        if (c.d_xb_ab) hipFree(c.d_xb_ab);
+        c.d_xb_cd = nullptr; c.d_xb_ab = nullptr; c.xb_p2 = 0; c.xb_cd_gen = 0;
+        HIP_TRY(hipMalloc(&c.d_xb_cd, (size_t)P2 * 2 * kXbBlock * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c.d_xb_ab, (size_t)2 * P2 * kXbBlock * sizeof(float4)));
+        c.xb_p2 = P2;
+    }
+    ConvXbArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.tw = ctx->d_tw; a.tw16384 = ctx->d_tw16384; a.P2 = P2;
+    if (c.xb_cd_gen != c.lb_tables_gen) {
+        if (c.irl_len < (long long)P2 * kXbBlock) return fail(OHS_ERR_HIP, "block-8192 plan: impulse responses not stored");
+        ConvXbArgs t = a;
+        t.in = c.d_irl; t.in_stream_stride = 2 * c.irl_len; t.in_ch_stride = c.irl_len; t.io_frames = c.irl_len;
+        t.n_streams = 2; t.n_blk = P2; t.run = 1; t.ab = c.d_xb_ab; t.tables_mode = 1;
+        t.fp_mode = 0;      // (tables are built in IEEE arithmetic, like k_ir_spectrum's)
+        hipError_t e = launch_conv_xb(t, st);
+        if (e == hipSuccess) e = launch_conv_xb_build_cd(c.d_xb_ab, P2, c.d_xb_cd, st);
+        if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-8192 tables: ") + hipGetErrorString(e));
+        c.xb_cd_gen = c.lb_tables_gen;
+    }
+    const long long frames = (long long)n_blocks * BS;
+    a.in = in; a.out = out;
+    a.in_stream_stride = in_ss; a.in_ch_stride = in_cs; a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
+    a.xhist = c.d_xhist; a.xh_len = c.xh_len; a.xh_head = c.xh_head;
+    a.io_frames = frames; a.n_streams = (int)c.S; a.n_blk = (int)((frames + kXbBlock - 1) / kXbBlock);
+    a.run = tuning().xb_run > 0 ? std::min(tuning().xb_run, a.n_blk) : conv_xb_run_for(a.n_streams, a.n_blk, P2, ctx->num_cus);
+    a.cd = c.d_xb_cd; a.gain = gain; a.fp_mode = c.fp_mode;
+    hipError_t e = launch_conv_xb(a, st);
+    // the call's last frames join the input history (behind the kernel: it reads the history's present state)
+    const long long xcnt = std::min(frames, c.xh_len);
+    if (e == hipSuccess) e = launch_conv_lb_xhist_append(in, in_ss, in_cs, c.d_xhist, c.xh_len, c.xh_head, frames, (int)c.S, st);
+    if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-8192 launch: ") + hipGetErrorString(e));
+    c.xh_head = (c.xh_head + xcnt) % (2 * c.xh_len);
+    c.xh_valid = std::min(c.xh_len, c.xh_valid + frames);
+    c.lb_valid = 0;             // (the block-2048 window ring has not seen these blocks)
+    c.lb_lazy = true;
+    c.last_kernel = 6; c.last_ranges = (a.n_blk + a.run - 1) / a.run;
+    return OHS_OK;
+}
+#endif
+
 // set_ir (convolution.rs:111-139) for one path; `ir` is a host pointer, or a device pointer on the state's
 // device when ir_on_device (the node-level batch hands over what RCCL has just broadcast)
 int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t len, hipStream_t st,
@@ -506,7 +561,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { hipFree(n); hipFree(n2); return fail(OHS_ERR_HIP, std::string("input history: ") + hipGetErrorString(e)); }
             c.d_xhist = n; c.d_xhist_alt = n2; c.xh_len = want; c.xh_head = BS; c.xh_valid = BS;
-            c.lb_valid = 0; c.lb_cd_valid = false;
+            c.lb_valid = 0; c.lb_cd_valid = false; c.lb_tables_gen++;
             const int rcr = conv_lb_irl_reserve(c, want, st);       // (the tails' tables span the new reach)
             if (rcr) return rcr;
         }
@@ -680,7 +735,7 @@ int conv_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, 
                 bool allow_fast, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int rc = conv_launch_impl(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st, allow_fast, ev_start, ev_stop);
-    if (rc == OHS_OK && n_blocks > 0 && c.last_kernel >= 0 && c.last_kernel < 6) c.kernel_calls[c.last_kernel]++;
+    if (rc == OHS_OK && n_blocks > 0 && c.last_kernel >= 0 && c.last_kernel < 8) c.kernel_calls[c.last_kernel]++;
     if (rc == OHS_OK && n_blocks > 0 && c.pt_active) {
         // what the frames in front of a per-path set_ir still owe these frames (conv_lb_tail_route)
         const long long n = (long long)n_blocks * BS;
@@ -812,7 +867,22 @@ static int conv_launch_impl(ConvState &c, DeviceCtx *ctx, const float *in, long 
             const bool lb_ok = (deep || together) && ((in_ss | in_cs | out_ss | out_cs) & 3) == 0 &&
                                ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
             if (lb_ok && (c.conv_plan == 2 || (c.conv_plan == 0 && conv_plan_auto_is_lb(c.S, n_blocks, Pmax)))) {
+#ifdef OHS_EXPERIMENTS
+                // long calls on responses of at most two 8192-tap partitions, out of place (the buffers must not overlap at
+                // all: a run's first windows read frames in front of its own blocks): block 8192, one kernel -- when a test or a
+                // sweep turns it on (Tuning::xb_min_p)
+                const int P2x = (Pmax + 15) / 16;
+                const long long call_frames = (long long)n_blocks * BS;
+                const float *in_end = in + (c.S - 1) * in_ss + in_cs + call_frames;
+                const float *out_end = out + (c.S - 1) * out_ss + out_cs + call_frames;
+                const bool apart = in_end <= out || out_end <= in;
+                const bool xb = P2x <= 2 && apart && Pmax >= tuning().xb_min_p && n_blocks >= tuning().xb_min_blocks &&
+                                c.xh_len >= (long long)P2x * kXbBlock && call_frames < (1ll << 29);
+                const int rcl = xb ? conv_xb_launch(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, P2x, gain, st)
+                                   : conv_lb_launch(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st);
+#else
                 const int rcl = conv_lb_launch(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st);
+#endif
                 if (rcl) return rcl;
                 c.cnt += (unsigned long long)n_blocks;
                 for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;

@@ -97,6 +97,18 @@ int get_ctx(int device, DeviceCtx **out)
             return fail(OHS_ERR_HIP, "w4096 table upload failed");
         }
     }
+#ifdef OHS_EXPERIMENTS
+    {
+        std::vector<float2> t16(15 * 1024);
+        conv_xb_build_twiddles(t16.data());
+        if (hipMalloc(&c->d_tw16384, t16.size() * sizeof(float2)) != hipSuccess ||
+            hipMemcpy(c->d_tw16384, t16.data(), t16.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(c->d_tw);
+            delete c;
+            return fail(OHS_ERR_HIP, "w16384 table upload failed");
+        }
+    }
+#endif
     g_ctx.push_back(c);
     *out = c;
     return OHS_OK;

@@ -56,6 +56,7 @@ struct DeviceCtx {
     float2 *d_tw = nullptr;
     float2 *d_tw2048 = nullptr; // k_conv_p1_os: w2048^bin in the paired layout
     float2 *d_tw4096 = nullptr; // k_conv_lb_*: w4096^(n1 c), [3][1024]
+    float2 *d_tw16384 = nullptr;// experiments build: k_conv_xb's w16384^(n1 c), [15][1024]
     int *d_pairs = nullptr;     // k_conv_tp_mac: leaders of the spectrum position pairs {b, mirror(b)}
     int n_pairs = 0;
     int num_cus = 256;
@@ -179,9 +180,14 @@ struct ConvState {
     bool pt_active = false;
     float4 *d_lb_cd_alt = nullptr;  // tables of one speaker pair alone (the tails' two runs)
     int lb_cd_alt_p2pad = 0;
+    // experiments build: block 8192 / FFT 16384 (experiments/conv_xb_kernels.hip): tables of the response's one or two 8192-tap partitions; valid with lb_cd_valid's
+    // generation (every place that invalidates the block-2048 tables bumps lb_tables_gen)
+    float4 *d_xb_cd = nullptr, *d_xb_ab = nullptr;
+    int xb_p2 = 0;
+    unsigned long long lb_tables_gen = 1, xb_cd_gen = 0;
     // what served the last convolution launch (ohs_batch_last_conv_plan): OHS_CONV_KERNEL_*, and its ranges per stream
     int last_kernel = 0, last_ranges = 0;
-    unsigned long long kernel_calls[6] = {0, 0, 0, 0, 0, 0};     // conv_launch calls served per family (ohs_batch_conv_plan_counts)
+    unsigned long long kernel_calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // conv_launch calls served per family (ohs_batch_conv_plan_counts)
     // ohs_*_set_speakers: what it last loaded into each path (a set_ir from anywhere else forgets it), so that a
     // change of the speaker angles re-loads only the paths whose impulse response really changed
     std::vector<float> spk_ir[4];

@@ -42,6 +42,10 @@ struct Tuning {
     int lb_seg_windows = 131072;            // windows (streams x blocks of 2048) per block-2048 launch pair, i.e. a ring of at most 4 GiB (a call's
                                             // own I/O at that size: 4 GiB): 512 streams x 256 blocks 1.16 ms at 4 096 -> 0.84, 2 048 streams 2.97 ms
                                             // (profiles/r05_lb_seg_sweep.txt)
+    int xb_min_p = 1 << 30;                 // experiments build: 512-tap partitions of the longest response from which the block-8192 kernel
+                                            // (experiments/conv_xb_kernels.hip) serves long out-of-place calls; off by default: it is slower
+    int xb_min_blocks = 128;                // ... for calls of at least this many 512-frame blocks
+    int xb_run = 0;                         // > 0: blocks of 8192 per workgroup (else conv_xb_run_for)
     int lb_skip = 0;                        // k_conv_lb_mac_inverse timing knock-outs (WRONG results; experiments build only): 1 = no
                                             // products, 2 = no inverse transforms, 4 = no ring loads, 8 = no table loads
     // ohs_batch_process_host
