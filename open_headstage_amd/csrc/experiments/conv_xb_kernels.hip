@@ -1,7 +1,7 @@
 // conv_xb_kernels.hip -- long impulse responses in batch mode, long calls: block 8192 / FFT 16384, overlap-save, ONE kernel.
 //
 // EXPERIMENTS BUILD ONLY (libohs_hip_exp.so; off unless ohs_debug_set_tuning("xb_min_p", ..) turns it on): parity-green
-// (tests/test_gpu_conv_xb.py) and at the traffic it was designed for, but SLOWER than the block-2048 plan on BASELINE config 4 --
+// (tests/test_gpu_conv_xb.py), 356 MB of measured traffic per step against the block-2048 plan's 445, but SLOWER than the block-2048 plan on BASELINE config 4 --
 // 0.152-0.165 ms against 0.133-0.145 -- for the reason at the end of this comment.  Kept as the measured "no" it is (LABNOTES.md).
 //
 // What it replaces: the reference's uniform blocking (src/dsp/convolution.rs:22-23: block 512 / FFT 1024; :120-132: one
