@@ -513,7 +513,7 @@ static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     a.xhist = c.d_xhist; a.xh_len = c.xh_len; a.xh_head = c.xh_head;
     a.io_frames = frames; a.n_streams = (int)c.S; a.n_blk = (int)((frames + kXbBlock - 1) / kXbBlock);
     a.run = tuning().xb_run > 0 ? std::min(tuning().xb_run, a.n_blk) : conv_xb_run_for(a.n_streams, a.n_blk, P2, ctx->num_cus);
-    a.cd = c.d_xb_cd; a.gain = gain; a.fp_mode = c.fp_mode;
+    a.cd = c.d_xb_cd; a.gain = gain; a.fp_mode = c.fp_mode; a.debug_skip = tuning().xb_skip;
     hipError_t e = launch_conv_xb(a, st);
     // the call's last frames join the input history (behind the kernel: it reads the history's present state)
     const long long xcnt = std::min(frames, c.xh_len);

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
     const __amdgpu_buffer_rsrc_t r_tw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(A.tw16384), 0, 15 * 1024 * 8, 0x00020000);
     const int v4 = tid * 4, v8 = tid * 8, v16 = tid * 16, v4h = (tid & 511) * 4;
     const int half = 512 * (c >> 3);                    // the wave's 64 frames sit in this half of a 1024-frame sixteenth
+    const int dskip = A.debug_skip;
     auto twiddle = [&](int cc) {            // w16384^(tid cc), cc = 1 .. 15
+        if (dskip & 2) return make_float2(1.0f, 0.001f * cc);
         return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r_tw, v8, (cc - 1) * 8192, 0));
     };
 
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
         for (int n2 = 0; n2 < 16; ++n2) {
             float l = 0.f, r = 0.f;
             const long long f0 = w0 + 1024 * n2;
-            if (!A.tables_mode || n2 < 8) {
+            if ((!A.tables_mode || n2 < 8) && !(dskip & 1)) {
                 if (f0 >= 0) {
                     if (f0 + half < A.io_frames) {              // (uniform over the wave: everything is a multiple of 512)
                         const int so = __builtin_amdgcn_readfirstlane((int)(f0 * 4));
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
             }
             z[n2] = make_float2(l, r);
         }
-        dft16<false>(z);
+        if (!(dskip & 64)) dft16<false>(z);
 #pragma unroll
         for (int cc = 1; cc < 16; ++cc) z[cc] = cmul(z[cc], twiddle(cc));
         __syncthreads();                                // whoever still reads the slabs' previous image is done
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = lds_ld(&slab[64 * a + lane]);
         wave_lds_sync();
-        wave_fft_fwd(v, slab, tab, lane);               // register 4 r + j holds k1 = 4 lane + j + 256 r, i.e. bin 16 k1 + c
+        if (!(dskip & 4)) wave_fft_fwd(v, slab, tab, lane);               // register 4 r + j holds k1 = 4 lane + j + 256 r, i.e. bin 16 k1 + c
         __syncthreads();                                // every wave is done with its slab: the slabs become the XP image
 #pragma unroll
         for (int R = 0; R < 16; ++R) lds_st(&X[xb_pair_addr(64 * lane + 16 * (R & 3) + 4096 * (R >> 2) + c)], v[R]);
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
     const bool special = tid == 0;                      // pair slot 0 holds bins 0 and 8192, each its own mirror
     const __amdgpu_buffer_rsrc_t r_cd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(A.cd), 0, P2 * 2 * kXbPairs * 16, 0x00020000);
     auto table = [&](int part, int plane, int p) {
+        if (dskip & 8) return (xb_v4f){0.5f, 0.25f, 0.125f, 0.0625f};
         return __builtin_bit_cast(xb_v4f, __builtin_amdgcn_raw_buffer_load_b128(r_cd, v16, ((part * 2 + plane) * kXbPairs + 1024 * p) * 16, 0));
     };
     auto products = [&](const xb_v4f (&zp)[8], xb_v2f (&acc)[8][2], xb_v2f (&carry)[8][2], bool first, bool last) {
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
 #pragma unroll
         for (int R = 0; R < 16; ++R) v[R] = lds_ld(&X[xb_pair_addr(64 * lane + 16 * (R & 3) + 4096 * (R >> 2) + c)]);
         __syncthreads();                                // every wave has its bins: the slabs are transform scratch again
-        wave_fft_inv(v, slab, tab, lane);               // register a holds y_c[64 a + lane]
+        if (!(dskip & 16)) wave_fft_inv(v, slab, tab, lane);               // register a holds y_c[64 a + lane]
 #pragma unroll
         for (int a = 0; a < 16; ++a) lds_st(&slab[64 * a + lane], v[a]);
         __syncthreads();
@@ -270,11 +273,11 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
         for (int cc = 0; cc < 16; ++cc) y[cc] = lds_ld(&X[kXbSlab * cc + tid]);
 #pragma unroll
         for (int cc = 1; cc < 16; ++cc) y[cc] = cmulc(y[cc], twiddle(cc));
-        dft16<true>(y);
+        if (!(dskip & 64)) dft16<true>(y);
 #pragma unroll
         for (int n2 = 8; n2 < 16; ++n2) {
             const long long f0 = (long long)i * 8192 + 1024 * (n2 - 8);
-            if (f0 + half < A.io_frames) {                      // (uniform over the wave)
+            if (f0 + half < A.io_frames && !(dskip & 32)) {     // (uniform over the wave)
                 const int so = __builtin_amdgcn_readfirstlane((int)(f0 * 4));
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[n2].x * A.gain), r_out_l, v4, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[n2].y * A.gain), r_out_r, v4, so, 0);

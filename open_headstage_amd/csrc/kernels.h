@@ -371,6 +371,7 @@ struct ConvXbArgs {
     float gain;
     int fp_mode;
     int tables_mode;            // 1 = window i is [block i of `in`, 8192 zeros], spectra to `ab`, nothing else
+    int debug_skip;             // timing knock-outs (WRONG results): Tuning::xb_skip
 };
 hipError_t launch_conv_xb(const ConvXbArgs &a, hipStream_t st);
 hipError_t launch_conv_xb_build_cd(const float4 *ab, int P2, float4 *cd, hipStream_t st);
