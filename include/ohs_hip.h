@@ -317,9 +317,10 @@ int  ohs_batch_update_eq_band(ohs_batch *b, size_t band, float fs, int filter_ty
  * (parametric_eq.rs:144-164), band >= num_bands ignored.  The first such call gives every stream a copy of the shared
  * table; from then on ohs_batch_set_eq_band_coeffs / _update_eq_band set the band of EVERY stream, and
  * ohs_batch_share_eq_table goes back to the one shared table (the values the shared calls have set).  All streams run in one
- * launch (each row of the EQ kernel reads its own stream's table when its wave starts; streams may enable different
- * bands and different NUMBERS of bands) as long as no stream enables more than 12 bands and the exact-specials mode is off;
- * otherwise every stream is a launch sequence of its own -- correct for any table, slow for many streams.  The tables are
+ * launch per 12 enabled bands of the busiest stream (each row of the EQ kernel reads its own stream's table when its wave
+ * starts; streams may enable different bands and different NUMBERS of bands; in a later pass the streams with fewer bands
+ * hand their samples on) as long as the exact-specials mode is off; in that mode every stream is a launch sequence of its
+ * own -- correct for any table, slow for many streams.  The tables are
  * uploaded by the first processing call after an edit, which waits for the work queued on its stream (not for the audio
  * thread; bit-exact against one StereoParametricEQ per stream either way). */
 int  ohs_batch_set_stream_eq_band_coeffs(ohs_batch *b, size_t stream, size_t band, const float coeffs[5], int enabled);

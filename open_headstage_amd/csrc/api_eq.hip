@@ -57,7 +57,7 @@ void eq_free(EqState &e)
     if (e.d_state) hipFree(e.d_state);
     if (e.d_stabs) hipFree(e.d_stabs);
     if (e.d_stamps) hipFree(e.d_stamps);
-    e.d_state = nullptr; e.d_stabs = nullptr; e.d_stamps = nullptr;
+    e.d_state = nullptr; e.d_stabs = nullptr; e.stabs_passes = 0; e.d_stamps = nullptr;
 }
 
 bool eq_any_enabled(const EqState &e)
@@ -151,38 +151,49 @@ static int eq_launch_table(EqState &e, const float *coeffs, const unsigned char 
     return OHS_OK;
 }
 
-// per-stream tables: compact every stream's enabled bands into its EqStreamTable and upload them.  Not on the audio path:
-// it waits for what the stream has queued (a launch in flight may still be reading the old tables) and copies synchronously.
+// per-stream tables: compact every stream's enabled bands into EqStreamTables of 12 and upload them: pass k of stream s, at
+// d_stabs[k * S + s], holds that stream's enabled bands 12 k .. 12 k + 11 (none: nb = 0, the pass hands the samples on).  Not on
+// the audio path: it waits for what the stream has queued (a launch in flight may still be reading the old tables) and copies
+// synchronously.
 static int eq_upload_stream_tables(EqState &e, hipStream_t st)
 {
     const size_t S = e.chains / 2;
-    std::vector<EqStreamTable> tabs(S);
     size_t mx = 0;
     for (size_t s = 0; s < S; ++s) {
-        EqStreamTable &t = tabs[s];
-        std::memset(&t, 0, sizeof(t));
-        int k = 0;
-        size_t count = 0, last = 0;
+        size_t count = 0;
+        for (size_t b = 0; b < e.nb; ++b) count += e.s_en[s * e.nb + b] ? 1 : 0;
+        mx = std::max(mx, count);
+    }
+    const size_t passes = std::max<size_t>(1, (mx + 11) / 12);
+    std::vector<EqStreamTable> tabs(passes * S);
+    std::memset(tabs.data(), 0, tabs.size() * sizeof(EqStreamTable));
+    for (size_t s = 0; s < S; ++s) {
+        size_t count = 0;
         for (size_t b = 0; b < e.nb; ++b) {
             if (!e.s_en[s * e.nb + b]) continue;
+            EqStreamTable &t = tabs[(count / 12) * S + s];
+            const int k = (int)(count % 12);
+            const float *c = &e.s_coeffs[(s * e.nb + b) * 5];
+            t.b0[k] = c[0]; t.b1[k] = c[1]; t.b2[k] = c[2]; t.a1[k] = c[3]; t.a2[k] = c[4];
+            t.slot[k] = (int)b;
+            t.nb = k + 1;
             ++count;
-            if (k < 12) {
-                const float *c = &e.s_coeffs[(s * e.nb + b) * 5];
-                t.b0[k] = c[0]; t.b1[k] = c[1]; t.b2[k] = c[2]; t.a1[k] = c[3]; t.a2[k] = c[4];
-                t.slot[k] = (int)b;
-                last = b;
-                ++k;
-            }
         }
-        for (int j = k; j < 12; ++j) t.slot[j] = (int)last;
-        t.nb = k;
-        mx = std::max(mx, count);
+        for (size_t pk = 0; pk < passes; ++pk) {        // unused entries repeat the pass's last band's slot (never stored)
+            EqStreamTable &t = tabs[pk * S + s];
+            for (int j = t.nb; j < 12; ++j) t.slot[j] = t.nb ? t.slot[t.nb - 1] : 0;
+        }
     }
     e.max_enabled = mx;
     DeviceWideSection dws;
     HIP_TRY(hipStreamSynchronize(st));
-    if (!e.d_stabs) HIP_TRY(hipMalloc(&e.d_stabs, S * sizeof(EqStreamTable)));
-    HIP_TRY(hipMemcpy(e.d_stabs, tabs.data(), S * sizeof(EqStreamTable), hipMemcpyHostToDevice));
+    if (!e.d_stabs || e.stabs_passes < passes) {
+        if (e.d_stabs) hipFree(e.d_stabs);
+        e.d_stabs = nullptr; e.stabs_passes = 0;
+        HIP_TRY(hipMalloc(&e.d_stabs, passes * S * sizeof(EqStreamTable)));
+        e.stabs_passes = passes;
+    }
+    HIP_TRY(hipMemcpy(e.d_stabs, tabs.data(), passes * S * sizeof(EqStreamTable), hipMemcpyHostToDevice));
     e.stabs_dirty = false;
     return OHS_OK;
 }
@@ -204,18 +215,23 @@ int eq_launch(EqState &e, const float *in, float *out, long long ss, long long c
         }
         if (e.max_enabled == 0) {
             // no stream has an enabled band: identity
-        } else if (e.max_enabled <= 12 && !e.exact_specials && !tuning().eq_conveyor && eq_ring_addressable(ss, cs, n)) {
-            // one launch for all streams: every row reads its own stream's table when its wave starts
+        } else if (!e.exact_specials && !tuning().eq_conveyor && eq_ring_addressable(ss, cs, n)) {
+            // one launch per 12 bands for all streams: every row reads its own stream's table when its wave starts (a stream with
+            // fewer bands than the pass's first hands its samples on -- exact except for -0.0, as the ring form's spare lanes are)
             int xcd_lo = e.xcd_lo, xcd_n = e.xcd_n;
             if (tuning().eq_xcd_n > 0) { xcd_lo = tuning().eq_xcd_lo; xcd_n = tuning().eq_xcd_n; }
-            hipError_t err = launch_eq_ring_streams(in, out, ss, cs, n, (int)e.chains, e.d_stabs, e.d_state, st, e.fp_mode, xcd_lo,
-                                                    xcd_n, ev_start, ev_stop);
-            if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch (per-stream tables): ") + hipGetErrorString(err));
+            const size_t S = e.chains / 2, passes = (e.max_enabled + 11) / 12;
+            for (size_t pk = 0; pk < passes; ++pk) {
+                hipError_t err = launch_eq_ring_streams(pk ? out : in, out, ss, cs, n, (int)e.chains, e.d_stabs + pk * S, e.d_state, st,
+                                                        e.fp_mode, xcd_lo, xcd_n, pk == 0 ? ev_start : nullptr,
+                                                        pk + 1 == passes ? ev_stop : nullptr);
+                if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("eq launch (per-stream tables): ") + hipGetErrorString(err));
+            }
             did = true;
         } else {
-            // A stream with more than 12 enabled bands, the exact-specials mode, strides beyond the ring form's reach: the
-            // conveyor kernel has its band count in its type, so every stream is a launch sequence of its own (correct for any
-            // table; an offline job that needs this at scale groups its streams by table and uses one batch per group).
+            // The exact-specials mode, strides beyond the ring form's reach: the conveyor kernel takes its table as a kernel
+            // argument, so every stream is a launch sequence of its own (correct for any table; an offline job that needs this at
+            // scale groups its streams by table and uses one batch per group).
             if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));
             const size_t S = e.chains / 2;
             for (size_t s = 0; s < S; ++s) {

@@ -248,7 +248,8 @@ struct EqState {
     bool per_stream = false;
     std::vector<float> s_coeffs;         // streams * nb * 5
     std::vector<unsigned char> s_en;     // streams * nb
-    EqStreamTable *d_stabs = nullptr;    // [streams]
+    EqStreamTable *d_stabs = nullptr;    // [passes][streams]: pass k = every stream's enabled bands 12 k .. 12 k + 11
+    size_t stabs_passes = 0;
     bool stabs_dirty = true;
     size_t max_enabled = 0;              // largest number of enabled bands of any stream (as of the last upload scan)
     unsigned long long *d_stamps = nullptr;     // [4] clock stamps of the last ring launch's wave 0 (ohs_batch_set_profiling)

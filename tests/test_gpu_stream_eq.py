@@ -147,14 +147,15 @@ def test_shared_calls_set_every_stream_and_the_shared_table_comes_back(oracle):
     step(2)
 
 
-@pytest.mark.parametrize("mode", ["exact_specials", "thirteen_bands"])
-def test_tables_the_ring_form_cannot_take_run_stream_by_stream(oracle, mode):
-    """the exact-specials mode (conveyor kernel: -0.0 and non-finite input exact) and a stream with more than 12 enabled
-    bands: every stream is a launch sequence of its own, bit-exact all the same; a stream without bands is still copied"""
+@pytest.mark.parametrize("mode", ["exact_specials", "thirteen_bands", "forty_bands"])
+def test_tables_one_ring_pass_cannot_take(oracle, mode):
+    """the exact-specials mode (conveyor kernel: -0.0 and non-finite input exact; its table is a kernel argument, so every stream
+    is a launch sequence of its own) and a stream with more than 12 enabled bands (a second ring pass for all streams, in which
+    the streams with 12 bands or fewer hand their samples on): bit-exact all the same; a stream without bands is still copied"""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
-    nb = 10 if mode == "exact_specials" else 16
+    nb = {"exact_specials": 10, "thirteen_bands": 16, "forty_bands": 40}[mode]     # (forty: 39 enabled on most streams = four passes)
     S, n = 4, 9 * 512
     irs = synth.hrir_set(512)
     coeffs, en = _tables(ohs, synth, S, nb)
