@@ -483,6 +483,8 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
 static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs, float *out,
                           long long out_ss, long long out_cs, int n_blocks, int P2, float gain, hipStream_t st)
 {
+    const int form = tuning().xb_form;
+    if (c.xb_form != form) { c.xb_cd_gen = 0; c.xb_form = form; }
     if (c.xb_p2 != P2 || !c.d_xb_cd) {
         DeviceWideSection dws;
         HIP_TRY(hipStreamSynchronize(st));
@@ -495,7 +497,7 @@ static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     }
     ConvXbArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.tw = ctx->d_tw; a.tw16384 = ctx->d_tw16384; a.P2 = P2;
+    a.tw = ctx->d_tw; a.tw16384 = ctx->d_tw16384; a.P2 = P2; a.form = form;
     if (c.xb_cd_gen != c.lb_tables_gen) {
         if (c.irl_len < (long long)P2 * kXbBlock) return fail(OHS_ERR_HIP, "block-8192 plan: impulse responses not stored");
         ConvXbArgs t = a;
@@ -503,7 +505,7 @@ static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
         t.n_streams = 2; t.n_blk = P2; t.run = 1; t.ab = c.d_xb_ab; t.tables_mode = 1;
         t.fp_mode = 0;      // (tables are built in IEEE arithmetic, like k_ir_spectrum's)
         hipError_t e = launch_conv_xb(t, st);
-        if (e == hipSuccess) e = launch_conv_xb_build_cd(c.d_xb_ab, P2, c.d_xb_cd, st);
+        if (e == hipSuccess) e = launch_conv_xb_build_cd(c.d_xb_ab, P2, c.d_xb_cd, st, form);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-8192 tables: ") + hipGetErrorString(e));
         c.xb_cd_gen = c.lb_tables_gen;
     }

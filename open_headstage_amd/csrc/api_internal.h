@@ -183,7 +183,7 @@ struct ConvState {
     // experiments build: block 8192 / FFT 16384 (experiments/conv_xb_kernels.hip): tables of the response's one or two 8192-tap partitions; valid with lb_cd_valid's
     // generation (every place that invalidates the block-2048 tables bumps lb_tables_gen)
     float4 *d_xb_cd = nullptr, *d_xb_ab = nullptr;
-    int xb_p2 = 0;
+    int xb_p2 = 0, xb_form = 0;
     unsigned long long lb_tables_gen = 1, xb_cd_gen = 0;
     // what served the last convolution launch (ohs_batch_last_conv_plan): OHS_CONV_KERNEL_*, and its ranges per stream
     int last_kernel = 0, last_ranges = 0;

@@ -1,8 +1,9 @@
 // conv_xb_kernels.hip -- long impulse responses in batch mode, long calls: block 8192 / FFT 16384, overlap-save, ONE kernel.
 //
 // EXPERIMENTS BUILD ONLY (libohs_hip_exp.so; off unless ohs_debug_set_tuning("xb_min_p", ..) turns it on): parity-green
-// (tests/test_gpu_conv_xb.py), 356 MB of measured traffic per step against the block-2048 plan's 445, but SLOWER than the block-2048 plan on BASELINE config 4 --
-// 0.152-0.165 ms against 0.133-0.145 -- for the reason at the end of this comment.  Kept as the measured "no" it is (LABNOTES.md).
+// (tests/test_gpu_conv_xb.py), 356 MB of measured traffic per step against the block-2048 plan's 445, but no faster than it on BASELINE
+// config 4: the sixteen-wave form below 0.152-0.165 ms against 0.133-0.145, the eight-wave form at the end of this file 0.130 (0.104
+// against 0.120 at 8192 taps) -- for the reasons at the end of this comment.  Kept as the measured "no" it is (LABNOTES.md).
 //
 // What it replaces: the reference's uniform blocking (src/dsp/convolution.rs:22-23: block 512 / FFT 1024; :120-132: one
 // spectrum per 512 taps; :261-273: P x 1024 complex products per block).  The block-2048 plan (conv_lb_kernels.hip) halved
@@ -47,6 +48,7 @@ namespace ohs {
 
 typedef float xb_v2f __attribute__((ext_vector_type(2)));
 typedef float xb_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned xb_v2u __attribute__((vector_size(8)));
 
 constexpr int kXbFft = 16384;
 constexpr int kXbPairs = 8192;
@@ -287,6 +289,257 @@ __global__ __launch_bounds__(1024) void k_conv_xb(const ConvXbArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Second form (ConvXbArgs::form == 2): 8 waves, wave w transforms the classes c = w AND 16 - w (wave 0: 0 and 8)
+// ---------------------------------------------------------------------------------
+// Bin k = 16 k1 + c has its mirror N - k = 16 (1023 - k1) + (16 - c) in the OTHER class of the same wave, at lane 63 - L and
+// register 15 - R of the 1024-point transform's bin layout (class 0 mirrors into itself by (1024 - k1) & 1023: wave_mirror;
+// class 8 into itself by the reversal): the packed two-channel product W[k] = Z[k] C[k] + conj(Z[N - k]) D[k] finds its second
+// input by a lane reversal (ds_bpermute) inside the wave -- no pair image, no workgroup barrier between the forward transform
+// and the inverse one, and the tables are stored per bin in the transforms' own layout ([partition][wave][class][register][lane]).
+// 512 threads (the samples n1 = 2 tid, 2 tid + 1 per thread in the radix-16 steps: 8-byte global and 16-byte LDS accesses).
+__device__ __forceinline__ float2 xc_rev(float2 v, int src)
+{
+    float2 o;
+    o.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x)));
+    o.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)));
+    return o;
+}
+
+template <int P2>
+__global__ __launch_bounds__(512) void k_conv_xc(const ConvXbArgs A)
+{
+    ohs_set_fp_mode(A.fp_mode);
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *tab = smem;
+    float2 *X = smem + kTabComplex;
+    const int tid = threadIdx.x;
+    fill_twiddle_tables(tab, A.tw, tid, 512);
+    const int runs = (A.n_blk + A.run - 1) / A.run;
+    size_t s;
+    int chunk;
+    if (!xb_job(runs, A.n_streams, s, chunk)) return;
+    const int i0 = chunk * A.run, i1 = i0 + A.run < A.n_blk ? i0 + A.run : A.n_blk;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int cA = w, cB = w == 0 ? 8 : 16 - w;
+    float2 *slabA = X + kXbSlab * cA, *slabB = X + kXbSlab * cB;
+    const int rev = (63 - lane) << 2;
+
+    const long long L2 = 2 * A.xh_len;
+    const int io_bytes = (int)(A.io_frames * 4);
+    const __amdgpu_buffer_rsrc_t r_in_l = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(A.in) + s * A.in_stream_stride, 0, io_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_in_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(A.in) + s * A.in_stream_stride + A.in_ch_stride, 0, io_bytes, 0x00020000);
+    const float *xh_base = A.xhist ? A.xhist + s * 2 * L2 : A.in;
+    const __amdgpu_buffer_rsrc_t r_xh_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xh_base), 0, (int)(L2 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_xh_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xh_base) + (A.xhist ? L2 : 0), 0,
+                                                                            (int)(L2 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_tw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(A.tw16384), 0, 15 * 1024 * 8, 0x00020000);
+    // The radix-16 steps: thread = the samples n1 = 2 tid and 2 tid + 1 of every sixteenth -- 8-byte global accesses, 16-byte
+    // twiddle loads and 16-byte X1 accesses serve both.
+    const int v8 = tid * 8, v16 = tid * 16, l16 = lane * 16, v8h = (tid & 255) * 8;
+    const int half = 512 * (w >> 2);                    // the wave's 128 frames sit in this half of a 1024-frame sixteenth
+    const int dskip = A.debug_skip;
+    auto twiddle2 = [&](int cc, float2 &t0, float2 &t1) {      // w16384^((2 tid + e) cc), cc = 1 .. 15
+        if (dskip & 2) { t0 = make_float2(1.0f, 0.001f * cc); t1 = t0; return; }
+        const xb_v4f t = __builtin_bit_cast(xb_v4f, __builtin_amdgcn_raw_buffer_load_b128(r_tw, v16, (cc - 1) * 8192, 0));
+        t0 = make_float2(t.x, t.y); t1 = make_float2(t.z, t.w);
+    };
+    // one sixteenth (1024 frames from frame f0 of the call's axis) of a window: the thread's frames f0 + 2 tid, + 1
+    auto load16th = [&](long long f0, xb_v2f &l, xb_v2f &r) {
+        l = (xb_v2f){0.f, 0.f}; r = (xb_v2f){0.f, 0.f};
+        if (dskip & 1) return;
+        if (f0 >= 0) {
+            if (f0 + half < A.io_frames) {              // (uniform over the wave: everything is a multiple of 512)
+                const int so = __builtin_amdgcn_readfirstlane((int)(f0 * 4));
+                l = __builtin_bit_cast(xb_v2f, __builtin_amdgcn_raw_buffer_load_b64(r_in_l, v8, so, 0));
+                r = __builtin_bit_cast(xb_v2f, __builtin_amdgcn_raw_buffer_load_b64(r_in_r, v8, so, 0));
+            }
+        } else if (A.xhist && A.xh_len + f0 >= 0) {
+            long long idx = A.xh_head + f0 + half;      // (the head is a multiple of 512: a half sixteenth does not straddle the wrap)
+            idx = idx < 0 ? idx + L2 : (idx >= L2 ? idx - L2 : idx);
+            const int so = __builtin_amdgcn_readfirstlane((int)(idx * 4));
+            l = __builtin_bit_cast(xb_v2f, __builtin_amdgcn_raw_buffer_load_b64(r_xh_l, v8h, so, 0));
+            r = __builtin_bit_cast(xb_v2f, __builtin_amdgcn_raw_buffer_load_b64(r_xh_r, v8h, so, 0));
+        }
+    };
+    // window i -> the spectra of the wave's two classes in the 1024-point transform's bin layout
+    auto forward = [&](int i, float2 (&ZA)[16], float2 (&ZB)[16]) {
+        const long long w0 = A.tables_mode ? (long long)i * 8192 : ((long long)i - 1) * 8192;
+        float2 z0[16], z1[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            xb_v2f l = {0.f, 0.f}, r = {0.f, 0.f};
+            if (!A.tables_mode || n2 < 8) load16th(w0 + 1024 * n2, l, r);
+            z0[n2] = make_float2(l.x, r.x); z1[n2] = make_float2(l.y, r.y);
+        }
+        float2 t0[16], t1[16];
+#pragma unroll
+        for (int cc = 1; cc < 16; ++cc) twiddle2(cc, t0[cc], t1[cc]);       // (requested with the frames: one wait for both)
+        dft16<false>(z0);
+#pragma unroll
+        for (int cc = 1; cc < 16; ++cc) z0[cc] = cmul(z0[cc], t0[cc]);
+        dft16<false>(z1);
+#pragma unroll
+        for (int cc = 1; cc < 16; ++cc) z1[cc] = cmul(z1[cc], t1[cc]);
+        __syncthreads();                                // whoever still reads X1 is done
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc)
+            *(volatile __attribute__((address_space(3))) lds_u32x4 *)&X[kXbSlab * cc + 2 * tid] =
+                (lds_u32x4){__float_as_uint(z0[cc].x), __float_as_uint(z0[cc].y), __float_as_uint(z1[cc].x), __float_as_uint(z1[cc].y)};
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 16; ++a) { ZA[a] = lds_ld(&slabA[64 * a + lane]); ZB[a] = lds_ld(&slabB[64 * a + lane]); }
+        wave_lds_sync();
+        if (!(dskip & 4)) {
+            wave_fft_fwd(ZA, slabA, tab, lane);         // register 4 r + j holds k1 = 4 lane + j + 256 r, i.e. bin 16 k1 + cA
+            wave_fft_fwd(ZB, slabB, tab, lane);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t r_cd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(A.cd), 0, P2 * 2 * kXbPairs * 16, 0x00020000);
+    auto table = [&](int part, int h, int R) {      // (C[k], D[k]) of the bin in register R of class h (0: cA, 1: cB)
+        if (dskip & 8) return (xb_v4f){0.5f, 0.25f, 0.125f, 0.0625f};
+        return __builtin_bit_cast(xb_v4f, __builtin_amdgcn_raw_buffer_load_b128(r_cd, l16, ((((part * 8 + w) * 2 + h) * 16 + R) * 64) * 16, 0));
+    };
+    auto v2 = [](float2 a) { return (xb_v2f){a.x, a.y}; };
+    // acc = carry + Z CD_0 ; carry = Z CD_1, register pairs (R, 15 - R) of both classes together: their mirrors are each other's
+    // reversals.  WA / WB receive acc; ZA / ZB are consumed, CA / CB are read (old carry) and rewritten (new carry).
+    auto products = [&](float2 (&ZA)[16], float2 (&ZB)[16], xb_v2f (&WA)[16], xb_v2f (&WB)[16], xb_v2f (&CA)[16], xb_v2f (&CB)[16],
+                        bool first, bool last) {
+        if (w == 0) {       // class 0 mirrors into itself by k1 <-> (1024 - k1) & 1023: fetched once, parked in the wave's own slab
+            float2 zmA[16];
+            wave_mirror(ZA, zmA, lane);
+#pragma unroll
+            for (int R = 0; R < 16; ++R) lds_st(&slabA[64 * R + lane], zmA[R]);
+        }
+        xb_v4f tn[2][2][P2];                            // [R or Q][class][partition]: the NEXT register pair's rows
+        auto request = [&](int R, xb_v4f (&t)[2][2][P2]) {
+#pragma unroll
+            for (int part = 0; part < P2; ++part) {
+                t[0][0][part] = table(part, 0, R); t[1][0][part] = table(part, 0, 15 - R);
+                t[0][1][part] = table(part, 1, R); t[1][1][part] = table(part, 1, 15 - R);
+            }
+        };
+        request(0, tn);
+#pragma unroll
+        for (int R = 0; R < 8; ++R) {
+            const int Q = 15 - R;
+            xb_v4f t[2][2][P2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int part = 0; part < P2; ++part) t[x][h][part] = tn[x][h][part];
+            __builtin_amdgcn_sched_barrier(0);
+            if (R + 1 < 8) request(R + 1, tn);
+            const float2 a0 = ZA[R], a1 = ZA[Q], b0 = ZB[R], b1 = ZB[Q];
+            float2 mA0, mA1, mB0, mB1;
+            if (w == 0) {
+                mA0 = lds_ld(&slabA[64 * R + lane]); mA1 = lds_ld(&slabA[64 * Q + lane]);
+                mB0 = xc_rev(b1, rev); mB1 = xc_rev(b0, rev);      // class 8 mirrors into itself by the reversal
+            } else {
+                mA0 = xc_rev(b1, rev); mA1 = xc_rev(b0, rev);
+                mB0 = xc_rev(a1, rev); mB1 = xc_rev(a0, rev);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!first) {
+                WA[R] = CA[R]; WA[Q] = CA[Q]; WB[R] = CB[R]; WB[Q] = CB[Q];
+                xb_cmac(WA[R], v2(a0), t[0][0][0].lo, v2(mA0), t[0][0][0].hi);
+                xb_cmac(WA[Q], v2(a1), t[1][0][0].lo, v2(mA1), t[1][0][0].hi);
+                xb_cmac(WB[R], v2(b0), t[0][1][0].lo, v2(mB0), t[0][1][0].hi);
+                xb_cmac(WB[Q], v2(b1), t[1][1][0].lo, v2(mB1), t[1][1][0].hi);
+            }
+            if constexpr (P2 == 2) {
+                CA[R] = (xb_v2f){0.f, 0.f}; CA[Q] = (xb_v2f){0.f, 0.f}; CB[R] = (xb_v2f){0.f, 0.f}; CB[Q] = (xb_v2f){0.f, 0.f};
+                if (!last) {
+                    xb_cmac(CA[R], v2(a0), t[0][0][1].lo, v2(mA0), t[0][0][1].hi);
+                    xb_cmac(CA[Q], v2(a1), t[1][0][1].lo, v2(mA1), t[1][0][1].hi);
+                    xb_cmac(CB[R], v2(b0), t[0][1][1].lo, v2(mB0), t[0][1][1].hi);
+                    xb_cmac(CB[Q], v2(b1), t[1][1][1].lo, v2(mB1), t[1][1][1].hi);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (A.tables_mode) {
+        for (int i = i0; i < i1; ++i) {
+            float2 ZA[16], ZB[16];
+            forward(i, ZA, ZB);
+            float2 *dst = reinterpret_cast<float2 *>(A.ab) + ((size_t)s * A.n_blk + i) * kXbFft + (size_t)(w * 2) * 16 * 64 + lane;
+#pragma unroll
+            for (int R = 0; R < 16; ++R) { dst[R * 64] = ZA[R]; dst[(16 + R) * 64] = ZB[R]; }
+        }
+        return;
+    }
+
+    xb_v2f CA[16], CB[16], WA[16], WB[16];
+#pragma unroll
+    for (int R = 0; R < 16; ++R) { CA[R] = (xb_v2f){0.f, 0.f}; CB[R] = (xb_v2f){0.f, 0.f}; }
+    if constexpr (P2 == 2) {
+        float2 ZA[16], ZB[16];
+        forward(i0 - 1, ZA, ZB);
+        products(ZA, ZB, WA, WB, CA, CB, true, false);
+    }
+    const __amdgpu_buffer_rsrc_t r_out_l = __builtin_amdgcn_make_buffer_rsrc(A.out + s * A.out_stream_stride, 0, io_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out_r = __builtin_amdgcn_make_buffer_rsrc(A.out + s * A.out_stream_stride + A.out_ch_stride, 0,
+                                                                             io_bytes, 0x00020000);
+    for (int i = i0; i < i1; ++i) {
+        {
+            float2 ZA[16], ZB[16];
+            forward(i, ZA, ZB);
+            products(ZA, ZB, WA, WB, CA, CB, false, i + 1 >= i1);
+        }
+        {
+            float2 v[16];
+#pragma unroll
+            for (int R = 0; R < 16; ++R) v[R] = make_float2(WA[R].x, WA[R].y);
+            if (!(dskip & 16)) wave_fft_inv(v, slabA, tab, lane);          // register a holds y_cA[64 a + lane]
+#pragma unroll
+            for (int a = 0; a < 16; ++a) lds_st(&slabA[64 * a + lane], v[a]);
+#pragma unroll
+            for (int R = 0; R < 16; ++R) v[R] = make_float2(WB[R].x, WB[R].y);
+            if (!(dskip & 16)) wave_fft_inv(v, slabB, tab, lane);
+#pragma unroll
+            for (int a = 0; a < 16; ++a) lds_st(&slabB[64 * a + lane], v[a]);
+        }
+        float2 t0[16], t1[16];
+#pragma unroll
+        for (int cc = 1; cc < 16; ++cc) twiddle2(cc, t0[cc], t1[cc]);       // (in flight across the barrier)
+        __syncthreads();
+        float2 y0[16], y1[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) lds_ld2(reinterpret_cast<const float4 *>(&X[kXbSlab * cc + 2 * tid]), y0[cc], y1[cc]);
+#pragma unroll
+        for (int cc = 1; cc < 16; ++cc) { y0[cc] = cmulc(y0[cc], t0[cc]); y1[cc] = cmulc(y1[cc], t1[cc]); }
+        dft16<true>(y0);
+        dft16<true>(y1);
+#pragma unroll
+        for (int n2 = 8; n2 < 16; ++n2) {
+            const long long f0 = (long long)i * 8192 + 1024 * (n2 - 8);
+            if (f0 + half < A.io_frames && !(dskip & 32)) {     // (uniform over the wave)
+                const int so = __builtin_amdgcn_readfirstlane((int)(f0 * 4));
+                const xb_v2f ol = {y0[n2].x * A.gain, y1[n2].x * A.gain}, orr = {y0[n2].y * A.gain, y1[n2].y * A.gain};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xb_v2u, ol), r_out_l, v8, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xb_v2u, orr), r_out_r, v8, so, 0);
+            }
+        }
+        // (the next forward() starts with a barrier: X1 has been read by then)
+    }
+}
+
+// form 2's tables: per bin, in the transforms' own layout; ab holds the spectra of A and B as float2 per bin
+__global__ __launch_bounds__(256) void k_conv_xc_build_cd(const float2 *__restrict__ ab, int P2, float4 *__restrict__ cd)
+{
+    const int i = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;      // q < 16384
+    const float2 a = ab[((size_t)0 * P2 + i) * kXbFft + q];
+    const float2 b = ab[((size_t)1 * P2 + i) * kXbFft + q];
+    const float h = 0.5f / (float)kXbFft;
+    cd[(size_t)i * kXbFft + q] = make_float4(h * (a.x + b.y), h * (a.y - b.x), h * (a.x - b.y), h * (a.y + b.x));
+}
+
 // (C, D) tables from the spectra of A = h_lsl + j h_lsr (ab[0][i]) and B = h_rsl + j h_rsr (ab[1][i]), i < P2
 __global__ __launch_bounds__(256) void k_conv_xb_build_cd(const float4 *__restrict__ ab, int P2, float4 *__restrict__ cd)
 {
@@ -331,10 +584,22 @@ hipError_t launch_conv_xb(const ConvXbArgs &a, hipStream_t st)
     if (a.tables_mode ? !a.ab : (!a.out || !a.cd)) return hipErrorInvalidValue;
     if (a.io_frames < 0 || (a.io_frames & 511) || (a.xhist && (a.xh_len <= 0 || (a.xh_len & 511) || a.xh_head < 0 || a.xh_head >= 2 * a.xh_len)))
         return hipErrorInvalidValue;
-    static std::atomic<unsigned long long> ok1{0}, ok2{0};
+    static std::atomic<unsigned long long> ok1{0}, ok2{0}, ok3{0}, ok4{0};
     const int runs = (a.n_blk + a.run - 1) / a.run;
     const unsigned grid = xb_grid(runs, a.n_streams);
     hipError_t e;
+    if (a.form == 2) {
+        if (a.P2 == 2 && !a.tables_mode) {
+            e = xb_allow_lds(reinterpret_cast<const void *>(&k_conv_xc<2>), ok3);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_conv_xc<2>, dim3(grid), dim3(512), kXbLdsBytes, st, a);
+        } else {
+            e = xb_allow_lds(reinterpret_cast<const void *>(&k_conv_xc<1>), ok4);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_conv_xc<1>, dim3(grid), dim3(512), kXbLdsBytes, st, a);
+        }
+        return hipGetLastError();
+    }
     if (a.P2 == 2 && !a.tables_mode) {
         e = xb_allow_lds(reinterpret_cast<const void *>(&k_conv_xb<2>), ok2);
         if (e != hipSuccess) return e;
@@ -347,10 +612,11 @@ hipError_t launch_conv_xb(const ConvXbArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_conv_xb_build_cd(const float4 *ab, int P2, float4 *cd, hipStream_t st)
+hipError_t launch_conv_xb_build_cd(const float4 *ab, int P2, float4 *cd, hipStream_t st, int form)
 {
     if (!ab || !cd || P2 < 1 || P2 > 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_conv_xb_build_cd, dim3(kXbPairs / 256, P2), dim3(256), 0, st, ab, P2, cd);
+    if (form == 2) hipLaunchKernelGGL(k_conv_xc_build_cd, dim3(kXbFft / 256, P2), dim3(256), 0, st, reinterpret_cast<const float2 *>(ab), P2, cd);
+    else hipLaunchKernelGGL(k_conv_xb_build_cd, dim3(kXbPairs / 256, P2), dim3(256), 0, st, ab, P2, cd);
     return hipGetLastError();
 }
 

@@ -372,9 +372,10 @@ struct ConvXbArgs {
     int fp_mode;
     int tables_mode;            // 1 = window i is [block i of `in`, 8192 zeros], spectra to `ab`, nothing else
     int debug_skip;             // timing knock-outs (WRONG results): Tuning::xb_skip
+    int form;                   // 1: sixteen waves + a pair image; 2: eight waves, mirrors by lane reversal (tables per bin, in the transforms' layout)
 };
 hipError_t launch_conv_xb(const ConvXbArgs &a, hipStream_t st);
-hipError_t launch_conv_xb_build_cd(const float4 *ab, int P2, float4 *cd, hipStream_t st);
+hipError_t launch_conv_xb_build_cd(const float4 *ab, int P2, float4 *cd, hipStream_t st, int form);
 int conv_xb_run_for(int n_streams, int n_blk, int P2, int num_cus);
 void conv_xb_build_twiddles(float2 *out);       // host: [15][1024]
 constexpr int kXbBlock = 8192;                  // frames per block of this plan

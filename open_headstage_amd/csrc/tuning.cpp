@@ -134,6 +134,7 @@ bool tuning_set(const std::string &key, const std::string &value)
     if (key == "xb_min_p") return one(&t.xb_min_p);
     if (key == "xb_min_blocks") return one(&t.xb_min_blocks);
     if (key == "xb_run") return one(&t.xb_run);
+    if (key == "xb_form") { if (!one(&t.xb_form)) return false; t.xb_form = t.xb_form == 2 ? 2 : 1; return true; }
     if (key == "xb_skip") return one(&t.xb_skip);
     if (key == "lb_seg_windows") { if (!one(&t.lb_seg_windows)) return false; if (t.lb_seg_windows < 64) t.lb_seg_windows = 64; return true; }
     if (key == "lb_min_p") { if (!one(&t.lb_min_p)) return false; if (t.lb_min_p < 2) t.lb_min_p = 2; return true; }

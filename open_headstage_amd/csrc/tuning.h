@@ -47,6 +47,7 @@ struct Tuning {
     int xb_min_blocks = 128;                // ... for calls of at least this many 512-frame blocks
     int xb_skip = 0;                        // k_conv_xb timing knock-outs (WRONG results): 1 no input loads, 2 no twiddle loads, 4 no forward
                                             // transforms, 8 no table loads, 16 no inverse transforms, 32 no stores, 64 no radix-16 steps
+    int xb_form = 1;                        // k_conv_xb (1) or k_conv_xc (2)
     int xb_run = 0;                         // > 0: blocks of 8192 per workgroup (else conv_xb_run_for)
     int lb_skip = 0;                        // k_conv_lb_mac_inverse timing knock-outs (WRONG results; experiments build only): 1 = no
                                             // products, 2 = no inverse transforms, 4 = no ring loads, 8 = no table loads

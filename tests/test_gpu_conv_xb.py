@@ -23,9 +23,10 @@ def _oracle_engines(oracle, irs, S):
     return engs
 
 
-@pytest.fixture(autouse=True)
-def _xb_on(exp_tuning):
+@pytest.fixture(autouse=True, params=[1, 2], ids=["sixteen_waves", "eight_waves"])
+def _xb_on(exp_tuning, request):
     exp_tuning("xb_min_p", 13)
+    exp_tuning("xb_form", request.param)
     yield
 
 
