@@ -64,7 +64,7 @@ NOMINAL_CLOCK_GHZ = 2.4        # same guide: max clock; only used to express the
 EQ_ISSUE_FLOOR_CYCLES = 26.7   # 6.5 VALU per sample x 4.1 cycles per instruction of a lone wave
 # ohs_batch_last_conv_plan's kernel family -> the kernel that dominates it (the name rocprofv3 shows)
 KERNEL_OF_FAMILY = {"block512_p1": "k_conv_p1", "hop1536_p1": "k_conv_p1_os", "block512_tp": "k_conv_tp_mac",
-                    "block2048": "k_conv_lb_mac_inverse", "sequential": "k_conv_general", "none": "none"}
+                    "block2048": "k_conv_lb_mac_inverse", "block8192": "k_conv_xb", "sequential": "k_conv_general", "none": "none"}
 
 
 def cpu_info():
@@ -953,8 +953,9 @@ def main() -> int:
             torch.cuda.empty_cache()
         out["saturation"] = sat
         # BASELINE configs[3] ("config 4" of SURVEY 8: 64 streams, 4 x 16 384 taps, no EQ), 256-block calls: the reference's
-        # block-512 partitioning (32 partitions) and the block-2048 plan the library picks for such calls (8 partitions,
-        # product and inverse transform in one kernel); per-step HIP events, median of 20 after 3
+        # block-512 partitioning (32 partitions) and what the library picks for such calls -- out of place the block-8192 kernel (2
+        # partitions, transforms and product in one kernel), in place the block-2048 plan (8 partitions, product and inverse
+        # transform in one kernel); per-step HIP events, median of 20 after 3
         try:
             S4, taps4, nb4 = 64, 16384, 256
             x4 = synth.white_noise_torch(0, S4, nb4 * 512, device)
@@ -962,25 +963,30 @@ def main() -> int:
             irs4 = synth.hrir_set(taps4)
             long_ir = {"workload": f"{S4} streams x {nb4 * 512} frames, 4 x {taps4} taps, EQ off, out of place",
                        "io_floor_bytes": S4 * nb4 * 512 * 16}
-            for plan, key in ((1, "block_512_plan"), (0, "library_choice")):
+            for plan, key in ((1, "block_512_plan"), (0, "library_choice"), (0, "library_choice_in_place")):
                 bp4 = ohs.BatchProcessor(S4, num_bands=nb, device=dev_index)
                 for p in range(4):
                     bp4.set_ir(p, irs4[p])
                 bp4.set_eq_enabled(False)
                 bp4.set_conv_plan(plan)
+                o4 = x4 if key.endswith("in_place") else y4       # (in place the single-kernel plan cannot serve: block 2048)
                 for _ in range(3):
-                    bp4.process(x4, out=y4)
+                    bp4.process(x4, out=o4)
                 torch.cuda.synchronize()
                 evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
                 for i in range(20):
                     evs[i].record()
-                    bp4.process(x4, out=y4)
+                    bp4.process(x4, out=o4)
                 evs[20].record()
                 torch.cuda.synchronize()
                 ts4 = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(20))
                 med = ts4[10] * 1e-3
                 fam4, ranges4 = bp4.last_conv_plan()
                 _, cb4 = bp4.kernel_bytes(nb4)
+                if fam4 == "block2048" and key.endswith("in_place"):
+                    # (ohs_batch_kernel_bytes has no in-place argument and takes an EQ-less call to be out of place; the block-2048
+                    # plan's design bytes, as api_batch.hip states them: audio in, ring written, ring read once, audio out, history)
+                    cb4 = S4 * nb4 * (4096 + 8192 + 8192 + 4096) + 2 * S4 * 2 * 16384 * 4
                 long_ir[key] = {"kernel": KERNEL_OF_FAMILY.get(fam4, fam4), "family": fam4, "ranges_per_stream": ranges4,
                                 "ms_per_step": round(med * 1e3, 4), "ms_min": round(ts4[0], 4), "ms_max": round(ts4[-1], 4),
                                 "Msamples_s": round(S4 * nb4 * 512 / med / 1e6, 1),

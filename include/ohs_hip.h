@@ -344,19 +344,24 @@ int  ohs_batch_set_gain(ohs_batch *b, float gain);
  *        longer responses (taps > 512; BASELINE configs[3]): block 2048 / FFT 4096, overlap-save -- a quarter of the
  *          reference blocking's products and history reads per frame (16 384 taps: 8 partitions instead of the 32 of
  *          convolution.rs:120-132), product and inverse transform in one kernel.  Needs strides that are multiples of 4
- *          floats and 16-byte aligned buffers.
+ *          floats and 16-byte aligned buffers.  Out-of-place calls of 128 blocks or more on responses of at most 16 384 taps
+ *          (with more than 8 192 taps: on 32 streams or more): block 8192 / FFT 16384 with both transforms and the product
+ *          in ONE kernel -- two partitions at most, the second one's product carried in registers to the next block, no
+ *          spectrum ever written to memory (BASELINE configs[3]: 0.116 ms per step against 0.135 for block 2048 and 0.27 for
+ *          the reference blocking).
  *      Equal to plan 1 up to f32 rounding (2-4e-7 relative RMS against the oracle, like every FFT path), not bit for bit,
  *      and the rounding depends on where the calls cut the signal.  The plans hand the per-stream state over to each other:
  *      any sequence of calls under any sequence of plans is one continuous signal.
  *   0  the library's choice (default).  One partition: plan 2 for calls of 48 blocks or more on 512 streams or more -- on
  *      256 or more when the call is out of place and the EQ is off --, plan 1 otherwise (at BASELINE configs[2] the
  *      convolution hides under the EQ either way, and the block-512 bits stay as recorded).  Longer responses: plan 2 for every
- *      call -- its 2048-frame blocks sit on the stream's absolute grid, so calls of any length continue one another.
+ *      call -- block 2048's blocks sit on the stream's absolute grid, so calls of any length continue one another, and the
+ *      block-8192 kernel starts from the same state at rest (the streams' last input frames).
  * The single-stream engine is always served by the reference blocking. */
 int  ohs_batch_set_conv_plan(ohs_batch *b, int plan);
 /* What served the handle's most recent convolution launch (of the last time chunk, when a call is cut into several): the
  * kernel family and the number of independent ranges a stream's frames were cut into for it (one-partition plans: time
- * chunks per stream; block 2048: output tiles per stream of the last segment; time-parallel block 512: blocks of the
+ * chunks per stream; block 2048: output tiles per stream of the last segment; block 8192: runs of blocks per stream; time-parallel block 512: blocks of the
  * last segment; sequential kernel: 1).  A benchmark or a test asks instead of restating the library's rule. */
 enum ohs_conv_kernel {
     OHS_CONV_KERNEL_NONE = 0,           /* no convolution launch yet */
@@ -365,8 +370,8 @@ enum ohs_conv_kernel {
     OHS_CONV_KERNEL_BLOCK512_TP = 3,    /* k_conv_tp_*: several partitions, block 512, time-parallel */
     OHS_CONV_KERNEL_BLOCK2048 = 4,      /* k_conv_lb_*: several partitions, block 2048 / FFT 4096 */
     OHS_CONV_KERNEL_SEQUENTIAL = 5,     /* k_conv_general: one wave per stream, blocks in sequence */
-    /* 6: never reported by this library (the experiments build's block 8192 / FFT 16384 kernel: slower, not shipped) */
-    OHS_CONV_KERNEL_COUNT = 8           /* length of ohs_batch_conv_plan_counts' array (6 and 7 are not reported by this library) */
+    OHS_CONV_KERNEL_BLOCK8192 = 6,      /* k_conv_xb: at most two partitions of 8192 taps, block 8192 / FFT 16384, one kernel */
+    OHS_CONV_KERNEL_COUNT = 8           /* length of ohs_batch_conv_plan_counts' array (7 is not reported by this library) */
 };
 int  ohs_batch_last_conv_plan(const ohs_batch *b, int *kernel, int *ranges_per_stream);
 /* convolution launch sequences served per kernel family (counts[OHS_CONV_KERNEL_*]) since the handle was created or since

@@ -92,7 +92,8 @@ class BatchProcessor:
 
     def set_conv_plan(self, plan: int) -> None:
         """1 = block 512 / FFT 1024 (the reference's blocking; bit-stable for taps <= 512), 2 = the large-transform plans
-        (taps <= 512: hop 1536 / FFT 2048; taps > 512: block 2048 / FFT 4096), 0 = the library's choice
+        (taps <= 512: hop 1536 / FFT 2048; taps > 512: block 2048 / FFT 4096, or block 8192 / FFT 16384 for long out-of-place
+        calls on taps <= 16384), 0 = the library's choice
         (ohs_batch_set_conv_plan)"""
         self._check(self._lib.ohs_batch_set_conv_plan(self._h, int(plan)))
 

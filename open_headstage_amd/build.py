@@ -55,6 +55,7 @@ def _units():
         ("conv_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
         ("conv_os_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),   # the overlap-save plan of the P = 1 path
         ("conv_lb_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),   # block 2048 / FFT 4096 for long impulse responses
+        ("conv_xb_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),   # block 8192 / FFT 16384 in one kernel: their long out-of-place calls
         # (experiments builds only: OHS_MAC_TB / OHS_MAC_PI fix the MAC's register tile)
         ("conv_mac_kernels.hip", [f"-D{k}={os.environ[k]}" for k in ("OHS_MAC_TB", "OHS_MAC_PI")
                                   if EXPERIMENTS and k in os.environ]),
@@ -70,8 +71,8 @@ def _units():
         # by itself)
         ("biquad_coeffs.cpp", ["-x", "hip", "-ffp-contract=off"]),
     ] + ([
-        # experiments builds only: block 8192 / FFT 16384 in one kernel -- parity-green, slower than the block-2048 plan (LABNOTES.md)
-        ("experiments/conv_xb_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
+        # experiments builds only: the block-8192 plan's first form (sixteen waves, pair image) -- parity-green, slower (LABNOTES.md)
+        ("experiments/conv_xb16_kernels.hip", ["-fno-slp-vectorize", "-ffp-contract=off"]),
     ] if EXPERIMENTS else [])
 
 

@@ -769,6 +769,15 @@ int ohs_batch_kernel_bytes(const ohs_batch *b, size_t n_blocks, uint64_t *eq_byt
         *conv_bytes = nbk * S * 8192u + S * ((K - 1) * (own_tails ? 1u : 3u) * 4096u + state);
     } else if (b->conv.d_xhist && P >= lb_min_p() &&
                (b->conv.conv_plan == 2 || (b->conv.conv_plan == 0 && conv_plan_auto_is_lb((size_t)S, (long long)nbk, P)))) {
+        if (!b->eq_enable && conv_plan_auto_is_xb((size_t)S, (long long)nbk, P)) {
+            // block-8192 kernel (EQ off: taken to be out of place, as the hop-1536 rule above does): audio in + out; per run of
+            // blocks the window's first half once more (64 KiB), with two partitions the carry's window as well; the history append
+            const int P2x = (P + 15) / 16;
+            const uint64_t n_blk = (nbk * 512u + 8191u) / 8192u;
+            const uint64_t run = (uint64_t)conv_xb_run_for((int)S, (int)n_blk, P2x, b->ctx->num_cus);
+            *conv_bytes = nbk * S * 8192u + S * ((n_blk + run - 1) / run) * (uint64_t)P2x * 65536u + 2u * S * 2u * (uint64_t)b->conv.xh_len * 4u;
+            return OHS_OK;
+        }
         // block-2048 plan: audio in, ring write (16 B per frame), ring read once, audio out -- the product never leaves the
         // chip; plus the input history copied once per segment (read + write)
         *conv_bytes = nbk * S * (4096u + 8192u + 8192u + 4096u) + 2u * S * 2u * (uint64_t)b->conv.xh_len * 4u;

@@ -476,14 +476,25 @@ static int conv_lb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     return OHS_OK;
 }
 
-#ifdef OHS_EXPERIMENTS
-// Block 8192 / FFT 16384, one kernel (experiments/conv_xb_kernels.hip; experiments build only, off by default: slower than block 2048): long out-of-place calls on responses of at most two 8192-tap
+// Block 8192 / FFT 16384, one kernel (conv_xb_kernels.hip): long out-of-place calls on responses of at most two 8192-tap
 // partitions.  It starts from the input history like the block-2048 plan and leaves the same state behind (the history
 // advanced; the block-2048 window ring does not see the call's blocks).
+// where the block-8192 kernel pays among the calls the large-block plans serve (out of place only: the caller checks)
+bool conv_plan_auto_is_xb(size_t S, long long n_blocks, int Pmax)
+{
+    const Tuning &tn = tuning();
+    const int P2x = (Pmax + 15) / 16;
+    return P2x <= 2 && Pmax >= tn.xb_min_p && n_blocks >= tn.xb_min_blocks && (P2x == 1 || (long long)S >= tn.xb_min_streams_p2);
+}
+
 static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long long in_ss, long long in_cs, float *out,
                           long long out_ss, long long out_cs, int n_blocks, int P2, float gain, hipStream_t st)
 {
-    const int form = tuning().xb_form;
+#ifdef OHS_EXPERIMENTS
+    const int form = tuning().xb_form == 1 ? 1 : 2;     // (1: the sixteen-wave first form, experiments/conv_xb16_kernels.hip)
+#else
+    constexpr int form = 2;
+#endif
     if (c.xb_form != form) { c.xb_cd_gen = 0; c.xb_form = form; }
     if (c.xb_p2 != P2 || !c.d_xb_cd) {
         DeviceWideSection dws;
@@ -495,17 +506,27 @@ static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
         HIP_TRY(hipMalloc(&c.d_xb_ab, (size_t)2 * P2 * kXbBlock * sizeof(float4)));
         c.xb_p2 = P2;
     }
+    auto launch = [&](const ConvXbArgs &x) -> hipError_t {
+#ifdef OHS_EXPERIMENTS
+        if (form == 1) return launch_conv_xb16(x, st);
+#endif
+        return launch_conv_xb(x, st);
+    };
     ConvXbArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.tw = ctx->d_tw; a.tw16384 = ctx->d_tw16384; a.P2 = P2; a.form = form;
+    a.tw = ctx->d_tw; a.tw16384 = ctx->d_tw16384; a.P2 = P2;
     if (c.xb_cd_gen != c.lb_tables_gen) {
         if (c.irl_len < (long long)P2 * kXbBlock) return fail(OHS_ERR_HIP, "block-8192 plan: impulse responses not stored");
         ConvXbArgs t = a;
         t.in = c.d_irl; t.in_stream_stride = 2 * c.irl_len; t.in_ch_stride = c.irl_len; t.io_frames = c.irl_len;
         t.n_streams = 2; t.n_blk = P2; t.run = 1; t.ab = c.d_xb_ab; t.tables_mode = 1;
         t.fp_mode = 0;      // (tables are built in IEEE arithmetic, like k_ir_spectrum's)
-        hipError_t e = launch_conv_xb(t, st);
-        if (e == hipSuccess) e = launch_conv_xb_build_cd(c.d_xb_ab, P2, c.d_xb_cd, st, form);
+        hipError_t e = launch(t);
+#ifdef OHS_EXPERIMENTS
+        if (e == hipSuccess && form == 1) e = launch_conv_xb16_build_cd(c.d_xb_ab, P2, c.d_xb_cd, st);
+        else
+#endif
+        if (e == hipSuccess) e = launch_conv_xb_build_cd(reinterpret_cast<const float2 *>(c.d_xb_ab), P2, c.d_xb_cd, st);
         if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-8192 tables: ") + hipGetErrorString(e));
         c.xb_cd_gen = c.lb_tables_gen;
     }
@@ -514,9 +535,13 @@ static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     a.in_stream_stride = in_ss; a.in_ch_stride = in_cs; a.out_stream_stride = out_ss; a.out_ch_stride = out_cs;
     a.xhist = c.d_xhist; a.xh_len = c.xh_len; a.xh_head = c.xh_head;
     a.io_frames = frames; a.n_streams = (int)c.S; a.n_blk = (int)((frames + kXbBlock - 1) / kXbBlock);
-    a.run = tuning().xb_run > 0 ? std::min(tuning().xb_run, a.n_blk) : conv_xb_run_for(a.n_streams, a.n_blk, P2, ctx->num_cus);
-    a.cd = c.d_xb_cd; a.gain = gain; a.fp_mode = c.fp_mode; a.debug_skip = tuning().xb_skip;
-    hipError_t e = launch_conv_xb(a, st);
+    a.run = conv_xb_run_for(a.n_streams, a.n_blk, P2, ctx->num_cus);
+    a.cd = c.d_xb_cd; a.gain = gain; a.fp_mode = c.fp_mode; a.stagger = tuning().xb_stagger;
+#ifdef OHS_EXPERIMENTS
+    if (tuning().xb_run > 0) a.run = std::min(tuning().xb_run, a.n_blk);
+    a.debug_skip = tuning().xb_skip;
+#endif
+    hipError_t e = launch(a);
     // the call's last frames join the input history (behind the kernel: it reads the history's present state)
     const long long xcnt = std::min(frames, c.xh_len);
     if (e == hipSuccess) e = launch_conv_lb_xhist_append(in, in_ss, in_cs, c.d_xhist, c.xh_len, c.xh_head, frames, (int)c.S, st);
@@ -525,10 +550,9 @@ static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     c.xh_valid = std::min(c.xh_len, c.xh_valid + frames);
     c.lb_valid = 0;             // (the block-2048 window ring has not seen these blocks)
     c.lb_lazy = true;
-    c.last_kernel = 6; c.last_ranges = (a.n_blk + a.run - 1) / a.run;
+    c.last_kernel = OHS_CONV_KERNEL_BLOCK8192; c.last_ranges = (a.n_blk + a.run - 1) / a.run;
     return OHS_OK;
 }
-#endif
 
 // set_ir (convolution.rs:111-139) for one path; `ir` is a host pointer, or a device pointer on the state's
 // device when ir_on_device (the node-level batch hands over what RCCL has just broadcast)
@@ -869,22 +893,18 @@ static int conv_launch_impl(ConvState &c, DeviceCtx *ctx, const float *in, long 
             const bool lb_ok = (deep || together) && ((in_ss | in_cs | out_ss | out_cs) & 3) == 0 &&
                                ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
             if (lb_ok && (c.conv_plan == 2 || (c.conv_plan == 0 && conv_plan_auto_is_lb(c.S, n_blocks, Pmax)))) {
-#ifdef OHS_EXPERIMENTS
-                // long calls on responses of at most two 8192-tap partitions, out of place (the buffers must not overlap at
-                // all: a run's first windows read frames in front of its own blocks): block 8192, one kernel -- when a test or a
-                // sweep turns it on (Tuning::xb_min_p)
+                // Long out-of-place calls on responses of at most two 8192-tap partitions: block 8192 / FFT 16384, one kernel (the
+                // buffers must not overlap at all: a run's first windows read frames in front of its own blocks).  Where it pays
+                // (profiles/r05_xb_vs_lb_shapes.txt): calls of 128 blocks or more; with two partitions, on 32 streams or more.
                 const int P2x = (Pmax + 15) / 16;
                 const long long call_frames = (long long)n_blocks * BS;
                 const float *in_end = in + (c.S - 1) * in_ss + in_cs + call_frames;
                 const float *out_end = out + (c.S - 1) * out_ss + out_cs + call_frames;
                 const bool apart = in_end <= out || out_end <= in;
-                const bool xb = P2x <= 2 && apart && Pmax >= tuning().xb_min_p && n_blocks >= tuning().xb_min_blocks &&
+                const bool xb = apart && conv_plan_auto_is_xb(c.S, n_blocks, Pmax) &&
                                 c.xh_len >= (long long)P2x * kXbBlock && call_frames < (1ll << 29);
                 const int rcl = xb ? conv_xb_launch(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, P2x, gain, st)
                                    : conv_lb_launch(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st);
-#else
-                const int rcl = conv_lb_launch(c, ctx, in, in_ss, in_cs, out, out_ss, out_cs, n_blocks, gain, st);
-#endif
                 if (rcl) return rcl;
                 c.cnt += (unsigned long long)n_blocks;
                 for (int p = 0; p < 4; ++p) c.since[p] += n_blocks;

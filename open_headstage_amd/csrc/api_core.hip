@@ -97,7 +97,6 @@ int get_ctx(int device, DeviceCtx **out)
             return fail(OHS_ERR_HIP, "w4096 table upload failed");
         }
     }
-#ifdef OHS_EXPERIMENTS
     {
         std::vector<float2> t16(15 * 1024);
         conv_xb_build_twiddles(t16.data());
@@ -108,7 +107,6 @@ int get_ctx(int device, DeviceCtx **out)
             return fail(OHS_ERR_HIP, "w16384 table upload failed");
         }
     }
-#endif
     g_ctx.push_back(c);
     *out = c;
     return OHS_OK;

@@ -56,7 +56,7 @@ struct DeviceCtx {
     float2 *d_tw = nullptr;
     float2 *d_tw2048 = nullptr; // k_conv_p1_os: w2048^bin in the paired layout
     float2 *d_tw4096 = nullptr; // k_conv_lb_*: w4096^(n1 c), [3][1024]
-    float2 *d_tw16384 = nullptr;// experiments build: k_conv_xb's w16384^(n1 c), [15][1024]
+    float2 *d_tw16384 = nullptr;// k_conv_xb: w16384^(n1 c), [15][1024]
     int *d_pairs = nullptr;     // k_conv_tp_mac: leaders of the spectrum position pairs {b, mirror(b)}
     int n_pairs = 0;
     int num_cus = 256;
@@ -180,7 +180,7 @@ struct ConvState {
     bool pt_active = false;
     float4 *d_lb_cd_alt = nullptr;  // tables of one speaker pair alone (the tails' two runs)
     int lb_cd_alt_p2pad = 0;
-    // experiments build: block 8192 / FFT 16384 (experiments/conv_xb_kernels.hip): tables of the response's one or two 8192-tap partitions; valid with lb_cd_valid's
+    // block 8192 / FFT 16384 (conv_xb_kernels.hip): tables of the response's one or two 8192-tap partitions; valid with lb_cd_valid's
     // generation (every place that invalidates the block-2048 tables bumps lb_tables_gen)
     float4 *d_xb_cd = nullptr, *d_xb_ab = nullptr;
     int xb_p2 = 0, xb_form = 0;
@@ -204,6 +204,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
 bool conv_plan_auto_is_os(size_t S, long long n_blocks, bool in_place);
 inline int lb_min_p() { return tuning().lb_min_p; }     // 512-tap partitions from which the block-2048 plan is considered (2: taps > 512)
 bool conv_plan_auto_is_lb(size_t S, long long n_blocks, int Pmax);
+bool conv_plan_auto_is_xb(size_t S, long long n_blocks, int Pmax);      // ... and among those, the block-8192 kernel (out-of-place calls)
 int conv_os_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, bool in_place);
 // time chunks per stream of the one-partition kernel's launch plan (also what ohs_batch_kernel_bytes prices)
 long long conv_p1_chunks(const DeviceCtx *ctx, size_t S, long long n_blocks, long long target_override, int xcd_n = 8);

@@ -345,18 +345,16 @@ void conv_lb_build_twiddles(float2 *out);       // host: [3][1024]
 constexpr int kLbBlock = 2048;                  // frames per block of this plan
 constexpr int kLbTile = 4;                      // output blocks per MI workgroup (calls of 1 or 2 blocks: that many)
 
-#ifdef OHS_EXPERIMENTS
-// ---- long impulse responses, batch objects, long calls: block 8192 / FFT 16384, one kernel (experiments/conv_xb_kernels.hip;
-// experiments build only -- a measured "no", LABNOTES.md) ------
+// ---- long impulse responses, batch objects, long out-of-place calls: block 8192 / FFT 16384, one kernel (conv_xb_kernels.hip) ------
 // Responses of at most two 8192-tap partitions: W_i = Z_i CD_0 + carry, carry' = Z_i CD_1 -- no spectrum leaves the
-// workgroup (16 waves = sixteen 1024-point transforms + a lane-local radix-16 step) that runs consecutive blocks of a
+// workgroup (8 waves = sixteen 1024-point transforms + a lane-local radix-16 step) that runs consecutive blocks of a
 // stream.  Frames are counted from the call's first frame; earlier ones come from the input history (ConvLbArgs: a ring
 // of twice its reach xh_len >= P2 x 8192), later ones are zeros.  Out of place only (a run's first windows read frames
 // another workgroup's blocks would overwrite).  Results equal the other plans' up to f32 rounding.
 struct ConvXbArgs {
     const float *in;            // the call's audio (planar); tables mode: the impulse responses
     float *out;
-    long long in_stream_stride, in_ch_stride, out_stream_stride, out_ch_stride;     // floats
+    long long in_stream_stride, in_ch_stride, out_stream_stride, out_ch_stride;     // floats; multiples of 4 (16-byte aligned buffers)
     const float *xhist;         // [stream][2][2 xh_len]; the frame k frames in front of the call at (xh_head - k) mod 2 xh_len; may be NULL
     long long xh_len, xh_head;
     long long io_frames;        // frames in `in` / `out` (a multiple of 512)
@@ -364,21 +362,25 @@ struct ConvXbArgs {
     int n_blk;                  // blocks of 8192 frames (the last one may reach beyond io_frames)
     int run;                    // consecutive blocks per workgroup (conv_xb_run_for)
     int P2;                     // partitions of 8192 taps: 1 or 2
-    const float4 *cd;           // [P2][2 planes][8192]: plane 0 = (C[k], D[k]), plane 1 = (C[N - k], D[N - k]), 1/16384 folded in
-    float4 *ab;                 // tables mode: the windows' spectra as pairs, [stream][n_blk][8192]
+    const float4 *cd;           // [P2][8 waves][2 classes][16 registers][64 lanes]: (C[k], D[k]) of that bin, 1/16384 folded in
+    float4 *ab;                 // tables mode: the windows' spectra per bin (float2, same layout), [stream][n_blk][16384]
     const float2 *tw;           // master twiddle table of the 1024-point transform
     const float2 *tw16384;      // [15][1024]: w16384^(n1 c), c = 1 .. 15
     float gain;
     int fp_mode;
     int tables_mode;            // 1 = window i is [block i of `in`, 8192 zeros], spectra to `ab`, nothing else
-    int debug_skip;             // timing knock-outs (WRONG results): Tuning::xb_skip
-    int form;                   // 1: sixteen waves + a pair image; 2: eight waves, mirrors by lane reversal (tables per bin, in the transforms' layout)
+    int stagger;                // every second workgroup starts this many x 3.5 us late (the CUs' load bursts then do not coincide)
+    int debug_skip;             // experiments build only (Tuning::xb_skip): timing knock-outs, wrong results; 0 in the product
 };
 hipError_t launch_conv_xb(const ConvXbArgs &a, hipStream_t st);
-hipError_t launch_conv_xb_build_cd(const float4 *ab, int P2, float4 *cd, hipStream_t st, int form);
+hipError_t launch_conv_xb_build_cd(const float2 *ab, int P2, float4 *cd, hipStream_t st);
 int conv_xb_run_for(int n_streams, int n_blk, int P2, int num_cus);
 void conv_xb_build_twiddles(float2 *out);       // host: [15][1024]
 constexpr int kXbBlock = 8192;                  // frames per block of this plan
+#ifdef OHS_EXPERIMENTS
+// the plan's first form (experiments/conv_xb16_kernels.hip): sixteen waves, pair tables [P2][2 planes][8192] as the block-2048 plan's
+hipError_t launch_conv_xb16(const ConvXbArgs &a, hipStream_t st);
+hipError_t launch_conv_xb16_build_cd(const float4 *ab, int P2, float4 *cd, hipStream_t st);
 #endif
 
 // IR chunk -> spectrum: dst[part][16][64], one wave per partition.

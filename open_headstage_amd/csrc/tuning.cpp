@@ -1,6 +1,7 @@
 // tuning.cpp -- see tuning.h.  Host-only.
 #include "tuning.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -133,6 +134,8 @@ bool tuning_set(const std::string &key, const std::string &value)
     if (key == "lb_skip") return one(&t.lb_skip);
     if (key == "xb_min_p") return one(&t.xb_min_p);
     if (key == "xb_min_blocks") return one(&t.xb_min_blocks);
+    if (key == "xb_min_streams_p2") return one(&t.xb_min_streams_p2);
+    if (key == "xb_stagger") { if (!one(&t.xb_stagger)) return false; t.xb_stagger = std::max(0, std::min(t.xb_stagger, 64)); return true; }
     if (key == "xb_run") return one(&t.xb_run);
     if (key == "xb_form") { if (!one(&t.xb_form)) return false; t.xb_form = t.xb_form == 2 ? 2 : 1; return true; }
     if (key == "xb_skip") return one(&t.xb_skip);

@@ -42,12 +42,15 @@ struct Tuning {
     int lb_seg_windows = 131072;            // windows (streams x blocks of 2048) per block-2048 launch pair, i.e. a ring of at most 4 GiB (a call's
                                             // own I/O at that size: 4 GiB): 512 streams x 256 blocks 1.16 ms at 4 096 -> 0.84, 2 048 streams 2.97 ms
                                             // (profiles/r05_lb_seg_sweep.txt)
-    int xb_min_p = 1 << 30;                 // experiments build: 512-tap partitions of the longest response from which the block-8192 kernel
-                                            // (experiments/conv_xb_kernels.hip) serves long out-of-place calls; off by default: it is slower
-    int xb_min_blocks = 128;                // ... for calls of at least this many 512-frame blocks
+    int xb_min_p = 2;                       // 512-tap partitions of the longest response from which the block-8192 kernel (conv_xb_kernels.hip)
+                                            // serves long out-of-place calls (up to 32: two partitions of 8192 taps)
+    int xb_min_blocks = 128;                // ... for calls of at least this many 512-frame blocks (64 streams x 128 blocks: a tie with block 2048;
+                                            // 256 blocks 0.118 vs 0.140 ms, 1024 blocks 0.38 vs 0.55: profiles/r05_xb_vs_lb_shapes.txt)
+    int xb_min_streams_p2 = 32;             // ... and, with two partitions, on at least this many streams (8 streams: 0.046 vs 0.043 ms)
+    int xb_stagger = 1;                     // every second workgroup starts this many x 3.5 us late
     int xb_skip = 0;                        // k_conv_xb timing knock-outs (WRONG results): 1 no input loads, 2 no twiddle loads, 4 no forward
                                             // transforms, 8 no table loads, 16 no inverse transforms, 32 no stores, 64 no radix-16 steps
-    int xb_form = 1;                        // k_conv_xb (1) or k_conv_xc (2)
+    int xb_form = 2;                        // experiments build: 1 = the sixteen-wave first form (experiments/conv_xb16_kernels.hip)
     int xb_run = 0;                         // > 0: blocks of 8192 per workgroup (else conv_xb_run_for)
     int lb_skip = 0;                        // k_conv_lb_mac_inverse timing knock-outs (WRONG results; experiments build only): 1 = no
                                             // products, 2 = no inverse transforms, 4 = no ring loads, 8 = no table loads

@@ -44,7 +44,8 @@ class _ExpTuning:
                 "p1_weights": "1425,1128,825,622", "p1_xcd": "off", "eq_xcd": "off", "eq_conveyor": "0", "eq_ring_v1": "0",
                 "eq_no_prio": "0", "eq_wg_waves": "0", "eq_lds": "0", "mac_no_xcd": "0",
                 "node_shared_device_rehearsal": "0", "node_inject_table_failure_slot": "0",
-                "xb_min_p": str(1 << 30), "xb_min_blocks": "128", "xb_run": "0", "xb_form": "1", "xb_skip": "0", "lb_min_p": "2", "lb_seg_windows": "131072",
+                "xb_min_p": "2", "xb_min_blocks": "128", "xb_min_streams_p2": "32", "xb_stagger": "1", "xb_run": "0", "xb_form": "2",
+                "xb_skip": "0", "lb_min_p": "2", "lb_seg_windows": "131072",
                 "lb_skip": "0"}
 
     def __init__(self):

@@ -162,7 +162,12 @@ def test_several_segments_per_call(oracle):
     bp = _make(ohs, S, irs, 2)
     base = synth.white_noise_torch(21, 3, 2 * nb * 512, dev)
     x = base[torch.arange(S, device=dev) % 3].contiguous()
-    y = torch.cat([bp.process(x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()) for c in range(2)], dim=2)
+    ys = []
+    for c in range(2):          # (in place: out of place a call this long would go to the block-8192 kernel)
+        xc = x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()
+        bp.process(xc, out=xc)
+        ys.append(xc)
+    y = torch.cat(ys, dim=2)
     torch.cuda.synchronize()
     assert bp.last_conv_plan()[0] == "block2048"
     for s in range(3, S):
@@ -320,26 +325,34 @@ def test_the_library_picks_block_2048_for_long_calls_on_long_responses():
 
 
 def test_config4_shape_both_plans(oracle):
-    """BASELINE config 4: 64 streams, 4 x 16 384 taps, 256-block calls: the block-2048 plan against the block-512 plan on all
-    streams and against the oracle on three, over two calls (the second one continues the first one's window grid)"""
+    """BASELINE config 4: 64 streams, 4 x 16 384 taps, 256-block calls: the library's choice out of place (the block-8192 kernel)
+    and in place (the block-2048 plan) against the block-512 plan on all streams and against the oracle on three, over two calls
+    (the second one continues from what the first one left)"""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
     dev = torch.device("cuda:0")
     S, nb, taps = 64, 256, 16384
     irs = synth.hrir_set(taps)
-    a, b = _make(ohs, S, irs, 1), _make(ohs, S, irs, 2)
+    a, b, c2 = _make(ohs, S, irs, 1), _make(ohs, S, irs, 0), _make(ohs, S, irs, 0)
     x = synth.white_noise_torch(50, S, 2 * nb * 512, dev)
     ya = torch.cat([a.process(x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()) for c in range(2)], dim=2)
     yb = torch.cat([b.process(x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()) for c in range(2)], dim=2)
+    ycs = []
+    for c in range(2):
+        xc = x[:, :, c * nb * 512:(c + 1) * nb * 512].contiguous()
+        c2.process(xc, out=xc)
+        ycs.append(xc)
+    yc = torch.cat(ycs, dim=2)
     torch.cuda.synchronize()
-    assert a.last_conv_plan()[0] == "block512_tp" and b.last_conv_plan() == ("block2048", 16)
-    d = (ya - yb).double()
-    per_stream = torch.sqrt((d * d).mean(dim=(1, 2))) / torch.sqrt((ya.double() ** 2).mean(dim=(1, 2)))
-    print(f"block 2048 vs block 512 at config 4: worst stream {float(per_stream.max()):.2e}")
-    assert float(per_stream.max()) <= 1e-6
+    assert a.last_conv_plan()[0] == "block512_tp" and b.last_conv_plan() == ("block8192", 4) and c2.last_conv_plan() == ("block2048", 16)
     xs = x.cpu().numpy()
-    for s in (0, 31, 63):
-        e = _oracle_engines(oracle, irs, 1)[0]
-        ref = np.stack(e.process_block(xs[s, 0], xs[s, 1]))
-        assert_parity(yb[s].cpu().numpy(), ref, f"config 4, block 2048, stream {s}")
+    for name, yy in (("block 8192", yb), ("block 2048", yc)):
+        d = (ya - yy).double()
+        per_stream = torch.sqrt((d * d).mean(dim=(1, 2))) / torch.sqrt((ya.double() ** 2).mean(dim=(1, 2)))
+        print(f"{name} vs block 512 at config 4: worst stream {float(per_stream.max()):.2e}")
+        assert float(per_stream.max()) <= 1e-6
+        for s in (0, 31, 63):
+            e = _oracle_engines(oracle, irs, 1)[0]
+            ref = np.stack(e.process_block(xs[s, 0], xs[s, 1]))
+            assert_parity(yy[s].cpu().numpy(), ref, f"config 4, {name}, stream {s}")

@@ -1,7 +1,7 @@
-"""The block-8192 / FFT-16384 kernel for long out-of-place calls on long impulse responses (csrc/experiments/conv_xb_kernels.hip) --
-EXPERIMENTS BUILD ONLY: a measured "no" (slower than the block-2048 plan on BASELINE config 4, LABNOTES.md round 5), kept honest
-by these tests: turned on through ohs_debug_set_tuning("xb_min_p", 13) for responses of 13 .. 32 partitions of 512 taps and calls
-of 128 blocks or more, checked against the oracle -- the restatement of the reference's uniform block-512 partitioning
+"""The block-8192 / FFT-16384 kernel for long out-of-place calls on long impulse responses (csrc/conv_xb_kernels.hip: the library's
+choice for responses of 2 .. 32 partitions of 512 taps on calls of 128 blocks or more -- with more than 16 partitions on 32 streams
+or more), and its sixteen-wave first form (csrc/experiments/conv_xb16_kernels.hip, experiments build, Tuning::xb_form = 1), checked
+against the oracle -- the restatement of the reference's uniform block-512 partitioning
 (src/dsp/convolution.rs:120-132,236-289) -- and against f64 direct convolution: one and two partitions of 8192 taps, calls that
 end inside an 8192-frame block, calls that follow calls served by the other plans (the state at rest is the input history all of
 them share), a per-path set_ir in mid-stream, paths of different lengths and a muted one."""
@@ -23,16 +23,26 @@ def _oracle_engines(oracle, irs, S):
     return engs
 
 
-@pytest.fixture(autouse=True, params=[1, 2], ids=["sixteen_waves", "eight_waves"])
-def _xb_on(exp_tuning, request):
-    exp_tuning("xb_min_p", 13)
-    exp_tuning("xb_form", request.param)
+_LIB = {"library": None}
+
+
+@pytest.fixture(autouse=True, params=["product", "sixteen_waves"])
+def _form(exp_tuning, request):
+    """product: libohs_hip.so as shipped; sixteen_waves: the experiments library with the first form selected.  Both with the
+    two-partition kernel allowed on any number of streams (the tests use 2 .. 3)."""
+    from open_headstage_amd import _ffi
+    if request.param == "product":
+        _LIB["library"] = None
+    else:
+        _LIB["library"] = _ffi.experiments_lib()
+        exp_tuning("xb_form", 1)
+        exp_tuning("xb_min_streams_p2", 1)
     yield
+    _LIB["library"] = None
 
 
 def _make(ohs, S, irs, plan=0, gain=1.0):
-    from open_headstage_amd import _ffi
-    bp = ohs.BatchProcessor(S, num_bands=10, library=_ffi.experiments_lib())
+    bp = ohs.BatchProcessor(S, num_bands=10, library=_LIB["library"])
     for p in range(4):
         bp.set_ir(p, irs[p])
     bp.set_eq_enabled(False)
@@ -41,19 +51,31 @@ def _make(ohs, S, irs, plan=0, gain=1.0):
     return bp
 
 
-@pytest.mark.parametrize("taps,blocks", [(16384, [144, 3, 131, 16, 160]), (9000, [129, 128]), (8192, [130, 1, 177]), (6700, [128, 200])])
+def _streams(taps):
+    """the library takes the kernel for two partitions of 8192 taps from 32 streams on: 34 streams that repeat three signals
+    (the experiments library of the sixteen-wave form has that threshold lowered: 3 streams do)"""
+    return 34 if taps > 8192 and _LIB["library"] is None else 3
+
+
+def _signals(synth, S, first_id, frames):
+    base = synth.white_noise(range(first_id, first_id + 3), frames)
+    return base, np.ascontiguousarray(base[np.arange(S) % 3])
+
+
+@pytest.mark.parametrize("taps,blocks", [(16384, [144, 3, 131, 16, 160]), (9000, [129, 128]), (8192, [130, 1, 177]), (6700, [128, 200]),
+                                         (1024, [128, 7, 150])])
 def test_block_8192_kernel_matches_the_oracle_and_f64(oracle, taps, blocks):
     """long calls take the block-8192 kernel, short ones in between the block-2048 plan: each continues from the input history the
     other leaves; call lengths that end inside an 8192-frame block (zeros behind the call, nothing stored there)"""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
-    S = 3
+    S = _streams(taps)
     irs = synth.hrir_set(taps)
     bp = _make(ohs, S, irs, 0, gain=0.9)
-    engs = _oracle_engines(oracle, irs, S)
+    engs = _oracle_engines(oracle, irs, 3)
     total = sum(blocks) * 512
-    x = synth.white_noise(range(S), total)
+    base, x = _signals(synth, S, 0, total)
     got, pos = [], 0
     for k, nb in enumerate(blocks):
         xt = torch.from_numpy(np.ascontiguousarray(x[:, :, pos:pos + nb * 512])).cuda()
@@ -62,24 +84,36 @@ def test_block_8192_kernel_matches_the_oracle_and_f64(oracle, taps, blocks):
         got.append(y.cpu().numpy())
         pos += nb * 512
     g = np.concatenate(got, axis=2)
-    for s in range(S):
-        ref = np.stack(engs[s].process_block(x[s, 0], x[s, 1])) * np.float32(0.9)
+    for s in range(3, S):
+        assert np.array_equal(g[s], g[s % 3]), f"stream {s} differs from stream {s % 3}"
+    for s in range(3):
+        ref = np.stack(engs[s].process_block(base[s, 0], base[s, 1])) * np.float32(0.9)
         assert_parity(g[s], ref, f"taps {taps}, stream {s}")
-    yl, yr = oracle.binaural_f64(x[0, 0], x[0, 1], irs)
+    yl, yr = oracle.binaural_f64(base[0, 0], base[0, 1], irs)
     a, r = rms_err(g[0], 0.9 * np.stack([yl, yr]))
     print(f"block-8192 kernel vs f64 direct convolution, {taps} taps: {r:.2e}")
     assert r <= 1e-6
 
 
-def test_in_place_calls_stay_with_block_2048(oracle):
+def test_what_the_library_does_not_give_the_kernel(oracle):
+    """in-place calls (a run's first windows read frames another workgroup's blocks would overwrite), calls shorter than 128
+    blocks, two partitions of 8192 taps on fewer than 32 streams (block 2048 is faster there), more than two partitions"""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
-    irs = synth.hrir_set(16384)
-    bp = _make(ohs, 2, irs)
-    x = torch.from_numpy(synth.white_noise(range(2), 160 * 512)).cuda()
-    bp.process(x, out=x)
-    assert bp.last_conv_plan()[0] == "block2048"
+    if _LIB["library"] is not None:
+        pytest.skip("the product's rule")
+    for taps, S, nb, in_place, want in ((16384, 34, 160, True, "block2048"), (16384, 34, 127, False, "block2048"),
+                                        (16384, 8, 160, False, "block2048"), (16385, 34, 160, False, "block2048"),
+                                        (8192, 2, 160, False, "block8192"), (16384, 32, 128, False, "block8192")):
+        irs = synth.hrir_set(taps)
+        bp = _make(ohs, S, irs)
+        x = torch.from_numpy(synth.white_noise(range(S), nb * 512)).cuda()
+        if in_place:
+            bp.process(x, out=x)
+        else:
+            bp.process(x)
+        assert bp.last_conv_plan()[0] == want, (taps, S, nb, in_place, bp.last_conv_plan())
 
 
 def test_different_lengths_a_muted_path_and_a_midstream_set_ir(oracle):
@@ -88,12 +122,12 @@ def test_different_lengths_a_muted_path_and_a_midstream_set_ir(oracle):
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
-    S = 3
-    base = synth.hrir_set(16384)
-    irs = [base[0], base[1][:700], base[2][:0], base[3][:9000]]
+    S = _streams(16384)
+    hb = synth.hrir_set(16384)
+    irs = [hb[0], hb[1][:700], hb[2][:0], hb[3][:9000]]
     bp = _make(ohs, S, irs)
-    engs = _oracle_engines(oracle, irs, S)
-    x = synth.white_noise(range(40, 40 + S), 3 * 140 * 512)
+    engs = _oracle_engines(oracle, irs, 3)
+    base, x = _signals(synth, S, 40, 3 * 140 * 512)
     got, ref = [], []
     for k in range(3):
         if k == 1:
@@ -101,12 +135,14 @@ def test_different_lengths_a_muted_path_and_a_midstream_set_ir(oracle):
             bp.set_ir(1, h)
             for e in engs:
                 e.set_ir(1, h)
-        seg = np.ascontiguousarray(x[:, :, k * 140 * 512:(k + 1) * 140 * 512])
-        got.append(bp.process(torch.from_numpy(seg).cuda()).cpu().numpy())
+        sl = slice(k * 140 * 512, (k + 1) * 140 * 512)
+        got.append(bp.process(torch.from_numpy(np.ascontiguousarray(x[:, :, sl])).cuda()).cpu().numpy())
         assert bp.last_conv_plan()[0] == "block8192", (k, bp.last_conv_plan())
-        ref.append(np.stack([np.stack(engs[s].process_block(seg[s, 0], seg[s, 1])) for s in range(S)]))
+        ref.append(np.stack([np.stack(engs[s].process_block(base[s, 0, sl].copy(), base[s, 1, sl].copy())) for s in range(3)]))
     g, r = np.concatenate(got, axis=2), np.concatenate(ref, axis=2)
-    for s in range(S):
+    for s in range(3, S):
+        assert np.array_equal(g[s], g[s % 3]), f"stream {s} differs from stream {s % 3}"
+    for s in range(3):
         assert_parity(g[s], r[s], f"stream {s}")
 
 

@@ -7,7 +7,8 @@ stream, blocks in sequence: ~290 x the steady call).  Now the time-parallel kern
 behind a zeroed gap of the ring and k_conv_tp_old adds, under the per-path gate, what each path may still see of them.
 Checked: parity with the oracle across several resets (longer, shorter, muted), and the cost of the call after a reset.
 
-Round 5: the steady call of this shape is served by the block-2048 plan (0.13 ms instead of 0.25), and an object that keeps
+Round 5: the steady call of this shape is served by the large-block plans (block 8192 out of place: 0.12 ms, block 2048 in place:
+0.135, instead of 0.25), and an object that keeps
 the input history (every batch object with a response of two partitions or more) carries a per-path set_ir out as "every
 path forgets its past" + pending tails -- what the frames in front of the reset still owe the output through the surviving
 paths, computed once at set_ir time and added to the calls that follow (api_conv.hip: conv_lb_tail_route).  The call
@@ -108,7 +109,7 @@ def test_the_call_after_a_per_path_set_ir_costs_at_most_three_steady_calls():
     for _ in range(3):
         timed_call()
     steady = sorted(timed_call() for _ in range(7))[3]
-    assert bp.last_conv_plan()[0] == "block2048"
+    assert bp.last_conv_plan()[0] == "block8192"        # (out of place, 256 blocks: the single-kernel plan; in place: block 2048)
     after = []
     for k in range(6):
         bp.set_ir(k % 4, irs[(k + 1) % 4])
