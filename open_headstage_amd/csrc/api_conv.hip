@@ -537,14 +537,20 @@ static int conv_xb_launch(ConvState &c, DeviceCtx *ctx, const float *in, long lo
     a.io_frames = frames; a.n_streams = (int)c.S; a.n_blk = (int)((frames + kXbBlock - 1) / kXbBlock);
     a.run = conv_xb_run_for(a.n_streams, a.n_blk, P2, ctx->num_cus);
     a.cd = c.d_xb_cd; a.gain = gain; a.fp_mode = c.fp_mode; a.stagger = tuning().xb_stagger;
+    // the call's last frames join the input history: appended by the kernel itself, into the half of the ring it does not read
+    const long long xcnt = std::min(frames, c.xh_len);
+    bool own_append = form == 2;
+#ifdef OHS_EXPERIMENTS
+    if (tuning().xb_append_launch) own_append = false;     // (A/B: the append as a launch of its own behind the kernel)
+#endif
+    if (own_append) { a.xh_append = c.d_xhist; a.xh_cnt = xcnt; }
 #ifdef OHS_EXPERIMENTS
     if (tuning().xb_run > 0) a.run = std::min(tuning().xb_run, a.n_blk);
     a.debug_skip = tuning().xb_skip;
 #endif
     hipError_t e = launch(a);
-    // the call's last frames join the input history (behind the kernel: it reads the history's present state)
-    const long long xcnt = std::min(frames, c.xh_len);
-    if (e == hipSuccess) e = launch_conv_lb_xhist_append(in, in_ss, in_cs, c.d_xhist, c.xh_len, c.xh_head, frames, (int)c.S, st);
+    if (e == hipSuccess && !own_append)     // (the first form does not append: a launch behind it)
+        e = launch_conv_lb_xhist_append(in, in_ss, in_cs, c.d_xhist, c.xh_len, c.xh_head, frames, (int)c.S, st);
     if (e != hipSuccess) return fail(OHS_ERR_HIP, std::string("block-8192 launch: ") + hipGetErrorString(e));
     c.xh_head = (c.xh_head + xcnt) % (2 * c.xh_len);
     c.xh_valid = std::min(c.xh_len, c.xh_valid + frames);

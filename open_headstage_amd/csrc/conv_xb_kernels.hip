@@ -10,7 +10,7 @@
 // -- the second partition's product is computed one block early and waits in registers.  A workgroup runs consecutive
 // blocks of one stream (the run's first window is transformed for its carry alone); per frame 8 B in (+ the window's
 // first half again: the output is stored non-temporally so that it stays in the L2), 8 B out, nothing else.  The state at
-// rest is the block-2048 plan's: the streams' last input frames (ConvState::d_xhist).
+// rest is the block-2048 plan's: the streams' last input frames (ConvState::d_xhist), which the kernel appends to itself.
 //
 // The 16 384-point transform = sixteen of the wave's 1024-point transforms (wave_fft.hpp) plus a lane-local radix-16 step
 // (tools/proto_xb_conv.py is the index-exact CPU model):
@@ -143,7 +143,10 @@ __global__ __launch_bounds__(512) void k_conv_xb(const ConvXbArgs A)
         t0 = make_float2(t.x, t.y); t1 = make_float2(t.z, t.w);
     };
     // one sixteenth (1024 frames from frame f0 of the call's axis) of a window: the thread's frames f0 + 2 tid, + 1
-    auto load16th = [&](long long f0, xb_v2f &l, xb_v2f &r) {
+    // own: the sixteenth belongs to the block's own frames (the window's second half) -- every frame of the call is loaded as
+    // such exactly once, and the call's last xh_cnt frames join the input history then, in the half of the ring no window reads
+    const long long app0 = A.io_frames - A.xh_cnt;
+    auto load16th = [&](long long f0, bool own, xb_v2f &l, xb_v2f &r) {
         l = (xb_v2f){0.f, 0.f}; r = (xb_v2f){0.f, 0.f};
         if (dskip & 1) return;
         if (f0 >= 0) {
@@ -151,6 +154,13 @@ __global__ __launch_bounds__(512) void k_conv_xb(const ConvXbArgs A)
                 const int so = __builtin_amdgcn_readfirstlane((int)(f0 * 4));
                 l = __builtin_bit_cast(xb_v2f, __builtin_amdgcn_raw_buffer_load_b64(r_in_l, v8, so, 0));
                 r = __builtin_bit_cast(xb_v2f, __builtin_amdgcn_raw_buffer_load_b64(r_in_r, v8, so, 0));
+                if (own && A.xh_append && f0 + half >= app0) {
+                    long long pos = A.xh_head + (f0 + half - app0);     // (a 512-frame chunk does not straddle the ring's wrap)
+                    pos = pos >= L2 ? pos - L2 : pos;
+                    const int sa = __builtin_amdgcn_readfirstlane((int)(pos * 4));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xb_v2u, l), r_xh_l, v8h, sa, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xb_v2u, r), r_xh_r, v8h, sa, 0);
+                }
             }
         } else if (A.xhist && A.xh_len + f0 >= 0) {
             long long idx = A.xh_head + f0 + half;      // (the head is a multiple of 512: a half sixteenth does not straddle the wrap)
@@ -161,13 +171,13 @@ __global__ __launch_bounds__(512) void k_conv_xb(const ConvXbArgs A)
         }
     };
     // window i -> the spectra of the wave's two classes in the 1024-point transform's bin layout
-    auto forward = [&](int i, float2 (&ZA)[16], float2 (&ZB)[16]) {
+    auto forward = [&](int i, bool main_block, float2 (&ZA)[16], float2 (&ZB)[16]) {
         const long long w0 = A.tables_mode ? (long long)i * 8192 : ((long long)i - 1) * 8192;
         float2 z0[16], z1[16];
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             xb_v2f l = {0.f, 0.f}, r = {0.f, 0.f};
-            if (!A.tables_mode || n2 < 8) load16th(w0 + 1024 * n2, l, r);
+            if (!A.tables_mode || n2 < 8) load16th(w0 + 1024 * n2, main_block && n2 >= 8 && !A.tables_mode, l, r);
             z0[n2] = make_float2(l.x, r.x); z1[n2] = make_float2(l.y, r.y);
         }
         float2 t0[16], t1[16];
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(512) void k_conv_xb(const ConvXbArgs A)
     if (A.tables_mode) {
         for (int i = i0; i < i1; ++i) {
             float2 ZA[16], ZB[16];
-            forward(i, ZA, ZB);
+            forward(i, false, ZA, ZB);
             float2 *dst = reinterpret_cast<float2 *>(A.ab) + ((size_t)s * A.n_blk + i) * kXbFft + (size_t)(w * 2) * 16 * 64 + lane;
 #pragma unroll
             for (int R = 0; R < 16; ++R) { dst[R * 64] = ZA[R]; dst[(16 + R) * 64] = ZB[R]; }
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(512) void k_conv_xb(const ConvXbArgs A)
     for (int R = 0; R < 16; ++R) { CA[R] = (xb_v2f){0.f, 0.f}; CB[R] = (xb_v2f){0.f, 0.f}; }
     if constexpr (P2 == 2) {
         float2 ZA[16], ZB[16];
-        forward(i0 - 1, ZA, ZB);
+        forward(i0 - 1, false, ZA, ZB);
         products(ZA, ZB, WA, WB, CA, CB, true, false);
     }
     const __amdgpu_buffer_rsrc_t r_out_l = __builtin_amdgcn_make_buffer_rsrc(A.out + s * A.out_stream_stride, 0, io_bytes, 0x00020000);
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(512) void k_conv_xb(const ConvXbArgs A)
     for (int i = i0; i < i1; ++i) {
         {
             float2 ZA[16], ZB[16];
-            forward(i, ZA, ZB);
+            forward(i, true, ZA, ZB);
             products(ZA, ZB, WA, WB, CA, CB, false, i + 1 >= i1);
         }
         {
@@ -368,6 +378,7 @@ hipError_t launch_conv_xb(const ConvXbArgs &a, hipStream_t st)
         return hipErrorInvalidValue;
     if (a.tables_mode ? !a.ab : (!a.out || !a.cd)) return hipErrorInvalidValue;
     if (a.io_frames < 0 || (a.io_frames & 511) || a.stagger < 0 || a.stagger > 64 ||
+        (a.xh_append && (a.xh_append != a.xhist || a.xh_cnt < 0 || (a.xh_cnt & 511) || a.xh_cnt > a.xh_len || a.xh_cnt > a.io_frames)) ||
         (a.xhist && (a.xh_len <= 0 || (a.xh_len & 511) || a.xh_head < 0 || a.xh_head >= 2 * a.xh_len)))
         return hipErrorInvalidValue;
     static std::atomic<unsigned long long> ok1{0}, ok2{0};

@@ -356,7 +356,9 @@ struct ConvXbArgs {
     float *out;
     long long in_stream_stride, in_ch_stride, out_stream_stride, out_ch_stride;     // floats; multiples of 4 (16-byte aligned buffers)
     const float *xhist;         // [stream][2][2 xh_len]; the frame k frames in front of the call at (xh_head - k) mod 2 xh_len; may be NULL
-    long long xh_len, xh_head;
+    float *xh_append;           // != NULL (k_conv_xb only): the call's last xh_cnt = min(io_frames, xh_len) frames are appended at xh_head ..
+                                // (the half of the ring nobody reads) by the workgroups that load them as their blocks' own frames
+    long long xh_len, xh_head, xh_cnt;
     long long io_frames;        // frames in `in` / `out` (a multiple of 512)
     int n_streams;
     int n_blk;                  // blocks of 8192 frames (the last one may reach beyond io_frames)

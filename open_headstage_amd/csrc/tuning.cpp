@@ -137,6 +137,7 @@ bool tuning_set(const std::string &key, const std::string &value)
     if (key == "xb_min_streams_p2") return one(&t.xb_min_streams_p2);
     if (key == "xb_stagger") { if (!one(&t.xb_stagger)) return false; t.xb_stagger = std::max(0, std::min(t.xb_stagger, 64)); return true; }
     if (key == "xb_run") return one(&t.xb_run);
+    if (key == "xb_append_launch") return one(&t.xb_append_launch);
     if (key == "xb_form") { if (!one(&t.xb_form)) return false; t.xb_form = t.xb_form == 2 ? 2 : 1; return true; }
     if (key == "xb_skip") return one(&t.xb_skip);
     if (key == "lb_seg_windows") { if (!one(&t.lb_seg_windows)) return false; if (t.lb_seg_windows < 64) t.lb_seg_windows = 64; return true; }

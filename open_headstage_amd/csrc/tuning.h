@@ -51,6 +51,7 @@ struct Tuning {
     int xb_skip = 0;                        // k_conv_xb timing knock-outs (WRONG results): 1 no input loads, 2 no twiddle loads, 4 no forward
                                             // transforms, 8 no table loads, 16 no inverse transforms, 32 no stores, 64 no radix-16 steps
     int xb_form = 2;                        // experiments build: 1 = the sixteen-wave first form (experiments/conv_xb16_kernels.hip)
+    int xb_append_launch = 0;               // experiments build: 1 = the history append as a launch of its own (A/B)
     int xb_run = 0;                         // > 0: blocks of 8192 per workgroup (else conv_xb_run_for)
     int lb_skip = 0;                        // k_conv_lb_mac_inverse timing knock-outs (WRONG results; experiments build only): 1 = no
                                             // products, 2 = no inverse transforms, 4 = no ring loads, 8 = no table loads
