@@ -363,7 +363,7 @@ int conv_xb_run_for(int n_streams, int n_blk, int P2, int num_cus)
 {
     int best_run = 1;
     double best = -1.0;
-    for (int run = 1; run <= n_blk; ++run) {
+    for (int run = 1; run <= n_blk && run <= 256; ++run) {      // (the search stops at 256 blocks per workgroup)
         const long long wgs = (long long)n_streams * ((n_blk + run - 1) / run);
         const long long rounds = (wgs + num_cus - 1) / num_cus;
         const double cost = (double)rounds * (run + (P2 == 2 ? 0.5 : 0.0));
