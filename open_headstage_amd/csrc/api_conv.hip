@@ -14,6 +14,8 @@ void conv_free(ConvState &c)
     DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
     for (int p = 0; p < 4; ++p) { if (c.d_H[p]) hipFree(c.d_H[p]); c.d_H[p] = nullptr; }
     if (c.d_hist) hipFree(c.d_hist);
+    if (c.d_pre) hipFree(c.d_pre);
+    c.d_pre = nullptr; c.pre_cnt = ~0ull; c.pre_n = 0;
     if (c.d_tails) hipFree(c.d_tails);
     if (c.d_tails_alt) hipFree(c.d_tails_alt);
     if (c.d_cd) hipFree(c.d_cd);
@@ -130,6 +132,7 @@ static int conv_materialise_from_xhist(ConvState &c, DeviceCtx *ctx, hipStream_t
 
 int conv_materialise_state(ConvState &c, DeviceCtx *ctx, hipStream_t st)
 {
+    if (c.lb_lazy || c.tails_lazy) c.pre_cnt = ~0ull;       // (the ring is about to be rewritten)
     if (c.lb_lazy) {
         const int rc = conv_materialise_from_xhist(c, ctx, st);
         if (rc) return rc;
@@ -154,6 +157,7 @@ int conv_grow_ring(ConvState &c, int need, hipStream_t st)
 {
     if (need <= c.cap) return OHS_OK;
     DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    c.pre_cnt = ~0ull;
     const int ncap = next_pow2(need);
     float2 *nh = nullptr;
     HIP_TRY(hipMalloc(&nh, c.S * (size_t)ncap * NF * sizeof(float2)));
@@ -570,6 +574,7 @@ int conv_set_ir(ConvState &c, DeviceCtx *ctx, int path, const float *ir, size_t 
     if (len > (size_t)1 << 30) return fail(OHS_ERR_INVALID_ARG, "ir too long");
     const int P = len == 0 ? 1 : (int)((len + BS - 1) / BS);
     DeviceWideSection dws;      // (frees / device-wide waits below: no resident kernel may be in their way)
+    c.pre_cnt = ~0ull;          // sums computed ahead belong to the old response and the old `since`
     if (c.lazy_ok && !c.d_xhist && c.tails_lazy && c.d_last_in) {
         // The first response of several partitions on an object that has run the one-partition fast path so far: no input
         // history was kept, but one-partition paths reach back 511 frames only, and the fast path's state at rest holds

@@ -103,6 +103,16 @@ int engine_pinned_reserve(ohs_engine *e, size_t n)
 // the whole process_block call -- FIFO adapter, up to 8 internal blocks, pop
 // with gain -- as ONE kernel launch reading / writing pinned host memory directly (plus one EQ
 // launch for the lib.rs chain).  Requires the invariant in.len < 512, which both call paths keep.
+// The buffer of the sums computed ahead (kernels.h: ConvGeneralArgs::pre) exists from the first response of more than one
+// partition on -- allocated where set_ir / clone allocate, never on the audio thread.
+int engine_pre_reserve(ConvState &c)
+{
+    if (c.d_pre || conv_max_p(c) <= 1) return OHS_OK;
+    HIP_TRY(hipMalloc(&c.d_pre, (size_t)8 * 2 * NF * sizeof(float2)));
+    c.pre_cnt = ~0ull; c.pre_n = 0;
+    return OHS_OK;
+}
+
 int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *in_r, float *out_l,
                                  float *out_r, size_t n, ohs_eq *eq, float gain)
 {
@@ -144,6 +154,7 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
     a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
     a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
     a.tw = e->ctx->d_tw; a.gain = 1.0f; a.fp_mode = e->conv.fp_mode;
+    conv_pre_args(c, a, (int)k);
     EngineCallArgs g;
     g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
     g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
@@ -155,6 +166,7 @@ int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *
     if (err != hipSuccess) return fail(OHS_ERR_HIP, std::string("engine call launch: ") + hipGetErrorString(err));
     c.cnt += k;
     for (int p = 0; p < 4; ++p) c.since[p] += (long long)k;
+    conv_pre_served(c, (int)k);
     e->in.len = e->in.len + n - k * BS;
     e->out.len = emit ? e->out.len + k * BS - n : e->out.len + k * BS;
     {   // the kernel's own completion word (it is stored behind a system-scope release of the frames); the stream
@@ -282,6 +294,7 @@ int rt_start(ohs_engine *e)
     a.hist = c.d_hist; a.cap = c.cap; a.cnt = c.cnt;
     a.tails = c.d_tails; a.tails_out = c.d_tails; a.skip_store = 0; a.zero_tails_in = 0;
     a.tw = e->ctx->d_tw; a.gain = 1.0f; a.fp_mode = e->conv.fp_mode;
+    conv_pre_args(c, a, 0);     // (the kernel sets pre_n itself after every call that completes a block; the host mirrors it)
     EngineCallArgs &g = mb->call;
     g.in_fifo = e->in.d; g.in_cap = (int)e->in.cap; g.in_len = (int)e->in.len;
     g.out_fifo = e->out.d; g.out_cap = (int)e->out.cap; g.out_len = (int)e->out.len;
@@ -380,6 +393,7 @@ int engine_process_resident(ohs_engine *e, const float *in_l, const float *in_r,
     }
     c.cnt += k;
     for (int p = 0; p < 4; ++p) c.since[p] += (long long)k;
+    conv_pre_served(c, (int)k);
     e->in.len = e->in.len + n - k * BS;
     e->out.len = emit ? e->out.len + k * BS - n : e->out.len + k * BS;
     if (emit) {
@@ -564,6 +578,7 @@ int ohs_engine_clone(const ohs_engine *src, ohs_engine **out)
         return bail(fail(OHS_ERR_HIP, "hipMemcpy"));
     if (hipMemcpyAsync(d.d_tails, s.d_tails, 2 * 8 * 64 * sizeof(float2), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return bail(fail(OHS_ERR_HIP, "hipMemcpy"));
+    if (engine_pre_reserve(d) != OHS_OK) return bail(OHS_ERR_HIP);      // (its first call computes every partition itself)
     const DevFifo *sf[2] = {&src->in, &src->out};
     DevFifo *df[2] = {&e->in, &e->out};
     for (int i = 0; i < 2; ++i) {
@@ -591,7 +606,9 @@ int ohs_engine_set_ir(ohs_engine *e, int path, const float *ir, size_t len)
     // older spectra the first of them reads AND the 8 new ones -- grown here, not on the audio thread
     int maxP = 1;
     for (int p = 0; p < 4; ++p) maxP = std::max(maxP, e->conv.P[p]);
-    return conv_grow_ring(e->conv, maxP + 7, e->st);
+    rc = conv_grow_ring(e->conv, maxP + 7, e->st);
+    if (rc) return rc;
+    return engine_pre_reserve(e->conv);
 }
 
 int ohs_engine_process_block(ohs_engine *e, const float *in_l, const float *in_r, float *out_l,
@@ -616,6 +633,7 @@ int ohs_engine_set_flush_denormals(ohs_engine *e, int mode)
         HIP_TRY(hipSetDevice(e->device));
         rt_stop(e);         // the resident kernel set its mode when it started; the next call restarts it
         e->conv.fp_mode = mode;
+        e->conv.pre_cnt = ~0ull;    // (sums computed ahead were computed in the old mode)
     }
     return OHS_OK;
 }

@@ -185,6 +185,13 @@ struct ConvState {
     float4 *d_xb_cd = nullptr, *d_xb_ab = nullptr;
     int xb_p2 = 0, xb_form = 0;
     unsigned long long lb_tables_gen = 1, xb_cd_gen = 0;
+    // Engines (one stream) with a response of more than one partition: the next call's sums over the partitions behind it
+    // (kernels.h: ConvGeneralArgs::pre), computed by the kernel that served the previous call.  They belong to the state
+    // with block counter pre_cnt; anything else that touches the state (set_ir, reset, a ring that moved, another kernel
+    // that processes blocks) leaves pre_cnt != cnt or sets it to ~0 here.
+    float2 *d_pre = nullptr;        // [8][2][1024]
+    unsigned long long pre_cnt = ~0ull;
+    int pre_n = 0;
     // what served the last convolution launch (ohs_batch_last_conv_plan): OHS_CONV_KERNEL_*, and its ranges per stream
     int last_kernel = 0, last_ranges = 0;
     unsigned long long kernel_calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // conv_launch calls served per family (ohs_batch_conv_plan_counts)
@@ -195,6 +202,23 @@ struct ConvState {
 };
 
 void conv_free(ConvState &c);
+inline int conv_max_p(const ConvState &c) { return std::max(std::max(c.P[0], c.P[1]), std::max(c.P[2], c.P[3])); }
+// the `pre` fields of an engine kernel's arguments for a call that completes k blocks (<= 8)
+inline void conv_pre_args(const ConvState &c, ConvGeneralArgs &a, int k)
+{
+    const bool on = c.d_pre != nullptr && conv_max_p(c) > 1;
+    a.pre = on ? c.d_pre : nullptr;
+    a.pre_n = (on && c.pre_cnt == c.cnt) ? c.pre_n : 0;
+    a.pre_next = on ? k : 0;
+}
+// ... and the host's mirror of what the kernel left behind (after c.cnt has been advanced by k)
+inline void conv_pre_served(ConvState &c, int k)
+{
+    if (k <= 0) return;             // no block completed: the sums found stay what they are
+    const bool on = c.d_pre != nullptr && conv_max_p(c) > 1;
+    c.pre_cnt = on ? c.cnt : ~0ull;
+    c.pre_n = on ? k : 0;
+}
 int conv_init(ConvState &c, size_t S, hipStream_t st);
 int conv_enable_lazy_state(ConvState &c);
 int conv_materialise_state(ConvState &c, DeviceCtx *ctx, hipStream_t st);

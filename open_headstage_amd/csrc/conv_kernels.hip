@@ -212,16 +212,24 @@ __device__ __forceinline__ void block_mac(const ConvGeneralArgs &A, const float2
 // 0, 1 (acc = lsl + j lsr), h = 1 -> paths 2, 3 (rsl + j rsr).  Same operations in the same order as block_mac (and
 // the same skip rule over all four gates), so the two agree bit for bit.  LDS_P0: partition 0 of path p is read from
 // hl[p][1024] in LDS (the resident kernel's copy) instead of A.H[p].
+// Partitions i_begin .. i_end - 1 only, on top of `init` (nullptr: zero): the engine kernels' split of the sum into the
+// part that involves the call's own blocks and the part computed ahead (ConvGeneralArgs::pre).
 template <bool LDS_P0>
 __device__ __forceinline__ void block_mac_half(const ConvGeneralArgs &A, const float2 *hist, const float2 *hl, int t,
-                                               int maxP, int h, const float2 (&v)[16], float2 (&acc)[16], int lane)
+                                               int i_begin, int i_end, const float2 *init, int h, const float2 (&v)[16],
+                                               float2 (&acc)[16], int lane)
 {
     const unsigned long long mask = (unsigned long long)(A.cap - 1);
     const int Pa = h ? A.P[2] : A.P[0], Pb = h ? A.P[3] : A.P[1];
     const float2 *Ha = h ? A.H[2] : A.H[0], *Hb = h ? A.H[3] : A.H[1];
+    if (init) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = make_float2(0.f, 0.f);
-    for (int i = 0; i < maxP; ++i) {
+        for (int r = 0; r < 16; ++r) acc[r] = init[r * 64 + lane];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = make_float2(0.f, 0.f);
+    }
+    for (int i = i_begin; i < i_end; ++i) {
         const bool g0 = i < A.P[0] && (long long)i <= A.since[0] + t;
         const bool g1 = i < A.P[1] && (long long)i <= A.since[1] + t;
         const bool g2 = i < A.P[2] && (long long)i <= A.since[2] + t;
@@ -434,8 +442,12 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     if (active) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = zt[r * 64 + lane];
+        // blocks whose sum over the partitions behind the call was computed ahead (engine_presum, by the kernel that
+        // served the previous call): only the partitions that pair with the call's own blocks are left
+        const bool ahead = t < A.pre_n;
+        const int i_end = ahead ? (t + 1 < maxP ? t + 1 : maxP) : maxP;
         for (int h = h0; h < h1; ++h) {
-            block_mac_half<RESIDENT>(A, hist, hl, t, maxP, h, v, acc, lane);
+            block_mac_half<RESIDENT>(A, hist, hl, t, 0, i_end, ahead ? A.pre + (size_t)(2 * t + h) * kFft : nullptr, h, v, acc, lane);
             OHS_DBG_STAMP(12);
             wave_fft_inv(acc, lds, tab, lane);      // re = lsl | rsl, im = lsr | rsr   (:276)
             OHS_DBG_STAMP(13);
@@ -473,11 +485,12 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     if (active && t == A.n_blocks - 1) {
         for (int h = h0; h < h1; ++h) {
             const float2 *park = parked(t, h);
+            const int ln = here(lane);      // (addresses formed here, not hoisted out of the resident kernel's call loop)
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                const float2 u = park[a * 64 + lane];
-                A.tails_out[(8 * h + a) * 64 + lane] = u;
-                if constexpr (RESIDENT) tails_lds[(8 * h + a) * 64 + lane] = u;     // the next call's block 0 reads it here
+                const float2 u = park[a * 64 + ln];
+                A.tails_out[(8 * h + a) * 64 + ln] = u;
+                if constexpr (RESIDENT) tails_lds[(8 * h + a) * 64 + ln] = u;       // the next call's block 0 reads it here
             }
         }
     }
@@ -509,6 +522,87 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     }
 }
 
+// What the NEXT call's blocks 0 .. n_next - 1 owe to the blocks already in the ring (ConvGeneralArgs::pre): run by every
+// wave of the workgroup behind the call's completion word, with `An` = the state AFTER the call (cnt, since advanced).
+// Task (j, h) = block j, half h: partitions j + 1 .. maxP - 1 pair with ring slots cnt + j - i < cnt only.  No barrier inside.
+// Same products and sums per spectrum value, in the same order, as block_mac_half -- but in no hurry and on few registers
+// (the resident kernel's call body leaves none: with block_mac_half inlined a second time hipcc parked loop-invariant
+// addresses of the CALL's path in scratch memory): the 16 registers of a spectrum go through in two passes of the
+// register groups {g, 3 - g}, which are each other's mirrors (wave_mirror), 8 accumulators at a time.
+__device__ __forceinline__ void engine_presum(const ConvGeneralArgs &An, int n_next, int wave_u, int lane, int n_waves)
+{
+    int maxP = An.P[0];
+#pragma unroll
+    for (int p = 1; p < 4; ++p) maxP = An.P[p] > maxP ? An.P[p] : maxP;
+    const unsigned long long mask = (unsigned long long)(An.cap - 1);
+    const int srcA = (63 - lane) << 2, srcB = ((64 - lane) & 63) << 2;
+    // A task's two passes are independent (different rows of the spectrum): with few blocks they are dealt to the waves
+    // one by one -- a 1 024-frame call's 2 blocks x 2 halves x 2 passes occupy all eight waves --, else a wave runs both.
+    // (This loop structure is also the one hipcc allocates without scratch in k_engine_resident; a flat loop over the
+    // passes, or block_mac_half itself, cost 1 - 8 spilled registers on the CALL's path: libohs_hip.resources.json.)
+    const bool deal_passes = 4 * n_next <= n_waves;
+    for (int sub = wave_u; sub < (deal_passes ? 4 : 2) * n_next; sub += n_waves) {
+        const int task = deal_passes ? sub >> 1 : sub;
+        const int g_begin = deal_passes ? (sub & 1) : 0, g_end = deal_passes ? g_begin + 1 : 2;
+        const int j = task >> 1, h = task & 1;
+        const int Pa = h ? An.P[2] : An.P[0], Pb = h ? An.P[3] : An.P[1];
+        const float2 *Ha = h ? An.H[2] : An.H[0], *Hb = h ? An.H[3] : An.H[1];
+        const long long sa = h ? An.since[2] : An.since[0], sb = h ? An.since[3] : An.since[1];
+        float2 *dst = An.pre + (size_t)task * kFft;
+#pragma unroll 1
+        for (int g = g_begin; g < g_end; ++g) {
+            // register groups g (rows 4 g ..) and 3 - g; row 4 (g ? 3 : 1) is what lane 0 needs beside them
+            const int r1 = 4 * g, r2 = 4 * (3 - g), rx = g ? 12 : 4;
+            float2 acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = make_float2(0.f, 0.f);
+#pragma unroll 1
+            for (int i = j + 1; i < maxP; ++i) {
+                const bool ga = i < Pa && (long long)i <= sa + j, gb = i < Pb && (long long)i <= sb + j;
+                if (!(ga || gb)) continue;
+                const float2 *hs = An.hist + ((An.cnt + (unsigned long long)j - (unsigned long long)i) & mask) * kFft;
+                float2 z[8], zm[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { z[k] = hs[(r1 + k) * 64 + lane]; z[4 + k] = hs[(r2 + k) * 64 + lane]; }
+                const float2 zx = hs[rx * 64 + lane];
+                // wave_mirror, groups g and 3 - g:  zm[4 r + q] <- z[4 (3 - r) + 4 - q] of lane 63 - L (q = 1..3);
+                //                                   zm[4 r]     <- z[4 (3 - r)] of lane 64 - L, lane 0: its own z[4 ((4 - r) & 3)]
+                auto bp = [](int src, float2 v) {
+                    float2 o;
+                    o.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x)));
+                    o.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)));
+                    return o;
+                };
+#pragma unroll
+                for (int q = 1; q < 4; ++q) { zm[q] = bp(srcA, z[4 + 4 - q]); zm[4 + q] = bp(srcA, z[4 - q]); }
+                {
+                    const float2 m0 = bp(srcB, z[4]), m1 = bp(srcB, z[0]);
+                    // own rows: group g = 0: z[4 ((4 - 0) & 3)] = z[0]; group 3: z[4]  (rx);   g = 1: group 1: z[12] (rx); group 2: z[8]
+                    const float2 own1 = g ? zx : z[0], own2 = g ? z[4] : zx;
+                    zm[0] = lane == 0 ? own1 : m0;
+                    zm[4] = lane == 0 ? own2 : m1;
+                }
+                const float fa = ga ? 1.0f : 0.0f, fb = gb ? 1.0f : 0.0f;
+                const float2 *ha = Ha + (size_t)(i < Pa ? i : Pa - 1) * kFft;
+                const float2 *hb = Hb + (size_t)(i < Pb ? i : Pb - 1) * kFft;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = (k < 4 ? r1 : r2 - 4) + k;
+                    float2 c0 = ha[row * 64 + lane], c1 = hb[row * 64 + lane];
+                    c0.x *= fa; c0.y *= fa; c1.x *= fb; c1.y *= fb;
+                    const float2 xl = make_float2(0.5f * (z[k].x + zm[k].x), 0.5f * (z[k].y - zm[k].y));
+                    const float2 xr = make_float2(0.5f * (z[k].y + zm[k].y), -0.5f * (z[k].x - zm[k].x));
+                    const float2 x = h ? xr : xl;
+                    cmac(acc[k], x, c0);
+                    cmac_j(acc[k], x, c1);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[((k < 4 ? r1 : r2 - 4) + k) * 64 + lane] = acc[k];
+        }
+    }
+}
+
 // One launch = one call.
 // `done` (pinned host memory, may be null): the call's sequence number is stored there once every wave's stores have
 // drained and been released -- the host spins on that word instead of querying the stream, whose completion signal
@@ -531,6 +625,15 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+    // behind the completion word (the host has its frames): the next call's sums over the partitions behind it.  The next
+    // launch on the engine's stream waits for this kernel, i.e. for them.
+    if (A.pre_next > 0) {
+        ConvGeneralArgs An = A;
+        An.cnt += (unsigned long long)A.n_blocks;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) An.since[p] += A.n_blocks;
+        engine_presum(An, A.pre_next, __builtin_amdgcn_readfirstlane(wave), lane, n_waves);     // (task, block, half: uniform)
     }
 }
 
@@ -815,6 +918,27 @@ __global__ __launch_bounds__(512) void k_engine_resident(RtMailbox *mb, const fl
             for (int p = 0; p < 4; ++p) A.since[p] += k;
             E.in_len = E.in_len + E.n - k * kBlock;
             E.out_len = E.emit ? E.out_len + k * kBlock - E.n : E.out_len + k * kBlock;
+            // the next call's blocks 0 .. k - 1 will find their sums over the partitions behind the call computed (below);
+            // a call that completed no block leaves the sums it found valid
+            if (k > 0) {
+                int mp = A.P[0];
+                for (int p = 1; p < 4; ++p) mp = A.P[p] > mp ? A.P[p] : mp;
+                A.pre_n = (A.pre != nullptr && mp > 1) ? k : 0;
+            }
+        }
+        __syncthreads();
+        {
+            // behind the completion word: ConvGeneralArgs::pre for the next call (every wave; no barrier inside; a doorbell
+            // that rings meanwhile is seen when wave 0 is back in its loop -- the call then waits for what it would
+            // otherwise have computed itself)
+            const int k_u = __builtin_amdgcn_readfirstlane(A.n_blocks);
+            const int pn_u = __builtin_amdgcn_readfirstlane(A.pre_n);
+            if (k_u > 0 && pn_u > 0) {
+                ConvGeneralArgs An;
+                uniform_copy(An, A);
+                engine_presum(An, k_u, wave_u, lane, 8);
+                __threadfence_block();
+            }
         }
         // (the barrier at the top of the loop orders these updates before the next call reads them)
     }

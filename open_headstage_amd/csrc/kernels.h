@@ -89,6 +89,15 @@ struct ConvGeneralArgs {
     const float2 *tw;           // master twiddle table, 1024 entries
     float gain;
     int fp_mode;                // denormal handling, see ohs_set_fp_mode
+    // Single-engine calls on responses of more than one partition (k_engine_call / k_engine_resident): the part of a block's
+    // spectrum product that only involves blocks ALREADY in the ring does not wait for the call -- the kernel that served
+    // call N computes, behind its completion word, for the next call's block j (0 <= j < pre_next) and half h
+    //     pre[2 j + h] = sum over partitions i = j + 1 .. P - 1 of  history[cnt' + j - i] * H[i]        (cnt', since': after call N)
+    // and call N + 1 only adds partitions 0 .. j (its own blocks) on top: a 1 024-frame call on a 16 384-tap response
+    // waits for 1 + 2 partition products instead of 2 x 32.  pre_n = how many blocks of THIS call find their sum in `pre`
+    // (0: none, every partition is computed in the call, as before).
+    float2 *pre = nullptr;      // [8][2][16][64]
+    int pre_n = 0, pre_next = 0;
 };
 hipError_t launch_conv_general(const ConvGeneralArgs &a, int n_streams, hipStream_t st);
 

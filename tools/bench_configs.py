@@ -45,12 +45,18 @@ def run_batch(name, S, taps, frames, eq_on, steps=5, warmup=2):
                       "conv_model_GBps": round(cb / (conv_ms / n * 1e-3) / 1e9, 1)}), flush=True)
 
 
-def _per_call(fn, items):
+def _per_call(fn, items, gap_us=0.0):
+    """gap_us > 0: the host idles that long in front of every call (not timed) -- a real-time host's calls are 21 ms apart,
+    and what the engine kernels compute ahead behind a call's completion word is then done when the next call arrives"""
     import gc
     gc.collect()
     gc.disable()        # a full collection with torch loaded takes ~40 ms and would land on one call
     ts = []
     for it in items:
+        if gap_us > 0:
+            tw = time.perf_counter() + gap_us * 1e-6
+            while time.perf_counter() < tw:
+                pass
         t0 = time.perf_counter()
         fn(*it)
         ts.append(time.perf_counter() - t0)
@@ -119,6 +125,31 @@ def run_engine_c2(calls=400, n=1024):
                       "x_realtime": round(n / (st["median"] * 1e-6) / 48000.0, 0)}), flush=True)
 
 
+def run_engine_long_ir(taps_list=(2048, 4096, 8192, 16384), calls=300, n=1024):
+    """The plugin's own use of config 4's response: ONE engine, a room response of `taps` taps per path, 1 024-frame
+    host blocks through the blocking C ABI (launch per call, then the resident kernel)."""
+    for taps in taps_list:
+        e = ohs.ConvolutionEngine.new()
+        irs = synth.hrir_set(taps)
+        for p in range(4):
+            e.set_ir(p, irs[p])
+        x = synth.white_noise([0], n * (calls + 40))[0]
+        ol = np.empty(n, np.float32); orr = np.empty(n, np.float32)
+        bl = [(x[0, c * n:(c + 1) * n].copy(), x[1, c * n:(c + 1) * n].copy()) for c in range(calls + 40)]
+        for mode in ("launch_per_call", "resident_kernel"):
+            e.set_realtime(mode == "resident_kernel")
+            for l, r in bl[:40]:
+                e.process_block(l, r, ol, orr)
+            st = _per_call(lambda l, r: e.process_block(l, r, ol, orr), bl[40:])
+            paced = _per_call(lambda l, r: e.process_block(l, r, ol, orr), bl[40:], gap_us=300.0)
+            print(json.dumps({"config": f"c4_engine_{n}_{mode}", "taps": taps, "partitions": (taps + 511) // 512,
+                              "us_per_call_back_to_back": st["median"], "us_per_call_300us_apart": paced["median"],
+                              "latency_us_back_to_back": st, "latency_us_300us_apart": paced,
+                              "x_realtime_back_to_back": round(n / (st["median"] * 1e-6) / 48000.0, 0)}), flush=True)
+        e.set_realtime(False)
+        del e
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c4", "c3noeq"]
     if "c2" in which:
@@ -127,5 +158,7 @@ if __name__ == "__main__":
     if "c3noeq" in which:
         # 30 untimed steps: the first full-chip steps after start run ~25 % slower than the steady state (bench.py, conv_alone)
         run_batch("c3_noeq", 256, 512, 480256, False, steps=16, warmup=30)
+    if "c4engine" in which:
+        run_engine_long_ir()
     if "c4" in which:
         run_batch("c4_p32_64streams", 64, 16384, 512 * 256, False, steps=16, warmup=30)
