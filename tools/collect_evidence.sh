@@ -15,6 +15,8 @@ python3 tools/bench_configs.py > "$out/other_configs.jsonl" 2> "$out/other_confi
 # native latency harness: the JSON lines join the other configs, the whole output (with the device-side phases) is kept too
 timeout -k 10 120 tools/bin/rt_latency > "$out/rt_latency.txt" 2>> "$out/other_configs.err" || true
 grep -v '^#' "$out/rt_latency.txt" >> "$out/other_configs.jsonl" || true
+timeout -k 10 120 tools/bin/rt_latency long > "$out/rt_latency_long.txt" 2>> "$out/other_configs.err" || true
+grep -v '^#' "$out/rt_latency_long.txt" >> "$out/other_configs.jsonl" || true
 timeout -k 10 120 tools/bin/rt_latency soak 300000 > "$out/rt_soak.txt" 2>> "$out/other_configs.err" || true
 # micro-benchmarks the design decisions quote
 timeout -k 10 120 tools/bin/ubench_lds > "$out/ubench_lds.txt" 2>&1 || true

@@ -30,6 +30,7 @@ static const char *fmt_phase(char *buf, size_t cap, uint64_t a, uint64_t b)
     return buf;
 }
 
+static double g_gap_us = 0.0;    /* > 0: the host idles that long in front of every call (not timed), as a real-time host does */
 static ohs_eq *g_eq = NULL;      /* != NULL: time ohs_chain_process (EQ -> convolution -> gain) instead of process_block */
 
 static int one_call(ohs_engine *e, float *il, float *ir, float *ol, float *orr, size_t n)
@@ -51,6 +52,7 @@ static void run(ohs_engine *e, size_t n, int calls, const char *what)
     for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; il[i] = (float)(s >> 8) / 8388608.0f - 1.0f; ir[i] = -il[i]; }
     for (int c = 0; c < 50; ++c) one_call(e, il, ir, ol, orr, n);
     for (int c = 0; c < calls; ++c) {
+        if (g_gap_us > 0.0) { const double tw = now_us() + g_gap_us; while (now_us() < tw) { } }
         const double t0 = now_us();
         if (one_call(e, il, ir, ol, orr, n)) { printf("error: %s\n", ohs_last_error()); exit(1); }
         t[c] = now_us() - t0;
@@ -92,6 +94,35 @@ int main(int argc, char **argv)
     for (int p = 0; p < 4; ++p) {
         for (int i = 0; i < 512; ++i) h[i] = (i == 30 + 15 * (p == 1 || p == 2)) ? 1.0f : 0.3f * expf(-i / 85.0f) * ((i * 7919 % 13) - 6) / 60.0f;
         ohs_engine_set_ir(e, p, h, 512);
+    }
+    if (argc > 1 && !strcmp(argv[1], "long")) {
+        /* rt_latency long: the plugin's 1 024-frame call on ROOM responses (BASELINE config 4's 4 x 16 384 taps, and 4 096):
+         * calls back to back -- each waits for what the previous one left to compute ahead -- and 300 us apart (a real-time
+         * host's are 21 ms apart) */
+        static float hl[16384];
+        const int taps_list[2] = {4096, 16384};
+        for (int k = 0; k < 2; ++k) {
+            const int taps = taps_list[k];
+            char name[96];
+            for (int p = 0; p < 4; ++p) {
+                for (int i = 0; i < taps; ++i)
+                    hl[i] = (i == 30 + 15 * (p == 1 || p == 2)) ? 1.0f : 0.3f * expf(-(float)i * 6.0f / (float)taps) * ((i * 7919 % 13) - 6) / (float)taps;
+                if (ohs_engine_set_ir(e, p, hl, (size_t)taps)) { printf("set_ir: %s\n", ohs_last_error()); return 1; }
+            }
+            for (int rt = 0; rt < 2; ++rt) {
+                ohs_engine_set_realtime(e, rt);
+                for (int paced = 0; paced < 2; ++paced) {
+                    g_gap_us = paced ? 300.0 : 0.0;
+                    snprintf(name, sizeof(name), "c_host_engine_1024_%dtaps_%s_%s", taps, rt ? "resident_kernel" : "launch_per_call",
+                             paced ? "300us_apart" : "back_to_back");
+                    run(e, 1024, 1000, name);
+                }
+            }
+            g_gap_us = 0.0;
+            ohs_engine_set_realtime(e, 0);
+        }
+        ohs_engine_destroy(e);
+        return 0;
     }
     if (soak > 0) {
         ohs_engine_set_realtime(e, 1);

@@ -6,7 +6,7 @@ tag=$1
 o=gpurun_out/$tag
 cp $o/bench.json profiles/${tag}_bench.json
 cp $o/other_configs.jsonl profiles/${tag}_other_configs.jsonl
-for f in rt_latency rt_soak ubench_lds ubench_pcie; do [ -s $o/$f.txt ] && cp $o/$f.txt profiles/${tag}_$f.txt; done
+for f in rt_latency rt_latency_long rt_soak ubench_lds ubench_pcie; do [ -s $o/$f.txt ] && cp $o/$f.txt profiles/${tag}_$f.txt; done
 for wl in headline c3noeq c4; do
     # kernel statistics of our own kernels only (the torch elementwise kernels of the synthetic-data generator are not ours)
     head -1 $o/kt_$wl/run_kernel_stats.csv > profiles/${tag}_kernel_stats_$wl.csv
