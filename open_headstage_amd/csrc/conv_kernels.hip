@@ -626,15 +626,62 @@ __global__ __launch_bounds__(512) void k_engine_call(const ConvGeneralArgs A, co
             __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    // behind the completion word (the host has its frames): the next call's sums over the partitions behind it.  The next
-    // launch on the engine's stream waits for this kernel, i.e. for them.
-    if (A.pre_next > 0) {
-        ConvGeneralArgs An = A;
-        An.cnt += (unsigned long long)A.n_blocks;
+}
+
+// The launch-per-call form's engine_presum: a kernel of its own, queued right behind k_engine_call (the host launches it
+// before it starts waiting for the call's completion word, so the call does not pay for it) -- over the chip instead of
+// inside the call's one workgroup: a host that calls back to back (an offline render through the reference's
+// process_block loop) waits 5 - 8 us for it instead of 35 - 45.  Workgroup = one wave = (task, spectrum row r): every lane
+// owns ONE spectrum value and walks the partitions in engine_presum's order with engine_presum's operations (the value's
+// mirror comes from memory instead of a lane permutation: same number), so both forms leave the same bits.
+// A = the state AFTER the call.  grid = 2 n_next x 16.
+__global__ __launch_bounds__(64) void k_engine_presum(const ConvGeneralArgs A)
+{
+    ohs_set_fp_mode(A.fp_mode);
+    const int lane = threadIdx.x;
+    const int task = blockIdx.x >> 4, r = blockIdx.x & 15;
+    const int j = task >> 1, h = task & 1;
+    int maxP = A.P[0];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) An.since[p] += A.n_blocks;
-        engine_presum(An, A.pre_next, __builtin_amdgcn_readfirstlane(wave), lane, n_waves);     // (task, block, half: uniform)
+    for (int p = 1; p < 4; ++p) maxP = A.P[p] > maxP ? A.P[p] : maxP;
+    const unsigned long long mask = (unsigned long long)(A.cap - 1);
+    const int Pa = h ? A.P[2] : A.P[0], Pb = h ? A.P[3] : A.P[1];
+    const float2 *Ha = h ? A.H[2] : A.H[0], *Hb = h ? A.H[3] : A.H[1];
+    const long long sa = h ? A.since[2] : A.since[0], sb = h ? A.since[3] : A.since[1];
+    // wave_mirror: register 4 rr + q of lane L takes  q = 1..3: register 4 (3 - rr) + 4 - q of lane 63 - L;
+    //              q = 0: register 4 (3 - rr) of lane 64 - L, lane 0: its own register 4 ((4 - rr) & 3)
+    const int rr = r >> 2, q = r & 3;
+    const int rm = q ? 4 * (3 - rr) + 4 - q : (lane == 0 ? 4 * ((4 - rr) & 3) : 4 * (3 - rr));
+    const int lm = q ? 63 - lane : (64 - lane) & 63;
+    const int own = r * 64 + lane, mir = rm * 64 + lm;
+    float2 acc = make_float2(0.f, 0.f);
+    constexpr int U = 8;                    // partitions whose four loads are in flight together
+    for (int i0 = j + 1; i0 < maxP; i0 += U) {
+        float2 z[U], zm[U], ca[U], cb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u < maxP ? i0 + u : maxP - 1;        // (clamped: loaded, not used)
+            const float2 *hs = A.hist + ((A.cnt + (unsigned long long)j - (unsigned long long)i) & mask) * kFft;
+            z[u] = hs[own]; zm[u] = hs[mir];
+            ca[u] = Ha[(size_t)(i < Pa ? i : Pa - 1) * kFft + own];
+            cb[u] = Hb[(size_t)(i < Pb ? i : Pb - 1) * kFft + own];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            const bool ga = i < Pa && (long long)i <= sa + j, gb = i < Pb && (long long)i <= sb + j;
+            if (i >= maxP || !(ga || gb)) continue;
+            const float fa = ga ? 1.0f : 0.0f, fb = gb ? 1.0f : 0.0f;
+            float2 c0 = ca[u], c1 = cb[u];
+            c0.x *= fa; c0.y *= fa; c1.x *= fb; c1.y *= fb;
+            const float2 xl = make_float2(0.5f * (z[u].x + zm[u].x), 0.5f * (z[u].y - zm[u].y));
+            const float2 xr = make_float2(0.5f * (z[u].y + zm[u].y), -0.5f * (z[u].x - zm[u].x));
+            const float2 x = h ? xr : xl;
+            cmac(acc, x, c0);
+            cmac_j(acc, x, c1);
+        }
     }
+    A.pre[(size_t)task * kFft + own] = acc;
 }
 
 // RESIDENT form ("persistent kernels + pinned-memory mailboxes"): one workgroup of 8
@@ -974,7 +1021,16 @@ hipError_t launch_engine_call(const ConvGeneralArgs &a, const EngineCallArgs &e,
     const hipError_t e2 = allow_large_lds(reinterpret_cast<const void *>(k_engine_call), kEngineLdsBytes, lds_ok);
     if (e2 != hipSuccess) return e2;
     hipLaunchKernelGGL(k_engine_call, dim3(1), dim3(512), kEngineLdsBytes, st, a, e, done, seq);
-    return hipGetLastError();
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess && a.pre_next > 0 && a.pre != nullptr) {
+        // the next call's sums over the partitions behind it (ConvGeneralArgs::pre), from the state this call leaves
+        ConvGeneralArgs an = a;
+        an.cnt += (unsigned long long)a.n_blocks;
+        for (int p = 0; p < 4; ++p) an.since[p] += a.n_blocks;
+        hipLaunchKernelGGL(k_engine_presum, dim3(2 * a.pre_next * 16), dim3(64), 0, st, an);
+        err = hipGetLastError();
+    }
+    return err;
 }
 
 // ---------------------------------------------------------------------------------

@@ -90,8 +90,9 @@ struct ConvGeneralArgs {
     float gain;
     int fp_mode;                // denormal handling, see ohs_set_fp_mode
     // Single-engine calls on responses of more than one partition (k_engine_call / k_engine_resident): the part of a block's
-    // spectrum product that only involves blocks ALREADY in the ring does not wait for the call -- the kernel that served
-    // call N computes, behind its completion word, for the next call's block j (0 <= j < pre_next) and half h
+    // spectrum product that only involves blocks ALREADY in the ring does not wait for the call -- behind call N (the resident
+    // kernel: behind its completion word; launch per call: k_engine_presum, queued behind k_engine_call) the next call's
+    // block j (0 <= j < pre_next) and half h get
     //     pre[2 j + h] = sum over partitions i = j + 1 .. P - 1 of  history[cnt' + j - i] * H[i]        (cnt', since': after call N)
     // and call N + 1 only adds partitions 0 .. j (its own blocks) on top: a 1 024-frame call on a 16 384-tap response
     // waits for 1 + 2 partition products instead of 2 x 32.  pre_n = how many blocks of THIS call find their sum in `pre`
