@@ -89,7 +89,13 @@ int  ohs_engine_set_ir(ohs_engine *e, int path, const float *ir, size_t len);
 /* ConvolutionEngine::process_block(&mut self, in_l, in_r, out_l, out_r)
  * convolution.rs:141-182.  All four slices have n elements.  Appends to the input
  * FIFOs, runs every complete 512-block, pops n outputs, or fills zeros when fewer
- * than n are available (:176-181). */
+ * than n are available (:176-181).
+ * Responses of more than one partition (convolution.rs:261-273): the part of a block's sum over the partitions that
+ * pairs with blocks processed EARLIER does not wait for the call -- it is computed behind the previous call (a kernel
+ * queued behind the call's own; in real-time mode the resident kernel, between the calls), so a 1 024-frame call on
+ * 4 x 16 384 taps costs what it costs on 4 x 512 (+ 2 us).  Nothing to do for the host; set_ir and calls of more than
+ * 4 096 frames simply start over.  A host that calls back to back (an offline render) is served fastest with real-time
+ * mode OFF: the resident kernel's one workgroup does that work between the calls. */
 int  ohs_engine_process_block(ohs_engine *e, const float *in_l, const float *in_r,
                               float *out_l, float *out_r, size_t n);
 /* engine.paths[p].ir_fft_partitions.len()  (asserted by the reference test, convolution.rs:395-399) */
