@@ -101,7 +101,7 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
             assert np.array_equal(r.view(np.uint32), orr.view(np.uint32)), (seed, step, n)
         elif op < 0.80:                 # one path gets a new impulse response (set_ir resets that path only)
             p = int(rng.integers(0, 4))
-            h = _random_ir(rng, int(rng.choice([0, 1, 100, 512, 513, 1500, 2048])))
+            h = _random_ir(rng, int(rng.choice([0, 1, 100, 512, 513, 1500, 2048, 5000])))   # (several partitions: sums computed ahead)
             eg.set_ir(p, h); eo.set_ir(p, h)
         elif op < 0.90:                 # retune / toggle a band (state is kept: parametric_eq.rs:112)
             i = int(rng.integers(0, nb))
