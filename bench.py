@@ -161,8 +161,30 @@ def cpu_baseline(frames: int, target_seconds: float = 10.0):
     for t in ths:
         t.join()
     tm = time.perf_counter() - t0
+    # the plugin's own call on BASELINE configs[3]'s response, one thread: one engine, 4 x 16 384 taps (32 partitions per path,
+    # convolution.rs:261-273), 1 024-frame process_block -- beside long_ir.plugin_call of the GPU record
+    long_call = None
+    try:
+        irs_l = synth.hrir_set(16384)
+        eng = orc.ConvolutionEngine()
+        for p in range(4):
+            eng.set_ir(p, irs_l[p])
+        xl = synth.white_noise([7], 1024 * 8)[0]
+        ts = []
+        for c in range(120):
+            l = xl[0, (c & 7) * 1024:((c & 7) + 1) * 1024]
+            r = xl[1, (c & 7) * 1024:((c & 7) + 1) * 1024]
+            t1 = time.perf_counter()
+            eng.process_block(l, r)
+            ts.append(time.perf_counter() - t1)
+        ts = sorted(ts[40:])
+        long_call = {"workload": "1 engine, 4 x 16384 taps, 1024-frame process_block, one thread",
+                     "us_per_call_median": round(ts[len(ts) // 2] * 1e6, 1), "us_per_call_min": round(ts[0] * 1e6, 1)}
+    except Exception as e:      # noqa: BLE001
+        long_call = {"error": str(e)[:200]}
     orc.use_library(None)
     return {
+        "long_ir_plugin_call": long_call,
         "value": round(sum(done) * sample_frames / tm / 1e6, 4),
         "unit": "Msamples/s",
         "cores": cores,
@@ -1008,10 +1030,13 @@ def main() -> int:
                 xn = synth.white_noise([0], 1024 * 8)[0]
                 bl = [(xn[0, c * 1024:(c + 1) * 1024].copy(), xn[1, c * 1024:(c + 1) * 1024].copy()) for c in range(8)]
                 ol, orr = np.empty(1024, np.float32), np.empty(1024, np.float32)
-                pc = {"workload": f"1 engine, 4 x {taps4} taps, 1024-frame calls, resident kernel, ctypes-driven"}
+                pc = {"workload": f"1 engine, 4 x {taps4} taps, 1024-frame calls, ctypes-driven; resident kernel unless named otherwise"}
                 gc.collect()
                 gc.disable()
-                for key, gap in (("us_per_call_300us_apart", 300e-6), ("us_per_call_back_to_back", 0.0)):
+                for key, gap in (("us_per_call_300us_apart", 300e-6), ("us_per_call_back_to_back", 0.0),
+                                 ("launch_per_call_us_back_to_back", 0.0)):
+                    if key.startswith("launch"):        # real-time mode off: what an offline render through process_block sees
+                        eng.set_realtime(False)
                     ts = []
                     for c in range(340):
                         if gap:
