@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the other BASELINE.json configs (not the headline bench): C2 single stream, C4 long IR.
-Prints one JSON line per config.  Usage: python tools/bench_configs.py [c2] [c4] [c3noeq]"""
+Prints one JSON line per config.  Usage: python tools/bench_configs.py [c2] [c4] [c3noeq] [c4engine]"""
 import json
 import os
 import sys
@@ -151,7 +151,7 @@ def run_engine_long_ir(taps_list=(2048, 4096, 8192, 16384), calls=300, n=1024):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c4", "c3noeq"]
+    which = sys.argv[1:] or ["c2", "c4", "c3noeq", "c4engine"]
     if "c2" in which:
         run_engine_c2()
         run_batch("c2_batch_1stream", 1, 512, 480256, False)
