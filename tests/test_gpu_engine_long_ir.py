@@ -128,3 +128,30 @@ def test_resident_and_launch_per_call_agree_bit_for_bit(ohs, synth, taps):
         ga, gb = np.stack(a.process_block(l, r)), np.stack(b.process_block(l, r))
         assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32)), (taps, n, o)
         o += n
+
+
+@pytest.mark.parametrize("realtime,n", [(False, 1024), (True, 1024), (True, 256), (False, 1536)])
+def test_an_impulse_reads_every_partition_back(ohs, synth, realtime, n):
+    """The reference's identity / delay known-answer tests (convolution.rs:317-383) on a response of 32 partitions: an
+    impulse in the left channel must come back as Lsl's taps in the left ear and Lsr's in the right, tap for tap -- every
+    partition paired with the right block, whether its product was computed in the call or ahead of it."""
+    taps = 16384
+    irs = synth.hrir_set(taps)
+    e = ohs.ConvolutionEngine.new()
+    for p in range(4):
+        e.set_ir(p, irs[p])
+    e.set_realtime(realtime)
+    pos = 700                                       # not on a block boundary
+    total = ((pos + taps + 2048) // n + 1) * n
+    x = np.zeros((2, total), np.float32)
+    x[0, pos] = 1.0
+    outs = []
+    for c in range(total // n):
+        outs.append(np.stack(e.process_block(x[0, c * n:(c + 1) * n].copy(), x[1, c * n:(c + 1) * n].copy())))
+    y = np.concatenate(outs, 1)
+    lat = 0 if n % 512 == 0 else int(e.latency_samples(n))
+    for ear, path in ((0, 0), (1, 1)):
+        got = y[ear, lat + pos:lat + pos + taps]
+        want = np.asarray(irs[path], np.float32)
+        assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())), (ear, float(np.abs(got - want).max()))
+    assert np.abs(y[:, :lat + pos]).max() <= 1e-6 and np.abs(y[:, lat + pos + taps:]).max() <= 1e-6
