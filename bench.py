@@ -485,7 +485,10 @@ def node_batch_leg(n: int, args, frames: int, headline_value, timeout_s: float =
                 os.killpg(proc.pid, signal.SIGKILL)
             except ProcessLookupError:
                 pass
-            proc.communicate()
+            try:
+                proc.communicate(timeout=10)        # (a child stuck in the driver does not die at once: do not wait for it)
+            except subprocess.TimeoutExpired:
+                pass
             return {"error": f"child run timed out after {timeout_s:.0f} s (process group ended)"}
         lines = [l for l in so.splitlines() if l.startswith("{")]
         if proc.returncode != 0 or len(lines) != 1:
@@ -1087,12 +1090,14 @@ def main() -> int:
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
                 try:
-                    out["node_batch"] = node_batch_leg(leg_n, args, frames, out["value"])
+                    # (first contact of N communicators in one process happens on the driver's box, unattended: a tighter
+                    # bound than at N = 1 -- the leg is an extra, the contract line must not wait minutes for it)
+                    out["node_batch"] = node_batch_leg(leg_n, args, frames, out["value"], timeout_s=150.0)
                 finally:
                     store.set("ohs_node_batch_leg_done", "1")
             else:
                 import datetime
-                store.wait(["ohs_node_batch_leg_done"], datetime.timedelta(seconds=330))
+                store.wait(["ohs_node_batch_leg_done"], datetime.timedelta(seconds=200))
         except Exception as e:      # noqa: BLE001 -- an extra must never break the contract line
             if rank == 0 and out is not None:
                 out.setdefault("node_batch", {"error": str(e)[:200]})
