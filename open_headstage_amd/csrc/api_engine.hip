@@ -100,9 +100,6 @@ int engine_pinned_reserve(ohs_engine *e, size_t n)
     return OHS_OK;
 }
 
-// SURVEY section 8 row f2: the whole process_block call -- FIFO adapter, up to 8 internal blocks, pop
-// with gain -- as ONE kernel launch reading / writing pinned host memory directly (plus one EQ
-// launch for the lib.rs chain).  Requires the invariant in.len < 512, which both call paths keep.
 // The buffer of the sums computed ahead (kernels.h: ConvGeneralArgs::pre) exists from the first response of more than one
 // partition on -- allocated where set_ir / clone allocate, never on the audio thread.
 int engine_pre_reserve(ConvState &c)
@@ -113,6 +110,9 @@ int engine_pre_reserve(ConvState &c)
     return OHS_OK;
 }
 
+// SURVEY section 8 row f2: the whole process_block call -- FIFO adapter, up to 8 internal blocks, pop
+// with gain -- as ONE kernel launch reading / writing pinned host memory directly (plus one EQ
+// launch for the lib.rs chain).  Requires the invariant in.len < 512, which both call paths keep.
 int engine_process_single_launch(ohs_engine *e, const float *in_l, const float *in_r, float *out_l,
                                  float *out_r, size_t n, ohs_eq *eq, float gain)
 {

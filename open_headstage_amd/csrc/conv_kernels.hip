@@ -442,8 +442,9 @@ __device__ __forceinline__ void engine_call_body(const ConvGeneralArgs &A, const
     if (active) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = zt[r * 64 + lane];
-        // blocks whose sum over the partitions behind the call was computed ahead (engine_presum, by the kernel that
-        // served the previous call): only the partitions that pair with the call's own blocks are left
+        // blocks whose sum over the partitions behind the call was computed ahead (behind the previous call: engine_presum in
+        // the resident kernel, k_engine_presum behind k_engine_call): only the partitions that pair with the call's own
+        // blocks are left
         const bool ahead = t < A.pre_n;
         const int i_end = ahead ? (t + 1 < maxP ? t + 1 : maxP) : maxP;
         for (int h = h0; h < h1; ++h) {

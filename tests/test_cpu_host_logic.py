@@ -214,7 +214,7 @@ def test_kernel_register_budgets(lib):
     assert res["k_conv_p1"]["scratch_bytes_per_lane"] == 0
     # the single-stream kernels: nothing in scratch memory on a real-time call's path (round 3: 92 B per lane in the
     # resident kernel -- thread 0's time stamps and loop-invariant addresses alive across the call body)
-    for k in ("k_engine_resident", "k_engine_call", "k_conv_general", "k_conv_p1_edges", "k_conv_p1_state", "k_conv_tp_old",
+    for k in ("k_engine_resident", "k_engine_call", "k_engine_presum", "k_conv_general", "k_conv_p1_edges", "k_conv_p1_state", "k_conv_tp_old",
               "k_conv_tp_mac<16>", "k_conv_tp_mac<32>", "k_conv_tp_forward", "k_conv_tp_inverse", "k_os_tables"):
         assert res[k]["scratch_bytes_per_lane"] == 0, (k, res[k])
     assert res["k_conv_general"]["vgprs"] <= 256 and res["k_conv_general"]["agprs"] <= 64      # (AGPR moves, no scratch: a fallback)
