@@ -440,6 +440,23 @@ int engine_process(ohs_engine *e, const float *in_l, const float *in_r, float *o
     }
     rt_stop(e);         // the paths below launch kernels on the engine's state
     if (rt_sized) return engine_process_single_launch(e, in_l, in_r, out_l, out_r, n, eq, gain);
+    // Host blocks of 4 097 .. 8 192 frames (a DAW's largest buffers): the path below stages through four stream copies
+    // from and to the caller's pageable buffers and costs ~100 us before its first frame (an 8 192-frame call took 3.5 x a
+    // 4 096-frame one: profiles/r05_engine_call_sizes_before.jsonl); two calls of the one-launch kernel serve such a block
+    // in about half of that while a block needs few partition products.  Same result as ONE call (convolution.rs:141-182):
+    // the first part completes exactly 8 blocks and empties the input FIFO; if the whole call pops its n frames
+    // (out_len + 512 k >= n, :163), so does each part -- out_len + 4096 >= n1 always, and the second part's condition
+    // is the whole call's with n1 subtracted on both sides.  A call that would answer with silence (:176-181) keeps the
+    // path below.  The chain's EQ is sample-serial: splitting its block changes nothing.
+    if (n <= 8192 && e->in.len < (size_t)BS && conv_max_p(e->conv) <= 8) {
+        const size_t k = (e->in.len + n) / BS;
+        if (e->out.len + k * BS >= n) {
+            const size_t n1 = (size_t)8 * BS - e->in.len;
+            const int rc1 = engine_process_single_launch(e, in_l, in_r, out_l, out_r, n1, eq, gain);
+            if (rc1) return rc1;
+            return engine_process_single_launch(e, in_l + n1, in_r + n1, out_l + n1, out_r + n1, n - n1, eq, gain);
+        }
+    }
     int rc = fifo_reserve(e->in, e->in.len + n, st);
     if (rc) return rc;
     // :149-150 append

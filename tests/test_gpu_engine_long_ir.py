@@ -155,3 +155,18 @@ def test_an_impulse_reads_every_partition_back(ohs, synth, realtime, n):
         want = np.asarray(irs[path], np.float32)
         assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())), (ear, float(np.abs(got - want).max()))
     assert np.abs(y[:, :lat + pos]).max() <= 1e-6 and np.abs(y[:, lat + pos + taps:]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("taps", [512, 3000, 16384])
+def test_host_blocks_of_up_to_8192_frames(ohs, synth, oracle, taps):
+    """Host blocks of 4 097 .. 8 192 frames are served as two calls of the one-launch kernel (few partitions) or by the
+    staged path (many; and whenever the call answers with silence, convolution.rs:176-181): the reference's FIFO
+    semantics either way -- ragged sizes, a first call that cannot pop its frames, the remainder carried over."""
+    ge = ohs.ConvolutionEngine.new()
+    irs = synth.hrir_set(taps)
+    eo = setup_engines(oracle, ge, irs)
+    sizes = [5000, 8192, 8192, 4608, 300, 8192, 6000, 4097, 1024, 8191, 8192, 211, 7000]
+    x = synth.white_noise([26], sum(sizes))[0]
+    g, r, _ = _run(ge, eo, x, sizes)
+    assert np.array_equal(g[:, :5000], np.zeros((2, 5000), np.float32)) and np.array_equal(r[:, :5000], np.zeros((2, 5000)))
+    assert_parity(g, r, f"{taps} taps, host blocks of up to 8192 frames")
