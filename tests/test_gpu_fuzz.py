@@ -68,7 +68,7 @@ def test_fuzz_engine_eq_chain(ohs, synth, oracle, seed):
     for p in range(4):
         h = _random_ir(rng, int(rng.choice([64, 512, 700])))
         eg.set_ir(p, h); eo.set_ir(p, h)
-    sizes = [1, 7, 64, 511, 512, 513, 1024, 1024, 1024, 1500, 2048, 3000, 4096, 9000]
+    sizes = [1, 7, 64, 511, 512, 513, 1024, 1024, 1024, 1500, 2048, 3000, 4096, 5000, 8192, 9000]
     stream = synth.white_noise([200 + seed], 45 * 9000)[0]        # 45 steps of <= 9000 frames
     pos = 0
     got, ref = [], []
