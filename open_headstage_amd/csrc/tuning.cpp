@@ -30,7 +30,7 @@ const struct { const char *env, *key; } kEnvKeys[] = {
     {"OHS_P1_TARGET_WAVES", "p1_target_waves"}, {"OHS_P1_ROUNDS", "p1_rounds"}, {"OHS_P1_OWN_TAILS", "p1_own_tails"},
     {"OHS_P1_STAGGER", "p1_stagger"}, {"OHS_P1_PRIO", "p1_prio"}, {"OHS_P1_WEIGHTS", "p1_weights"},
     {"OHS_P1_LAZY_STATE", "p1_lazy_state"}, {"OHS_P1_XCD", "p1_xcd"}, {"OHS_EQ_XCD", "eq_xcd"},
-    {"OHS_EQ_CONVEYOR", "eq_conveyor"}, {"OHS_EQ_RING_V1", "eq_ring_v1"}, {"OHS_EQ_NO_PRIO", "eq_no_prio"},
+    {"OHS_EQ_CONVEYOR", "eq_conveyor"}, {"OHS_EQ_RING_V1", "eq_ring_v1"}, {"OHS_EQ_NO_PRIO", "eq_no_prio"}, {"OHS_EQ_FORM", "eq_form"},
     {"OHS_EQ_WG_WAVES", "eq_wg_waves"}, {"OHS_EQ_LDS", "eq_lds"}, {"OHS_NO_OVERLAP", "no_overlap"},
     {"OHS_FORCE_OVERLAP", "force_overlap"}, {"OHS_XCD_SPLIT", "xcd_split"}, {"OHS_OVERLAP_CUTS", "overlap_cuts"},
     {"OHS_CONV_CU_MASK", "conv_cu_mask"}, {"OHS_MAC_NO_XCD", "mac_no_xcd"}, {"OHS_HOST_PIPE_TRACE", "host_pipe_trace"},
@@ -92,6 +92,7 @@ bool tuning_set(const std::string &key, const std::string &value)
     if (key == "eq_conveyor") return one(&t.eq_conveyor);
     if (key == "eq_ring_v1") return one(&t.eq_ring_v1);
     if (key == "eq_no_prio") return one(&t.eq_no_prio);
+    if (key == "eq_form") return one(&t.eq_form);
     if (key == "eq_wg_waves") {
         if (!one(&t.eq_wg_waves)) return false;
         const int w = t.eq_wg_waves;

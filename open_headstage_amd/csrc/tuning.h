@@ -28,6 +28,8 @@ struct Tuning {
     int eq_conveyor = 0;                    // k_eq_pass also for <= 12 bands
     int eq_ring_v1 = 0;                     // round 2's 114-VGPR ring kernel (experiments build only)
     int eq_no_prio = 0;                     // no s_setprio 3 in k_eq_ring
+    int eq_form = 0;                        // k_eq_ring's form: 0 = the library's choice, 1 = four chains per wave (16-lane rows), 2 = one chain
+                                            // per wave (the ring over all 64 lanes: eq_ring64_body.hpp)
     int eq_wg_waves = 0;                    // 0: 1 wave per workgroup below one wave per CU, else 4
     int eq_lds = 0;                         // LDS reservation per EQ workgroup, bytes
     // ohs_batch_process

@@ -27,12 +27,18 @@ G = 48                      # samples per group = conveyor length (rows 1..3)
 FULL = "row_mask:0xf bank_mask:0xf"
 ROWS123 = "quad_perm:[0,1,2,3] row_mask:0xe bank_mask:0xf"
 
-O = f"v_add_f32_dpp v2, v4, v10 wave_ror:1 {FULL}"
-T = f"v_add_f32_dpp v6, v5, v11 wave_ror:1 {FULL}"
+# PROTO_VARIANT: "wave" (default) all three DPP instructions wave_ror:1; "o" only O -- T and M feed the band lanes, which all
+# sit in row 0 and read their left neighbour in row 0 (a pass-on lane's T / M results are zeros whichever lane it reads);
+# "row" all three row_ror:1 (NOT a conveyor: wrong results, the timing reference of this loop)
+VARIANT = os.environ.get("PROTO_VARIANT", "wave")
+RO = "row_ror:1" if VARIANT == "row" else "wave_ror:1"
+RT = "wave_ror:1" if VARIANT == "wave" else "row_ror:1"
+O = f"v_add_f32_dpp v2, v4, v10 {RO} {FULL}"
+T = f"v_add_f32_dpp v6, v5, v11 {RT} {FULL}"
 A = "v_pk_mul_f32 v[8:9], v[14:15], v[2:3] op_sel_hi:[1,0]"
 P = "v_pk_mul_f32 v[4:5], v[12:13], v[2:3] op_sel_hi:[1,0]"
 N = "v_pk_add_f32 v[10:11], v[6:7], v[8:9] neg_lo:[0,1] neg_hi:[0,1]"
-M = f"v_mul_f32_dpp v7, v2, v1 wave_ror:1 {FULL}"
+M = f"v_mul_f32_dpp v7, v2, v1 {RT} {FULL}"
 
 
 def group():
@@ -55,7 +61,7 @@ def group():
 
 
 def main():
-    body = ["1:"] + group() + ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "s_waitcnt vmcnt(0)", "s_nop 1"]
+    body = [".p2align 5", "1:"] + group() + ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "s_waitcnt vmcnt(0)", "s_nop 1"]
     asm = "\n".join('        "' + l + '\\n"' for l in body)
     n_valu = sum(1 for l in group() if l.startswith("v_") and not l.startswith("v_add_u32"))
     src = r'''
@@ -92,10 +98,13 @@ __global__ __launch_bounds__(64) void k(const float *src, float *dst, long long 
     // during it); the host finds the lag
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     asm volatile(
+        ".p2align 5\n"
         "s_nop 4\n"
+        "s_nop 0\n"
         "%(P)s\n"
         "%(M)s\n"
         "s_nop 1\n"
+        "s_nop 0\n"
 %(asm)s
         : [X] "+{v2}"(X), [st] "+{v3}"(st), [u] "+{v[4:5]}"(u), [b2x] "+{v7}"(b2x), [s] "+{v[10:11]}"(s), [voff] "+{v0}"(off),
           [xin] "+{v16}"(xin1), [cnt] "+s"(cnt)
@@ -187,8 +196,8 @@ int main()
     open(path, "w").write(src)
     os.makedirs(os.path.join(HERE, "bin"), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-w", "-ffp-contract=off", "--offload-arch=gfx950", "-o",
-                    os.path.join(HERE, "bin", "proto_eq_wave_ring"), path], check=True)
-    print("built tools/bin/proto_eq_wave_ring;", n_valu, "VALU per", G, "samples")
+                    os.path.join(HERE, "bin", "proto_eq_wave_ring" + ("" if VARIANT == "wave" else "_" + VARIANT)), path], check=True)
+    print("built tools/bin/proto_eq_wave_ring (variant", VARIANT + ");", n_valu, "VALU per", G, "samples")
 
 
 if __name__ == "__main__":
