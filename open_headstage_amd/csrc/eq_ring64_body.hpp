@@ -79,7 +79,8 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
     const v2f pb01 = {c.pb0, c.pb1}, a12 = {c.a1, c.a2};
     unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane(groups);
     unsigned kg = kR64Group * 4;                        // (not const: the host pass of hipcc refuses constants as asm operands)
-    unsigned long long mrows = 0xFFFFFFFFFFFF0000ull;   // rows 1 .. 3
+    unsigned mlo = 0xFFFF0000u;                         // EXEC's low half with row 0 off (a 64-bit literal would reach the
+                                                        // scalar unit as its low 32 bits, zero-extended: rows 2 and 3 off as well)
     asm volatile(
         ".p2align 5\n"
         "s_nop 1\n"
@@ -91,11 +92,11 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
         "s_nop 0\n"
         "v_mov_b32_dpp v3, v2 " R64_ROWS123
         "v_mov_b32_dpp v2, v16 " R64_ROWS123
-        "s_mov_b64 exec, %[mrows]\n"
+        "s_mov_b32 exec_lo, %[mlo]\n"
         "s_nop 0\n"
         "global_store_dword v0, v3, %[dst] offset:-64\n"
         "global_load_dword v16, v0, %[src] offset:384\n"
-        "s_mov_b64 exec, -1\n"
+        "s_mov_b32 exec_lo, -1\n"
         "v_add_u32_e32 v0, %[kg], v0\n"
         R64_P R64_N R64_M
         "s_sub_u32 %[cnt], %[cnt], 1\n"
@@ -107,7 +108,7 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
         : [X] "+{v2}"(r.X), [st] "+{v3}"(r.st), [u] "+{v[4:5]}"(r.u), [b2x] "+{v7}"(r.b2x), [s] "+{v[10:11]}"(r.s),
           [voff] "+{v0}"(lane_off), [xin] "+{v16}"(xnext), [cnt] "+s"(cnt)
         : [b2] "{v1}"(c.b2), [pb01] "{v[12:13]}"(pb01), [a12] "{v[14:15]}"(a12), [src] "s"(src), [dst] "s"(dst), [kg] "s"(kg),
-          [mrows] "s"(mrows)
+          [mlo] "s"(mlo)
         : "v6", "v8", "v9", "memory", "scc");
 }
 
