@@ -61,7 +61,8 @@ STREAMS_PER_GPU = 256
 TAPS = 512
 FS = 48000.0
 NOMINAL_CLOCK_GHZ = 2.4        # same guide: max clock; only used to express the EQ's ns per sample in cycles
-EQ_ISSUE_FLOOR_CYCLES = 26.7   # 6.5 VALU per sample x 4.1 cycles per instruction of a lone wave
+EQ_ISSUE_FLOOR_CYCLES = 26.7   # 6.5 VALU per sample x 4.1 cycles per instruction of a lone wave: four chains per wave
+EQ_ISSUE_FLOOR_CYCLES_WAVE_RING = 24.8     # 6.04 VALU per sample x 4.1: one chain per wave, the ring over all 64 lanes (eq_ring64_body.hpp)
 # ohs_batch_last_conv_plan's kernel family -> the kernel that dominates it (the name rocprofv3 shows)
 KERNEL_OF_FAMILY = {"block512_p1": "k_conv_p1", "hop1536_p1": "k_conv_p1_os", "block512_tp": "k_conv_tp_mac",
                     "block2048": "k_conv_lb_mac_inverse", "block8192": "k_conv_xb", "sequential": "k_conv_general", "none": "none"}
@@ -729,6 +730,8 @@ def main() -> int:
             # the counters are collected live only by the default one-GPU run (two rocprofv3 --pmc child runs)
             traffic_source = "FALLBACK, not measured in this run: " + traffic_source
         ns_per_sample = eq_ms / max(n_calls, 1) * 1e6 / frames
+        eq_wave_ring = 2 * S <= 2 * torch.cuda.get_device_properties(device).multi_processor_count and frames // 6 >= 8192
+        eq_floor = EQ_ISSUE_FLOOR_CYCLES_WAVE_RING if eq_wave_ring else EQ_ISSUE_FLOOR_CYCLES
         eq_is_dom = dom == eq_name
         out = {
             "metric": METRIC,
@@ -788,8 +791,13 @@ def main() -> int:
                                     if eq_clock_ghz else f"NOMINAL {NOMINAL_CLOCK_GHZ} GHz (no ring-form launch to measure)",
                     "cycles_per_sample": round(ns_per_sample * (eq_clock_ghz or NOMINAL_CLOCK_GHZ), 2),
                     "cycles_per_sample_at_2p4GHz": round(ns_per_sample * NOMINAL_CLOCK_GHZ, 2),
-                    "cycles_per_sample_floor": EQ_ISSUE_FLOOR_CYCLES,
-                    "frac_of_floor": round(EQ_ISSUE_FLOOR_CYCLES / max(ns_per_sample * (eq_clock_ghz or NOMINAL_CLOCK_GHZ), 1e-9), 4),
+                    # k_eq_ring has two forms (same bits); which one a launch takes is launch_eq_pass's rule (eq_kernels.hip), quoted
+                    # here because the C ABI has no entry that reports it: one chain per wave up to two chains per CU
+                    # (2 x streams <= 2 x CUs) when the launch is 8 192 samples or longer, else four chains per wave
+                    "form": "one chain per wave (ring over 64 lanes), 6.04 VALU per sample" if eq_wave_ring
+                            else "four chains per wave (16-lane rows), 6.5 VALU per sample",
+                    "cycles_per_sample_floor": eq_floor,
+                    "frac_of_floor": round(eq_floor / max(ns_per_sample * (eq_clock_ghz or NOMINAL_CLOCK_GHZ), 1e-9), 4),
                 } if eq_is_dom else None,
                 # the convolution kernel, which runs underneath the EQ here and sets the rate from ~1000 streams up:
                 # bytes it really moves (16 B per frame + chunk tails), NOT the per-block model it does not execute;
