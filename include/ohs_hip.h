@@ -174,7 +174,9 @@ int  ohs_eq_get_band_coeffs(const ohs_eq *eq, size_t band, float coeffs[5], int 
 /* process_block(&mut [f32], &mut [f32]) in place  parametric_eq.rs:166-179.  Same products and sums
  * in the same order, each rounded separately: bit-identical to the reference's DF2T recurrence for
  * finite samples, except that a -0.0 may come out as +0.0; a non-finite INPUT sample makes the output
- * non-finite from up to 16 samples before it (the reference: from that sample on).  DESIGN.md 4.5, LABNOTES.md. */
+ * non-finite from up to 16 samples before it -- up to 64 in long launches on few chains, where a chain has a wave of
+ * its own and 48 samples travel through its pass-on lanes at a time -- (the reference: from that sample on).  DESIGN.md 4.5,
+ * LABNOTES.md. */
 int  ohs_eq_process_block(ohs_eq *eq, float *left, float *right, size_t n);
 /* Opt-in exactness for the two special-value corners above (default off): with enable != 0 the EQ runs its
  * "conveyor" kernel, in which samples move between lanes by register moves only -- a -0.0 stays -0.0 and a

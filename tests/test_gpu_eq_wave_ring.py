@@ -102,3 +102,29 @@ def test_the_product_librarys_own_choice_on_long_calls(ohs, synth, oracle):
     eg, eo = _pair(ohs, oracle, synth.eq_table())
     x = synth.white_noise([34], 50000)[0]
     _same_bits(eg, eo, x, [20000, 9000, 21000], "library's choice")
+
+
+def test_documented_edge_cases_of_the_wave_ring(ohs, synth, oracle, forced_form):
+    """include/ohs_hip.h: the ring kernels' pass-on lanes compute 1 * x + 0.  A -0.0 sample may come out as +0.0 (equal as
+    numbers, every other sample bit-exact); a non-finite input sample makes the output non-finite from up to 16 samples
+    before it in the row form, up to 64 in the wave ring (48 samples travel through a chain's pass-on lanes at a time) --
+    everything earlier is bit-exact, and from that sample on the reference's output is non-finite as well."""
+    eg, eo = _pair(ohs, oracle, synth.eq_table())
+    n = 12000
+    x = synth.white_noise([35], n)[0]
+    x[:, 1000:1100] = -0.0
+    gl, gr = x[0].copy(), x[1].copy(); ol, orr = x[0].copy(), x[1].copy()
+    eg.process_block(gl, gr); eo.process_block(ol, orr)
+    assert np.array_equal(gl, ol) and np.array_equal(gr, orr)
+    nz = ol != 0
+    assert np.array_equal(gl[nz].view(np.uint32), ol[nz].view(np.uint32))
+    eg, eo = _pair(ohs, oracle, synth.eq_table())
+    x = synth.white_noise([36], n)[0]
+    k = 7013
+    x[0, k] = np.nan
+    gl, gr = x[0].copy(), x[1].copy(); ol, orr = x[0].copy(), x[1].copy()
+    eg.process_block(gl, gr); eo.process_block(ol, orr)
+    reach = 64 if forced_form == 2 else 16
+    assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32))
+    assert np.array_equal(gl[:k - reach].view(np.uint32), ol[:k - reach].view(np.uint32))
+    assert np.isnan(ol[k:]).all() and np.isnan(gl[k:]).all()
