@@ -114,28 +114,45 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
 
 // One WAVE = one chain: chain `chain` of n_chains, the whole of n samples, state read at entry and written back at exit.
 // No barrier, no LDS.  Same addressing limits as the row form (eq_ring2_addressable).
-__device__ __forceinline__ void eq_ring64_wave(const float *in, float *out, long long stream_stride, long long ch_stride,
-                                               long long n, int n_chains, int nb, const EqPassTable &tab,
-                                               float *__restrict__ state, long long chain)
+// PER_STREAM: the chain's stream owns its bands (parametric_eq.rs:125-129) -- constants, state slots and the NUMBER of enabled
+// bands come from stabs[chain / 2] (kernels.h: EqStreamTable) instead of the launch's one table.
+template <bool PER_STREAM>
+__device__ __forceinline__ void eq_ring64_wave_t(const float *in, float *out, long long stream_stride, long long ch_stride,
+                                                 long long n, int n_chains, int nb_shared, const EqPassTable &tab,
+                                                 const EqStreamTable *__restrict__ stabs, float *__restrict__ state, long long chain)
 {
     constexpr int G = kR64Group;
     if (chain >= n_chains) return;
     const int lane = threadIdx.x & 63;
     const int n32 = (int)n;
+    int nb = nb_shared;
+    if constexpr (PER_STREAM) nb = stabs[chain >> 1].nb;
     const bool pre = lane < nb, band = lane >= 1 && lane <= nb;
-    const int jb = band ? lane - 1 : 0;
+    const int jb = band ? lane - 1 : 0, jp = pre ? lane : 0;
     RingLane c;
-    c.pb0 = pre ? tab.b0[lane & 15] : 1.0f;
-    c.pb1 = pre ? tab.b1[lane & 15] : 0.0f;
-    c.b2 = band ? tab.b2[jb] : 0.0f;
-    c.a1 = band ? tab.a1[jb] : 0.0f;
-    c.a2 = band ? tab.a2[jb] : 0.0f;
+    int slot;
+    if constexpr (PER_STREAM) {
+        const EqStreamTable *T = stabs + (chain >> 1);
+        c.pb0 = pre ? T->b0[jp] : 1.0f;
+        c.pb1 = pre ? T->b1[jp] : 0.0f;
+        c.b2 = band ? T->b2[jb] : 0.0f;
+        c.a1 = band ? T->a1[jb] : 0.0f;
+        c.a2 = band ? T->a2[jb] : 0.0f;
+        slot = T->slot[jb];
+    } else {
+        c.pb0 = pre ? tab.b0[jp] : 1.0f;
+        c.pb1 = pre ? tab.b1[jp] : 0.0f;
+        c.b2 = band ? tab.b2[jb] : 0.0f;
+        c.a1 = band ? tab.a1[jb] : 0.0f;
+        c.a2 = band ? tab.a2[jb] : 0.0f;
+        slot = tab.slot[jb];
+    }
     // wave-uniform bases + per-lane 32-bit byte offsets (rows 1 .. 3: lane 63 - i <-> sample i of a group)
     const long long base = (chain >> 1) * stream_stride + (chain & 1) * ch_stride;
     const float *src0 = in + base;
     float *dst0 = out + base;
     float *state0 = state + chain * (kEqStateSlots * 2);
-    const unsigned state_off = (unsigned)(tab.slot[jb] * 2) * 4u;
+    const unsigned state_off = (unsigned)(slot * 2) * 4u;
     const bool conv = lane >= 16;
     unsigned lane_off = (unsigned)(63 - lane) * 4u;
     v2f s_init = {0.0f, 0.0f};
@@ -191,6 +208,14 @@ __device__ __forceinline__ void eq_ring64_wave(const float *in, float *out, long
         ring2_st(state0, state_off, s_save.x);
         ring2_st(state0, state_off + 4u, s_save.y);
     }
+}
+
+// the shared-table form
+__device__ __forceinline__ void eq_ring64_wave(const float *in, float *out, long long stream_stride, long long ch_stride,
+                                               long long n, int n_chains, int nb, const EqPassTable &tab,
+                                               float *__restrict__ state, long long chain)
+{
+    eq_ring64_wave_t<false>(in, out, stream_stride, ch_stride, n, n_chains, nb, tab, nullptr, state, chain);
 }
 
 }  // namespace ohs

@@ -56,10 +56,11 @@ def _conv_only(ohs, synth, S, irs, gain):
     return bp
 
 
-@pytest.mark.parametrize("blocks", [[20, 7], [70, 66]])
+@pytest.mark.parametrize("blocks", [[20, 7], [70, 66], [130, 101]])
 def test_nine_streams_nine_tables_bit_exact_against_nine_oracle_eqs(oracle, blocks):
     """two calls each (the EQ state carries over); [70, 66]: calls long enough for the EQ || convolution overlap, i.e. six EQ
-    launches per call, each reading the tables again"""
+    launches per call, each reading the tables again; [130, 101]: launches of 8 192 samples or more, which take the EQ's
+    wave-ring form (one chain per wave, csrc/eq_ring64_body.hpp) with every chain's own table"""
     import torch
     import open_headstage_amd as ohs
     from open_headstage_amd import synth
