@@ -69,12 +69,15 @@ __device__ __forceinline__ void ring64_pm(Ring64Regs &r, const RingLane &c)
 #define R64_STEPS47 R64_X32(R64_STEP) R64_X8(R64_STEP) R64_X4(R64_STEP) R64_X2(R64_STEP) R64_STEP
 #define R64_ROWS123 "quad_perm:[0,1,2,3] row_mask:0xe bank_mask:0xf\n"
 
-// `groups` >= 1 interior groups in ONE statement: every sample they load, filter and store exists, no band starts or
-// ends inside them.  On entry: the first step's P and M have run (by the C++ form), v16 = the inputs of the group BEHIND
-// the first one here, v0 = this lane's byte offset of the first group's input slot.  Every 8-byte encoding is 8-byte
-// aligned (a lone wave pays for one that straddles a fetch line); the vector-memory instructions run with row 0 masked.
+// `groups` >= 1 interior groups in ONE statement: every sample they filter and store exists, no band starts or ends
+// inside them.  Their loads run two groups ahead and may reach beyond the launch's last sample: the address is clamped to
+// that sample's (`max_load_off`), so what arrives there is a copy of it instead of the zero the C++ form puts -- harmless:
+// every band's state has left its lane before such a value reaches it, and outputs beyond n are never stored.
+// On entry: the first step's P and M have run (by the C++ form), v16 = the inputs of the group BEHIND the first one here,
+// v0 = this lane's byte offset of the first group's input slot.  Every 8-byte encoding is 8-byte aligned (a lone wave pays
+// for one that straddles a fetch line); the vector-memory instructions run with row 0 masked.
 __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &r, float &xnext, unsigned &lane_off,
-                                                 const float *src, float *dst, int groups)
+                                                 const float *src, float *dst, int groups, unsigned max_load_off)
 {
     const v2f pb01 = {c.pb0, c.pb1}, a12 = {c.a1, c.a2};
     unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane(groups);
@@ -93,9 +96,9 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
         "v_mov_b32_dpp v3, v2 " R64_ROWS123
         "v_mov_b32_dpp v2, v16 " R64_ROWS123
         "s_mov_b32 exec_lo, %[mlo]\n"
-        "s_nop 0\n"
+        "v_min_u32_e32 v17, %[maxo], v0\n"
         "global_store_dword v0, v3, %[dst] offset:-64\n"
-        "global_load_dword v16, v0, %[src] offset:384\n"
+        "global_load_dword v16, v17, %[src] offset:384\n"
         "s_mov_b32 exec_lo, -1\n"
         "v_add_u32_e32 v0, %[kg], v0\n"
         R64_P R64_N R64_M
@@ -108,8 +111,8 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
         : [X] "+{v2}"(r.X), [st] "+{v3}"(r.st), [u] "+{v[4:5]}"(r.u), [b2x] "+{v7}"(r.b2x), [s] "+{v[10:11]}"(r.s),
           [voff] "+{v0}"(lane_off), [xin] "+{v16}"(xnext), [cnt] "+s"(cnt)
         : [b2] "{v1}"(c.b2), [pb01] "{v[12:13]}"(pb01), [a12] "{v[14:15]}"(a12), [src] "s"(src), [dst] "s"(dst), [kg] "s"(kg),
-          [mlo] "s"(mlo)
-        : "v6", "v8", "v9", "memory", "scc");
+          [mlo] "s"(mlo), [maxo] "s"(max_load_off)
+        : "v6", "v8", "v9", "v17", "memory", "scc");
 }
 
 // One WAVE = one chain: chain `chain` of n_chains, the whole of n samples, state read at entry and written back at exit.
@@ -197,10 +200,12 @@ __device__ __forceinline__ void eq_ring64_wave_t(const float *in, float *out, lo
     const int g_total = (n32 + 16 + G - 1) / G;
     group_cpp(0);
     int g = 1;
-    const int n_asm = n32 / G - 3;                  // groups 1 .. n / 48 - 3: everything in bounds, no band starts or ends
+    // groups 1 .. n / 48 - 1: every step filters existing samples (the last of them ends at step 48 (n / 48) <= n: the
+    // first state leaves behind step n + 1), every store lands below n
+    const int n_asm = n32 >= 4 * G ? n32 / G - 1 : 0;
     if (n_asm >= 1) {
         lane_off += (unsigned)(G * 4);
-        eq_ring64_groups(c, r, xnext, lane_off, src0, dst0, n_asm);
+        eq_ring64_groups(c, r, xnext, lane_off, src0, dst0, n_asm, (unsigned)(n32 - 1) * 4u - 384u);
         g += n_asm;
     }
     for (; g < g_total; ++g) group_cpp(g);
