@@ -69,18 +69,40 @@ __device__ __forceinline__ void ring64_pm(Ring64Regs &r, const RingLane &c)
 #define R64_STEPS47 R64_X32(R64_STEP) R64_X8(R64_STEP) R64_X4(R64_STEP) R64_X2(R64_STEP) R64_STEP
 #define R64_ROWS123 "quad_perm:[0,1,2,3] row_mask:0xe bank_mask:0xf\n"
 
-// `groups` >= 1 interior groups in ONE statement: every sample they filter and store exists, no band starts or ends
-// inside them.  Their loads run two groups ahead and may reach beyond the launch's last sample: the address is clamped to
-// that sample's (`max_load_off`), so what arrives there is a copy of it instead of the zero the C++ form puts -- harmless:
-// every band's state has left its lane before such a value reaches it, and outputs beyond n are never stored.
-// On entry: the first step's P and M have run (by the C++ form), v16 = the inputs of the group BEHIND the first one here,
-// v0 = this lane's byte offset of the first group's input slot.  Every 8-byte encoding is 8-byte aligned (a lone wave pays
-// for one that straddles a fetch line); the vector-memory instructions run with row 0 masked.
-__device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &r, float &xnext, unsigned &lane_off,
-                                                 const float *src, float *dst, int groups, unsigned max_load_off)
+// One interior group as asm text: 47 plain steps, the port step (the input register REG is injected and refilled in place).
+#define R64_GROUP(REG) \
+        R64_STEPS47 \
+        R64_O R64_T R64_A \
+        "s_waitcnt vmcnt(2)\n" \
+        "s_nop 0\n" \
+        "v_mov_b32_dpp v3, v2 " R64_ROWS123 \
+        "v_mov_b32_dpp v2, " REG " " R64_ROWS123 \
+        "s_mov_b32 exec_lo, %[mlo]\n" \
+        "v_min_u32_e32 v18, %[maxo], v0\n" \
+        "global_store_dword v0, v3, %[dst] offset:-64\n" \
+        "global_load_dword " REG ", v18, %[src] offset:576\n" \
+        "s_mov_b32 exec_lo, -1\n" \
+        "v_add_u32_e32 v0, %[kg], v0\n" \
+        R64_P R64_N R64_M
+
+// `pairs` >= 1 PAIRS of interior groups in ONE statement: every sample they filter and store exists, no band starts or
+// ends inside them.  The input register is double-buffered (v16: even groups, v17: odd ones): the port of group g injects
+// group g + 1, requested at port g - 2, and requests group g + 3 into the register it has just emptied -- 96 steps =
+// ~1.06 us between a load and its use (with one register and 48 steps the wave waited for memory at every port: the
+// prototype, alone on the chip, 11.05 -> 10.88 ns per sample; profiles/r05_proto_eq_wave_ring_ahead.txt).  In front of a
+// port the store and the load of the previous port may still be in flight: vmcnt(2) (they retire in issue order).
+// Loads may reach beyond the launch's last sample: the address is clamped to that sample's (`max_load_off`), so what
+// arrives there is a copy of it instead of the zero the C++ form puts -- harmless: every band's state has left its lane
+// before such a value reaches it, and outputs beyond n are never stored.
+// On entry: the first step's P and M have run (by the C++ form), v16 / v17 = the inputs of the two groups BEHIND the first
+// one here, v0 = this lane's byte offset of the first group's input slot; on exit v16 = the inputs of the group behind the
+// next one.  Every 8-byte encoding is 8-byte aligned (a lone wave pays for one that straddles a fetch line); the
+// vector-memory instructions run with row 0 masked.
+__device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &r, float &xnext, float xnext2, unsigned &lane_off,
+                                                 const float *src, float *dst, int pairs, unsigned max_load_off)
 {
     const v2f pb01 = {c.pb0, c.pb1}, a12 = {c.a1, c.a2};
-    unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane(groups);
+    unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane(pairs);
     unsigned kg = kR64Group * 4;                        // (not const: the host pass of hipcc refuses constants as asm operands)
     unsigned mlo = 0xFFFF0000u;                         // EXEC's low half with row 0 off (a 64-bit literal would reach the
                                                         // scalar unit as its low 32 bits, zero-extended: rows 2 and 3 off as well)
@@ -89,19 +111,8 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
         "s_nop 1\n"
         "s_nop 0\n"
         "1:\n"
-        R64_STEPS47
-        R64_O R64_T R64_A
-        "s_waitcnt vmcnt(0)\n"              // the store and the load issued one group ago (they retire in issue order)
-        "s_nop 0\n"
-        "v_mov_b32_dpp v3, v2 " R64_ROWS123
-        "v_mov_b32_dpp v2, v16 " R64_ROWS123
-        "s_mov_b32 exec_lo, %[mlo]\n"
-        "v_min_u32_e32 v17, %[maxo], v0\n"
-        "global_store_dword v0, v3, %[dst] offset:-64\n"
-        "global_load_dword v16, v17, %[src] offset:384\n"
-        "s_mov_b32 exec_lo, -1\n"
-        "v_add_u32_e32 v0, %[kg], v0\n"
-        R64_P R64_N R64_M
+        R64_GROUP("v16")
+        R64_GROUP("v17")
         "s_sub_u32 %[cnt], %[cnt], 1\n"
         "s_cmp_lg_u32 %[cnt], 0\n"
         "s_cbranch_scc1 1b\n"
@@ -109,14 +120,12 @@ __device__ __forceinline__ void eq_ring64_groups(const RingLane &c, Ring64Regs &
         "s_waitcnt vmcnt(0)\n"
         "s_nop 1\n"
         : [X] "+{v2}"(r.X), [st] "+{v3}"(r.st), [u] "+{v[4:5]}"(r.u), [b2x] "+{v7}"(r.b2x), [s] "+{v[10:11]}"(r.s),
-          [voff] "+{v0}"(lane_off), [xin] "+{v16}"(xnext), [cnt] "+s"(cnt)
+          [voff] "+{v0}"(lane_off), [xa] "+{v16}"(xnext), [xb] "+{v17}"(xnext2), [cnt] "+s"(cnt)
         : [b2] "{v1}"(c.b2), [pb01] "{v[12:13]}"(pb01), [a12] "{v[14:15]}"(a12), [src] "s"(src), [dst] "s"(dst), [kg] "s"(kg),
           [mlo] "s"(mlo), [maxo] "s"(max_load_off)
-        : "v6", "v8", "v9", "v17", "memory", "scc");
+        : "v6", "v8", "v9", "v18", "memory", "scc");
 }
 
-// One WAVE = one chain: chain `chain` of n_chains, the whole of n samples, state read at entry and written back at exit.
-// No barrier, no LDS.  Same addressing limits as the row form (eq_ring2_addressable).
 // PER_STREAM: the chain's stream owns its bands (parametric_eq.rs:125-129) -- constants, state slots and the NUMBER of enabled
 // bands come from stabs[chain / 2] (kernels.h: EqStreamTable) instead of the launch's one table.
 template <bool PER_STREAM>
@@ -200,13 +209,14 @@ __device__ __forceinline__ void eq_ring64_wave_t(const float *in, float *out, lo
     const int g_total = (n32 + 16 + G - 1) / G;
     group_cpp(0);
     int g = 1;
-    // groups 1 .. n / 48 - 1: every step filters existing samples (the last of them ends at step 48 (n / 48) <= n: the
-    // first state leaves behind step n + 1), every store lands below n
-    const int n_asm = n32 >= 4 * G ? n32 / G - 1 : 0;
-    if (n_asm >= 1) {
+    // groups 1 .. n / 48 - 1, two at a time (an odd one left over runs in the C++ form): every step filters existing samples
+    // (the last of them ends at step 48 (n / 48) <= n: the first state leaves behind step n + 1), every store lands below n
+    const int n_pairs = n32 >= 4 * G ? (n32 / G - 1) / 2 : 0;
+    if (n_pairs >= 1) {
+        const float xnext2 = load_group(3);         // (exists: n >= 192)
         lane_off += (unsigned)(G * 4);
-        eq_ring64_groups(c, r, xnext, lane_off, src0, dst0, n_asm, (unsigned)(n32 - 1) * 4u - 384u);
-        g += n_asm;
+        eq_ring64_groups(c, r, xnext, xnext2, lane_off, src0, dst0, n_pairs, (unsigned)(n32 - 1) * 4u - 576u);
+        g += 2 * n_pairs;
     }
     for (; g < g_total; ++g) group_cpp(g);
     if (band) {

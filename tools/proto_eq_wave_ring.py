@@ -41,19 +41,24 @@ N = "v_pk_add_f32 v[10:11], v[6:7], v[8:9] neg_lo:[0,1] neg_hi:[0,1]"
 M = f"v_mul_f32_dpp v7, v2, v1 {RT} {FULL}"
 
 
-def group():
+# PROTO_AHEAD=2: the input register is double-buffered (v16 / v17, two groups per loop iteration): a load is consumed two
+# ports = 96 steps = ~1.06 us after its issue instead of 48 steps = ~0.53 us
+AHEAD = int(os.environ.get("PROTO_AHEAD", "1"))
+
+
+def group(reg="v16", wait="s_waitcnt vmcnt(0)", load_off=2 * G * 4):
     out = []
     for k in range(G):
         out += [O, T, A]
         if k == G - 1:
             # the port, in front of the NEXT step's P and M: the 48 outputs that have travelled into rows 1..3 leave, the
             # next 48 inputs take their place; the store and the reload of the input register go out back to back
-            out += ["s_waitcnt vmcnt(0)",                       # the store and the load issued one group ago (they retire in issue order)
+            out += [wait,                                       # the store and the load issued one group ago (they retire in issue order)
                     "s_nop 0",
                     f"v_mov_b32_dpp v3, v2 {ROWS123}",
-                    f"v_mov_b32_dpp v2, v16 {ROWS123}",
+                    f"v_mov_b32_dpp v2, {reg} {ROWS123}",
                     "global_store_dword v0, v3, %[dst]",
-                    f"global_load_dword v16, v0, %[src] offset:{2 * G * 4}",
+                    f"global_load_dword {reg}, v0, %[src] offset:{load_off}",
                     "v_add_u32_e32 v0, %[kg], v0",
                     "s_nop 0"]
         out += [P, N, M]
@@ -61,7 +66,13 @@ def group():
 
 
 def main():
-    body = [".p2align 5", "1:"] + group() + ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "s_waitcnt vmcnt(0)", "s_nop 1"]
+    if AHEAD == 2:
+        # port g injects group g + 1 (loaded at port g - 2) and requests group g + 3 into the register it has just emptied;
+        # in front of it the store and the load of port g - 1 may still be in flight: vmcnt(2)
+        two = group("v16", "s_waitcnt vmcnt(2)", 3 * G * 4) + group("v17", "s_waitcnt vmcnt(2)", 3 * G * 4)
+        body = [".p2align 5", "1:"] + two + ["s_sub_u32 %[cnt], %[cnt], 2", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "s_waitcnt vmcnt(0)", "s_nop 1"]
+    else:
+        body = [".p2align 5", "1:"] + group() + ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "s_waitcnt vmcnt(0)", "s_nop 1"]
     asm = "\n".join('        "' + l + '\\n"' for l in body)
     n_valu = sum(1 for l in group() if l.startswith("v_") and not l.startswith("v_add_u32"))
     src = r'''
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(64) void k(const float *src, float *dst, long long 
     // prologue: group 0's inputs into the conveyor, group 1's requested; the first step's P and M
     xin = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + off);
     float xin1 = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + off + G * 4);
+    float xin2 = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + off + 2 * G * 4);
     X = lane >= 16 ? xin : 0.0f;
     // dst is written one group late (the outputs captured at the end of group g are those that entered rows 1 .. 3
     // during it); the host finds the lag
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(64) void k(const float *src, float *dst, long long 
         "s_nop 0\n"
 %(asm)s
         : [X] "+{v2}"(X), [st] "+{v3}"(st), [u] "+{v[4:5]}"(u), [b2x] "+{v7}"(b2x), [s] "+{v[10:11]}"(s), [voff] "+{v0}"(off),
-          [xin] "+{v16}"(xin1), [cnt] "+s"(cnt)
+          [xin] "+{v16}"(xin1), [xin2] "+{v17}"(xin2), [cnt] "+s"(cnt)
         : [b2] "{v1}"(b2), [pb01] "{v[12:13]}"(pb01), [a12] "{v[14:15]}"(a12), [src] "s"(src), [dst] "s"(dst), [kg] "s"(kg)
         : "v6", "v8", "v9", "memory", "scc");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -139,7 +151,7 @@ int main()
         c.b0[b] = (float)((1.0 + al * A_) / a0); c.b1[b] = (float)(-2.0 * std::cos(w) / a0); c.b2[b] = (float)((1.0 - al * A_) / a0);
         c.a1[b] = (float)(-2.0 * std::cos(w) / a0); c.a2[b] = (float)((1.0 - al / A_) / a0);
     }
-    const int chains = 512, groups = 480256 / G + 1;        // 480 288 samples per chain
+    const int chains = 512, groups = (480256 / G + 2) & ~1;        // an even number of groups (PROTO_AHEAD=2 runs two per iteration)
     const long long n = (long long)groups * G, stride = 2 * (n + 4 * G);
     std::vector<float> hx((size_t)chains * stride, 0.0f);
     unsigned long long sd = 0x0A5EAD00ull;
@@ -196,7 +208,7 @@ int main()
     open(path, "w").write(src)
     os.makedirs(os.path.join(HERE, "bin"), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-w", "-ffp-contract=off", "--offload-arch=gfx950", "-o",
-                    os.path.join(HERE, "bin", "proto_eq_wave_ring" + ("" if VARIANT == "wave" else "_" + VARIANT)), path], check=True)
+                    os.path.join(HERE, "bin", "proto_eq_wave_ring" + ("" if VARIANT == "wave" else "_" + VARIANT) + ("_ahead2" if AHEAD == 2 else "")), path], check=True)
     print("built tools/bin/proto_eq_wave_ring (variant", VARIANT + ");", n_valu, "VALU per", G, "samples")
 
 
